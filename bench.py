@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- MVN log-likelihood evals/sec at N = 256 (BASELINE.json metric), one process per GPU.
+
+A "step" is one pass of the hot path over one batch of chains: one launch of the batched
+log-likelihood kernel over `--chains` chains (default 512, BASELINE.json configs[2]: synthetic
+256-dimensional problem, dense random Sigma, 512 chains on one MI355X).  Inputs are resident in
+HBM before the timed region.  With --gpus N > 1 (torchrun, RCCL) every rank evaluates its own 512
+chains (weak scaling; the path has no exchange step -- chains are independent).  `--swap-period P`
+adds the sampler-level exchange of config 5 (an all-gather of the per-chain log-likelihoods every
+P steps, mirroring MC3's SwapPeriod, app/Main.hs:477); it is off by default because it is not part
+of the likelihood path.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM (north_star);
+`cpu_baseline` times the CPU oracle (a restatement of the reference's algebra -- the Haskell
+toolchain is absent) on a bounded sample on rank 0's host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # vector fp64 FMA peak (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+
+
+def algorithmic_bytes_per_eval(n: int, batch: int) -> float:
+    """x (8n) + ll (8) + (mu (8n) + packed L (4n(n+1))) amortised over the launch."""
+    return 8.0 * n + 8.0 + (8.0 * n + 4.0 * n * (n + 1)) / batch
+
+
+def algorithmic_flops_per_eval(n: int) -> float:
+    return float(n) * n + 5.0 * n
+
+
+def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
+    """The oracle in the reference's own algebra (Sigma^-1 dgemv + ddot, one evaluation per call,
+    fresh dx buffer per call -- app/Probability.hs:167-173) on one host core."""
+    import oracle as O
+
+    P = np.linalg.inv(sigma)
+    logdet = float(np.linalg.slogdet(sigma)[1])
+    O.build(native=True, force=True)   # -march=native: always rebuild on the host that runs it
+    sample = X[: min(len(X), 512)]
+    O.logpdf_full_batch(mu, P, logdet, sample[:32], native=True)  # warm
+    t0 = time.perf_counter()
+    evals = 0
+    while True:
+        O.logpdf_full_batch(mu, P, logdet, sample, native=True)
+        evals += len(sample)
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or evals >= 400 * len(sample):
+            break
+    return {"value": evals / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{evals} evaluations (sweeps over {len(sample)} of the bench's chains, n={n}) in {dt:.1f} s; "
+                      "C restatement of app/Probability.hs:167-173 (Sigma^-1 form), gcc -O3 -march=native"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--n", type=int, default=256, help="MVN dimension")
+    ap.add_argument("--chains", type=int, default=512, help="chains per GPU")
+    ap.add_argument("--swap-period", type=int, default=0, help="all-gather ll every P steps (0 = off)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
+    ap.add_argument("--graph-chunk", type=int, default=100, help="steps captured per hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import mcmc_date_amd as M
+    from mcmc_date_amd import synthetic as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, B = args.n, args.chains
+    if args.kind in ("tree", "tree_grad"):
+        topo = S.random_topology((n + 3) // 2, seed=n)
+        n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=n)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma, device=local_rank)
+    X_host = S.sample_chains(mu, sigma, B, seed=n + 1000 * rank)
+    X = torch.as_tensor(X_host, device=dev)
+    ll = torch.empty(B, dtype=torch.float64, device=dev)
+    lib = M._capi.lib()
+
+    if args.kind == "logpdf":
+        def step():
+            lik.logpdf_into(X, ll)
+    elif args.kind == "grad":
+        G = torch.empty_like(X)
+
+        def step():
+            M._capi.check(lib.mcd_mvn_grad_batch(lik._h, X.data_ptr(), X.stride(0), B, 1,
+                                                 torch.cuda.current_stream().cuda_stream, ll.data_ptr(), G.data_ptr(), G.stride(0)))
+    else:
+        tl = lik.bind_tree(topo)
+        st = S.random_states(topo, B, seed=n + 1000 * rank).to(dev)
+        lj = torch.empty(B, dtype=torch.float64, device=dev)
+        gH, gR = torch.empty_like(st.heights), torch.empty_like(st.rates)
+        gt, gm = torch.empty_like(st.time_height), torch.empty_like(st.rate_mean)
+        if args.kind == "tree":
+            def step():
+                M._capi.check(lib.mcd_tree_loglik_batch(tl._t, st.heights.data_ptr(), st.rates.data_ptr(), st.heights.stride(0),
+                                                        st.time_height.data_ptr(), st.rate_mean.data_ptr(), B, 1,
+                                                        torch.cuda.current_stream().cuda_stream, ll.data_ptr(), lj.data_ptr()))
+        else:
+            def step():
+                M._capi.check(lib.mcd_tree_grad_batch(tl._t, st.heights.data_ptr(), st.rates.data_ptr(), st.heights.stride(0),
+                                                      st.time_height.data_ptr(), st.rate_mean.data_ptr(), B, 1,
+                                                      torch.cuda.current_stream().cuda_stream, ll.data_ptr(), gH.data_ptr(),
+                                                      gR.data_ptr(), gt.data_ptr(), gm.data_ptr()))
+
+    gathered = torch.empty(world * B, dtype=torch.float64, device=dev) if (world > 1 and args.swap_period > 0) else None
+    use_graph = (not args.no_graph) and gathered is None
+    K, W = args.steps, args.warmup
+
+    # --- build the launch schedule -----------------------------------------------------------
+    graphs = []
+    if use_graph:
+        chunk = max(1, min(args.graph_chunk, K))
+        sizes = sorted({chunk, K % chunk} - {0})
+        cap_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(cap_stream):
+            step()                                       # load the code object before capture
+        cap_stream.synchronize()
+        gmap = {}
+        for sz in sizes:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap_stream):
+                for _ in range(sz):
+                    step()
+            gmap[sz] = g
+
+        def run(k):
+            full, rem = divmod(k, chunk)
+            for _ in range(full):
+                gmap[chunk].replay()
+            if rem:
+                if rem in gmap:
+                    gmap[rem].replay()
+                else:
+                    for _ in range(rem):
+                        step()
+    else:
+        def run(k):
+            for i in range(k):
+                step()
+                if gathered is not None and (i + 1) % args.swap_period == 0:
+                    dist.all_gather_into_tensor(gathered, ll)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(W)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(K)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the result of the last step is the oracle-checked quantity (finite, right magnitude)
+    ll_host = ll.cpu().numpy()
+    assert np.all(np.isfinite(ll_host)), "non-finite log-likelihood in the bench batch"
+
+    if rank == 0:
+        evals = float(K) * B * world
+        per_launch_s = (dev_ms * 1e-3) / K
+        alg_b = algorithmic_bytes_per_eval(n, B) * B
+        achieved = alg_b / per_launch_s / 1e9
+        flops = algorithmic_flops_per_eval(n) * B / per_launch_s / 1e12
+        out = {
+            "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec x chains) at N=256 nodes",
+            "value": evals / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {n}-dimensional MVN (dense random SPD Sigma, seed {n}), {B} chains per GPU, "
+                                   f"kind={args.kind}", "n": n, "chains_per_gpu": B, "kernel": args.kind,
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "swap_period": args.swap_period, "parallelism": (f"chains sharded x{world}, no data-path collective" if gathered is None
+                                       else f"chains sharded x{world} + ll all-gather every {args.swap_period} steps")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_us_per_launch": per_launch_s * 1e6,
+                         "alg_bytes_per_launch": alg_b,
+                         "fp64_tflops": flops, "fp64_frac": flops / FP64_PEAK_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, mu, sigma, X_host)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

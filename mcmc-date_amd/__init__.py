@@ -1,0 +1,21 @@
+"""mcmc-date_amd -- MI355X-native MVN phylogenetic log-likelihood for McmcDate's sampler.
+
+One hot path, hand-written for gfx950, behind the reference's likelihood plugin surface:
+    likelihood_function(lhd, topology)  ~  likelihoodFunction :: LikelihoodData -> LikelihoodFunction I
+(app/Probability.hs:277-281).  See DESIGN.md and include/mcmcdate_mvn.h.
+"""
+from . import _capi
+from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating
+from .likelihood import (Full, LikelihoodData, MvnLikelihood, NoData, Sparse, TreeLikelihood, Univariate,
+                         jacobian_root_branch, likelihood_function, read_data_file, write_data_file)
+from .state import State, StateBatch
+from .tree import (Topology, TreeError, branch_slots, get_branches, height_tree_to_length_tree, parse_newick,
+                   read_newick_file, sum_first_two)
+
+__all__ = [
+    "Full", "Sparse", "Univariate", "NoData", "LikelihoodData", "MvnLikelihood", "TreeLikelihood",
+    "likelihood_function", "jacobian_root_branch", "read_data_file", "write_data_file",
+    "State", "StateBatch", "Topology", "TreeError", "parse_newick", "read_newick_file", "get_branches",
+    "sum_first_two", "branch_slots", "height_tree_to_length_tree",
+    "McdError", "NotPositiveDefinite", "RootNotBifurcating", "NoDevice",
+]

@@ -1,0 +1,97 @@
+"""ctypes binding of include/mcmcdate_mvn.h (libmcmcdate_mvn.so).
+
+The product has no CPU path: if the shared library is missing or no GPU is present, the calls
+below raise -- they never fall back to anything else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcmcdate_mvn.so")
+
+MCD_OK = 0
+MCD_ERR_INVALID_ARG = -1
+MCD_ERR_NOT_SPD = -2
+MCD_ERR_HIP = -3
+MCD_ERR_ROOT_NOT_BIFURCATING = -4
+MCD_ERR_NO_DEVICE = -5
+MCD_ERR_UNSUPPORTED = -6
+MCD_MAT_SIGMA = 0
+MCD_MAT_SIGMA_INV = 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/mcmcdate_mvn.h
+SYMBOLS = {
+    "mcd_device_count": (C.c_int, []),
+    "mcd_version": (C.c_char_p, []),
+    "mcd_last_error": (C.c_char_p, []),
+    "mcd_mvn_create": (C.c_int, [C.POINTER(_vp), C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_int]),
+    "mcd_mvn_destroy": (None, [_vp]),
+    "mcd_mvn_dim": (C.c_int, [_vp]),
+    "mcd_mvn_device": (C.c_int, [_vp]),
+    "mcd_mvn_logdet": (C.c_double, [_vp]),
+    "mcd_mvn_get_factor": (C.c_int, [_vp, _dp]),
+    "mcd_mvn_logpdf": (C.c_int, [_vp, _dp, _dp]),
+    "mcd_mvn_logpdf_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp]),
+    "mcd_mvn_grad_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int64]),
+    "mcd_tree_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, _ip]),
+    "mcd_tree_destroy": (None, [_vp]),
+    "mcd_tree_n_nodes": (C.c_int, [_vp]),
+    "mcd_tree_loglik_batch": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "mcd_tree_grad_batch": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class McdError(RuntimeError):
+    """Structural fault reported by the C ABI (the reference raises `error` for these)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+class NotPositiveDefinite(McdError):
+    pass
+
+
+class RootNotBifurcating(McdError):
+    pass
+
+
+class NoDevice(McdError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library.  Raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  mcmc-date_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc == MCD_OK:
+        return
+    msg = lib().mcd_last_error().decode()
+    cls = {MCD_ERR_NOT_SPD: NotPositiveDefinite, MCD_ERR_ROOT_NOT_BIFURCATING: RootNotBifurcating,
+           MCD_ERR_NO_DEVICE: NoDevice}.get(rc, McdError)
+    raise cls(rc, msg)

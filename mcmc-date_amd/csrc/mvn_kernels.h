@@ -1,0 +1,46 @@
+// mvn_kernels.h -- device-side operand descriptors and kernel launchers (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcd {
+
+// Immutable device operands of one MVN (created once per analysis; app/Main.hs:333-347 builds the
+// equivalent closure over mu, Sigma^-1, logdet in the reference).
+struct MvnDev {
+    int n;          // MVN dimension N (= 2 leaves - 3 for a tree)
+    int R;          // 64-row blocks per chain held in registers; NP = 64 R >= N
+    int ncols;      // columns swept (N rounded up to the chunk size of Cfg<R>)
+    double c;       // -N * ln sqrt(2 pi)                     (app/Probability.hs:172-173)
+    double logdet;  // log det Sigma
+    const double* mu;       // [NP], zero padded
+    const double* invdiag;  // [NP], 1 / L_ii, one padded
+    const double* Ft;       // forward factor  L[i][j]/L[i][i], pair-interleaved column layout, NP*NP
+    const double* Ut;       // backward factor L[i][r]/L[r][r], same layout, NP*NP
+};
+
+// Topology tables of the time/rate trees (pre-order node ids, root = 0).
+struct TreeDev {
+    int n_nodes;
+    int n_nodes_pad;
+    int root_right;           // second child of the root (the first one is node 1)
+    const int32_t* parent;    // [n_nodes]
+    const int32_t* slot_node; // [NP] node whose branch feeds distance slot i (slot 0: node 1), -1 padded
+    const int32_t* child_ptr; // [n_nodes + 1] CSR children
+    const int32_t* child_idx; // [n_nodes - 1]
+};
+
+int padded_blocks(int n);          // supported R for dimension n, or -1
+int sweep_chunk_columns(int R);    // columns per register buffer (ncols granularity)
+
+hipError_t launch_logpdf(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
+hipError_t launch_grad(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
+                       hipStream_t st);
+hipError_t launch_tree_logpdf(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                              const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
+                              hipStream_t st);
+hipError_t launch_tree_grad(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                            const double* tH, const double* rMu, int64_t batch, double* ll, double* gH, double* gR,
+                            double* gtH, double* grMu, hipStream_t st);
+
+}  // namespace mcd

@@ -1,0 +1,209 @@
+"""CPU oracle for the MVN log-likelihood path -- TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED (see oracle/mvn_oracle.c header): the reference has no golden vectors for
+this path and cannot be built here (Haskell, no GHC).  The oracle is a restatement.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  The product (mcmc-date_amd/) never does.
+
+`lib()` returns the ctypes handle of oracle/liboracle.so (built by oracle/Makefile, or by
+__graft_entry__.build()).  The thin wrappers below take/return numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_LIBS = {}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def build(native: bool = False, force: bool = False) -> str:
+    target = "liboracle_native.so" if native else "liboracle.so"
+    subprocess.run(["make", "-s"] + (["-B"] if force else []) + ["-C", _HERE, target], check=True)
+    _LIBS.pop(bool(native), None)
+    return os.path.join(_HERE, target)
+
+
+def lib(native: bool = False):
+    key = bool(native)
+    if key in _LIBS:
+        return _LIBS[key]
+    path = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+    src = os.path.join(_HERE, "mvn_oracle.c")
+    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+        build(native)
+    L = C.CDLL(path)
+    L.orc_logpdf_full.restype = C.c_double
+    L.orc_logpdf_full.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp]
+    L.orc_logpdf_full_ld.restype = C.c_longdouble
+    L.orc_logpdf_full_ld.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp]
+    L.orc_quadform_full.restype = C.c_double
+    L.orc_quadform_full.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.orc_logpdf_univariate.restype = C.c_double
+    L.orc_logpdf_univariate.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.orc_logpdf_sparse.restype = C.c_double
+    L.orc_logpdf_sparse.argtypes = [C.c_int, _dp, C.c_int64, _ip, _ip, _dp, C.c_double, _dp]
+    L.orc_cholesky.restype = C.c_int
+    L.orc_cholesky.argtypes = [C.c_int, _dp, _dp]
+    L.orc_quadform_chol.restype = C.c_double
+    L.orc_quadform_chol.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.orc_logpdf_chol.restype = C.c_double
+    L.orc_logpdf_chol.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.orc_grad_full.restype = None
+    L.orc_grad_full.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+    L.orc_height_to_length.restype = None
+    L.orc_height_to_length.argtypes = [C.c_int, _ip, _dp, _dp]
+    L.orc_get_branches.restype = C.c_int
+    L.orc_get_branches.argtypes = [C.c_int, _ip, _dp, _dp]
+    L.orc_sum_first_two.restype = None
+    L.orc_sum_first_two.argtypes = [C.c_int, _dp, _dp]
+    L.orc_distances.restype = C.c_int
+    L.orc_distances.argtypes = [C.c_int, _ip, _dp, _dp, C.c_double, C.c_double, _dp]
+    L.orc_tree_loglik_full.restype = C.c_int
+    L.orc_tree_loglik_full.argtypes = [C.c_int, _ip, _dp, _dp, C.c_double, C.c_double, _dp, _dp, C.c_double, _dp]
+    L.orc_log_jacobian_root_branch.restype = C.c_int
+    L.orc_log_jacobian_root_branch.argtypes = [C.c_int, _ip, _dp, _dp, C.c_double, C.c_double, _dp]
+    L.orc_tree_grad_full.restype = C.c_int
+    L.orc_tree_grad_full.argtypes = [C.c_int, _ip, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_logpdf_full_batch.restype = None
+    L.orc_logpdf_full_batch.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, C.c_int64, C.c_int64, _dp]
+    L.orc_logpdf_chol_batch.restype = None
+    L.orc_logpdf_chol_batch.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int64, C.c_int64, _dp]
+    L.orc_grad_full_batch.restype = None
+    L.orc_grad_full_batch.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int64, C.c_int64, _dp, C.c_int64]
+    L.orc_tree_loglik_full_batch.restype = C.c_int
+    L.orc_tree_loglik_full_batch.argtypes = [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int64, _dp, _dp]
+    _LIBS[key] = L
+    return L
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc == -2:
+        raise OracleError("getBranches: Root node is not bifurcating.")  # app/Tools.hs:43
+    if rc != 0:
+        raise OracleError(f"oracle error {rc}")
+
+
+# ---- raw-x entry points ---------------------------------------------------------------
+def logpdf_full(mu, sigma_inv, logdet, x) -> float:
+    mu, pm = _d(mu); P, pp = _d(sigma_inv); x, px = _d(x)
+    return float(lib().orc_logpdf_full(len(mu), pm, pp, float(logdet), px))
+
+
+def logpdf_full_ld(mu, sigma_inv, logdet, x) -> float:
+    mu, pm = _d(mu); P, pp = _d(sigma_inv); x, px = _d(x)
+    return float(lib().orc_logpdf_full_ld(len(mu), pm, pp, float(logdet), px))
+
+
+def logpdf_full_batch(mu, sigma_inv, logdet, X, native=False) -> np.ndarray:
+    """X: [batch, n] chain-major."""
+    mu, pm = _d(mu); P, pp = _d(sigma_inv); X, px = _d(X)
+    out = np.empty(X.shape[0]); po = out.ctypes.data_as(_dp)
+    lib(native).orc_logpdf_full_batch(len(mu), pm, pp, float(logdet), px, X.shape[1], X.shape[0], po)
+    return out
+
+
+def cholesky(sigma) -> np.ndarray:
+    S, ps = _d(sigma)
+    n = S.shape[0]
+    L = np.zeros((n, n)); pl = L.ctypes.data_as(_dp)
+    rc = lib().orc_cholesky(n, ps, pl)
+    if rc != 0:
+        raise OracleError("covariance matrix is not positive definite")
+    return L
+
+
+def logpdf_chol_batch(mu, L, X) -> np.ndarray:
+    mu, pm = _d(mu); L, pl = _d(L); X, px = _d(X)
+    out = np.empty(X.shape[0]); po = out.ctypes.data_as(_dp)
+    lib().orc_logpdf_chol_batch(len(mu), pm, pl, px, X.shape[1], X.shape[0], po)
+    return out
+
+
+def logpdf_univariate(mu, vs, x) -> float:
+    mu, pm = _d(mu); vs, pv = _d(vs); x, px = _d(x)
+    return float(lib().orc_logpdf_univariate(len(mu), pm, pv, px))
+
+
+def logpdf_sparse(mu, ii, jj, vv, logdet, x) -> float:
+    mu, pm = _d(mu); ii, pi = _i(ii); jj, pj = _i(jj); vv, pv = _d(vv); x, px = _d(x)
+    return float(lib().orc_logpdf_sparse(len(mu), pm, len(vv), pi, pj, pv, float(logdet), px))
+
+
+def grad_full_batch(mu, sigma_inv, X) -> np.ndarray:
+    mu, pm = _d(mu); P, pp = _d(sigma_inv); X, px = _d(X)
+    G = np.empty_like(X); pg = G.ctypes.data_as(_dp)
+    lib().orc_grad_full_batch(len(mu), pm, pp, px, X.shape[1], X.shape[0], pg, X.shape[1])
+    return G
+
+
+# ---- tree entry points ----------------------------------------------------------------
+def height_to_length(parent, heights) -> np.ndarray:
+    parent, pp = _i(parent); h, ph = _d(heights)
+    out = np.empty_like(h)
+    lib().orc_height_to_length(len(parent), pp, ph, out.ctypes.data_as(_dp))
+    return out
+
+
+def get_branches(parent, values) -> np.ndarray:
+    parent, pp = _i(parent); v, pv = _d(values)
+    out = np.empty(max(len(parent) - 1, 0))
+    _check(lib().orc_get_branches(len(parent), pp, pv, out.ctypes.data_as(_dp)))
+    return out
+
+
+def sum_first_two(v) -> np.ndarray:
+    v, pv = _d(v)
+    out = np.empty(len(v) - 1)
+    lib().orc_sum_first_two(len(v), pv, out.ctypes.data_as(_dp))
+    return out
+
+
+def distances(parent, heights, rates, tH, rMu) -> np.ndarray:
+    parent, pp = _i(parent); h, ph = _d(heights); r, pr = _d(rates)
+    out = np.empty(len(parent) - 2)
+    _check(lib().orc_distances(len(parent), pp, ph, pr, float(tH), float(rMu), out.ctypes.data_as(_dp)))
+    return out
+
+
+def tree_loglik_full_batch(parent, heights, rates, tH, rMu, mu, sigma_inv, logdet, native=False):
+    """heights, rates: [batch, n_nodes]; returns (ll[batch], log_jacobian_root_branch[batch])."""
+    parent, pp = _i(parent); H, ph = _d(heights); R, pr = _d(rates)
+    tH, pt = _d(tH); rMu, pm_ = _d(rMu); mu, pmu = _d(mu); P, pP = _d(sigma_inv)
+    B = H.shape[0]
+    ll = np.empty(B); lj = np.empty(B)
+    _check(lib(native).orc_tree_loglik_full_batch(len(parent), pp, ph, pr, pt, pm_, pmu, pP, float(logdet), B,
+                                                  ll.ctypes.data_as(_dp), lj.ctypes.data_as(_dp)))
+    return ll, lj
+
+
+def tree_grad_full(parent, heights, rates, tH, rMu, mu, sigma_inv):
+    parent, pp = _i(parent); h, ph = _d(heights); r, pr = _d(rates)
+    mu, pmu = _d(mu); P, pP = _d(sigma_inv)
+    gh = np.empty_like(h); gr = np.empty_like(r)
+    gt = C.c_double(); gm = C.c_double()
+    _check(lib().orc_tree_grad_full(len(parent), pp, ph, pr, float(tH), float(rMu), pmu, pP,
+                                    gh.ctypes.data_as(_dp), gr.ctypes.data_as(_dp), C.byref(gt), C.byref(gm)))
+    return gh, gr, gt.value, gm.value

@@ -1,0 +1,302 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (fp64):
+  real fixtures (cond <= 1e2):  |ll_gpu - ll_oracle| <= 1e-10 * max(1, |ll|)
+  synthetic Sigma:              |ll_gpu - ll_oracle| <= 64 * N * eps * cond(Sigma) * max(1, q),  eps = 2^-53
+  gradients:                    same bound per component relative to ||g||_inf
+"""
+import numpy as np
+import pytest
+
+import mcmc_date_amd as M
+import oracle as O
+from mcmc_date_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.0 ** -53
+
+
+def rel_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+# ------------------------------------------------------------------------------------------
+# golden fixtures (reference test inputs -> restated prepare -> oracle)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["06-leaves-constant-rate", "10-leaves-autocorrelated-rate",
+                                  "12-leaves-variable-rate", "24-leaves-braces"])
+def test_fixture_rawx_host_and_device(gpu, golden, name):
+    import torch
+
+    fx = golden[name]
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"])))
+    ll_host = lik.logpdf(fx["X"])
+    assert np.max(rel_err(ll_host, fx["ll_X"])) <= 1e-10
+    Xd = torch.as_tensor(fx["X"], device=gpu)
+    ll_dev = lik.logpdf(Xd).cpu().numpy()
+    assert np.array_equal(ll_dev, ll_host)           # same kernel, same bits
+    # single evaluation = drop-in for logDensityFullMultivariateNormal
+    for i in (0, 5, len(fx["X"]) - 1):
+        assert lik.logpdf1(fx["X"][i]) == ll_host[i]
+    # the same operands given as the covariance matrix
+    lik2 = M.MvnLikelihood.from_covariance(fx["mu"], fx["sigma"])
+    assert abs(lik2.logdet_sigma - float(fx["logdet"])) <= 1e-10 * abs(float(fx["logdet"]))
+    assert np.max(rel_err(lik2.logpdf(fx["X"]), fx["ll_X"])) <= 1e-10
+
+
+@pytest.mark.parametrize("name", ["06-leaves-constant-rate", "10-leaves-autocorrelated-rate",
+                                  "12-leaves-variable-rate", "24-leaves-braces"])
+def test_fixture_tree_states(gpu, golden, name):
+    fx = golden[name]
+    topo = M.Topology(fx["parent"])
+    tl = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    st = M.StateBatch(fx["H"], fx["R"], fx["tH"], fx["rMu"])
+    ll, lj = tl.loglik(st)
+    assert np.max(rel_err(ll, fx["ll_S"])) <= 1e-10
+    assert np.max(rel_err(lj, fx["lj_S"])) <= 1e-12
+    ll_d, lj_d = tl.loglik(st.to(gpu))
+    assert np.array_equal(ll_d.cpu().numpy(), ll) and np.array_equal(lj_d.cpu().numpy(), lj)
+    # the plugin closure: one state in, one log-likelihood out
+    f = M.likelihood_function(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"])), topo)
+    x = M.State(1.0, 1.0, float(fx["tH"][3]), fx["H"][3], float(fx["rMu"][3]), 1.0, fx["R"][3])
+    assert f(x) == ll[3]
+
+
+@pytest.mark.parametrize("name", ["12-leaves-variable-rate", "24-leaves-braces"])
+def test_fixture_tree_gradient(gpu, golden, name):
+    """Config 4: analytic gradient vs the oracle's and vs central finite differences of the oracle."""
+    fx = golden[name]
+    topo = M.Topology(fx["parent"])
+    tl = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    st = M.StateBatch(fx["H"], fx["R"], fx["tH"], fx["rMu"])
+    ll, gH, gR, gt, gm = tl.grad(st)
+    assert np.max(rel_err(ll, fx["ll_S"])) <= 1e-10
+    ng = len(fx["gH"])
+    scale = max(np.abs(fx["gH"]).max(), np.abs(fx["gR"]).max())
+    assert np.max(np.abs(gH[:ng] - fx["gH"])) <= 1e-9 * scale
+    assert np.max(np.abs(gR[:ng] - fx["gR"])) <= 1e-9 * scale
+    assert np.max(rel_err(gt[:ng], fx["gtH"])) <= 1e-9 and np.max(rel_err(gm[:ng], fx["grMu"])) <= 1e-9
+    # finite differences of the ORACLE log-likelihood (h = 1e-6 relative) for chain 1
+    b = 1
+    def ll_at(H, R, tH, rMu):
+        return O.tree_loglik_full_batch(fx["parent"], H[None], R[None], np.array([tH]), np.array([rMu]), fx["mu"],
+                                        fx["sigma_inv"], float(fx["logdet"]))[0][0]
+    H0, R0 = fx["H"][b].copy(), fx["R"][b].copy()
+    for v in (1, 2, topo.n_nodes - 2):
+        for arr, g in ((H0, gH), (R0, gR)):
+            if arr[v] == 0:
+                continue
+            h = 1e-6 * abs(arr[v])
+            a = arr.copy(); a[v] += h
+            c = arr.copy(); c[v] -= h
+            if arr is H0:
+                fd = (ll_at(a, R0, fx["tH"][b], fx["rMu"][b]) - ll_at(c, R0, fx["tH"][b], fx["rMu"][b])) / (2 * h)
+            else:
+                fd = (ll_at(H0, a, fx["tH"][b], fx["rMu"][b]) - ll_at(H0, c, fx["tH"][b], fx["rMu"][b])) / (2 * h)
+            assert abs(fd - g[b, v]) <= 1e-5 * max(1.0, abs(fd)), (v, fd, g[b, v])
+    # device-resident call returns the same bits
+    out_d = tl.grad(st.to(gpu))
+    assert np.array_equal(out_d[1].cpu().numpy(), gH) and np.array_equal(out_d[2].cpu().numpy(), gR)
+
+
+def test_fixture_rawx_gradient(gpu, golden):
+    fx = golden["24-leaves-braces"]
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"])))
+    ll, G = lik.grad(fx["X"])
+    Gref = O.grad_full_batch(fx["mu"], fx["sigma_inv"], fx["X"])
+    assert np.max(rel_err(ll, fx["ll_X"])) <= 1e-10
+    assert np.max(np.abs(G - Gref)) <= 1e-10 * np.abs(Gref).max()
+
+
+# ------------------------------------------------------------------------------------------
+# the other LikelihoodData constructors (app/Probability.hs:210-235) run through the same kernel
+# ------------------------------------------------------------------------------------------
+def test_univariate_sparse_nodata(gpu, golden):
+    fx = golden["12-leaves-variable-rate"]
+    mu, X = fx["mu"], fx["X"]
+    vs = np.diag(fx["sigma"]).copy()
+    uni = M.MvnLikelihood(M.Univariate(mu, vs))
+    ref = np.array([O.logpdf_univariate(mu, vs, x) for x in X])
+    assert np.max(rel_err(uni.logpdf(X), ref)) <= 1e-10
+    # sparse: drop small precision entries like toAssocMatrix (app/Main.hs:142-155) would
+    P = fx["sigma_inv"].copy()
+    P[np.abs(P) < 0.02 * np.abs(P).max()] = 0.0
+    ii, jj = np.nonzero(P)
+    assoc = [((int(i), int(j)), float(P[i, j])) for i, j in zip(ii, jj)]
+    logdet = -np.linalg.slogdet(P)[1]
+    sp = M.MvnLikelihood(M.Sparse(mu, assoc, logdet))
+    ref = np.array([O.logpdf_sparse(mu, ii, jj, P[ii, jj], logdet, x) for x in X])
+    assert np.max(rel_err(sp.logpdf(X), ref)) <= 1e-10
+    nd = M.MvnLikelihood(M.NoData())
+    assert np.all(nd.logpdf(X) == 0.0)                # likelihood 1.0, app/Probability.hs:281
+
+
+# ------------------------------------------------------------------------------------------
+# synthetic Sigma: every register-block size, ragged batches, strides
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,batch", [(1, 3), (2, 1), (9, 5), (63, 7), (64, 64), (65, 33), (128, 130), (129, 17),
+                                     (200, 64), (256, 512), (257, 9), (384, 40), (500, 21), (768, 12), (1024, 16)])
+def test_synthetic_logpdf_and_grad(gpu, n, batch):
+    import torch
+
+    mu, sigma = S.random_spd_problem(n, seed=n)
+    X = S.sample_chains(mu, sigma, batch, seed=n)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    kappa = np.linalg.cond(sigma)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    ref = O.logpdf_full_batch(mu, P, logdet, X)
+    q = -2.0 * (ref + 0.9189385332046727 * n) - logdet
+    tol = 64 * n * EPS * kappa * np.maximum(1.0, q)
+    ll = lik.logpdf(X)
+    assert np.all(np.abs(ll - ref) <= tol), (np.max(np.abs(ll - ref)), tol.min())
+    # device-resident, padded leading dimension
+    ld = n + 3
+    Xd = torch.zeros(batch, ld, dtype=torch.float64, device=gpu)
+    Xd[:, :n] = torch.as_tensor(X, device=gpu)
+    out = torch.empty(batch, dtype=torch.float64, device=gpu)
+    M._capi.check(M._capi.lib().mcd_mvn_logpdf_batch(lik._h, Xd.data_ptr(), ld, batch, 1, None, out.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ll)
+    ll2, G = lik.grad(X)
+    assert np.array_equal(ll2, ll)
+    Gref = O.grad_full_batch(mu, P, X)
+    gtol = 64 * n * EPS * kappa * np.abs(Gref).max() * 4
+    assert np.max(np.abs(G - Gref)) <= gtol, (np.max(np.abs(G - Gref)), gtol)
+
+
+def test_large_batch_two_chains_per_wave(gpu):
+    """Batches above 8192 chains switch to two chains per wave; same results per chain."""
+    import torch
+
+    n, batch = 96, 8192 + 1027
+    mu, sigma = S.random_spd_problem(n, seed=5)
+    X = S.sample_chains(mu, sigma, batch, seed=5)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    ll = lik.logpdf(torch.as_tensor(X, device=gpu)).cpu().numpy()
+    small = lik.logpdf(X[:300])
+    assert np.array_equal(ll[:300], small)
+    ref = O.logpdf_full_batch(mu, np.linalg.inv(sigma), np.linalg.slogdet(sigma)[1], X[-50:])
+    assert np.max(rel_err(ll[-50:], ref)) <= 1e-9
+
+
+def test_synthetic_tree_256(gpu):
+    """Config 3 tree variant: L = 129 leaves -> N = 255 (2L-3 is odd; 256 itself cannot be a tree)."""
+    topo = S.random_topology(129, seed=256)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=256)
+    st = S.random_states(topo, 96, seed=256)
+    # put the states near mu: choose rMu so that distances have the scale of mu
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    tl = M.MvnLikelihood(M.Full(mu, P, logdet)).bind_tree(topo)
+    ll, lj = tl.loglik(st)
+    ref, refj = O.tree_loglik_full_batch(topo.parent, st.heights, st.rates, st.time_height, st.rate_mean, mu, P, logdet)
+    assert np.max(np.abs(ll - ref) / np.abs(ref)) <= 1e-11
+    assert np.max(rel_err(lj, refj)) <= 1e-12
+    out = tl.grad(st)
+    for b in (0, 17, 95):
+        gH, gR, gt, gm = O.tree_grad_full(topo.parent, st.heights[b], st.rates[b], st.time_height[b], st.rate_mean[b], mu, P)
+        sc = max(np.abs(gH).max(), np.abs(gR).max())
+        assert np.max(np.abs(out[1][b] - gH)) <= 1e-9 * sc and np.max(np.abs(out[2][b] - gR)) <= 1e-9 * sc
+        assert abs(out[3][b] - gt) <= 1e-9 * abs(gt) and abs(out[4][b] - gm) <= 1e-9 * abs(gm)
+
+
+# ------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes
+# ------------------------------------------------------------------------------------------
+def test_properties_full_size(gpu):
+    import torch
+
+    n, batch = 256, 512
+    mu, sigma = S.random_spd_problem(n, seed=256)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    L = lik.cholesky_factor()
+    assert np.allclose(L @ L.T, sigma, rtol=1e-12, atol=1e-18)
+    rng = np.random.default_rng(1)
+    Z = rng.standard_normal((batch, n))
+    X = mu + Z @ L.T                                   # then L^-1 (x - mu) = z exactly up to rounding
+    ll = lik.logpdf(torch.as_tensor(X, device=gpu)).cpu().numpy()
+    q_expected = np.sum(Z * Z, axis=1)
+    c = -0.9189385332046727 * n
+    q = -2.0 * (ll - c) - lik.logdet_sigma
+    assert np.max(np.abs(q - q_expected) / q_expected) <= 1e-10
+    # maximum at mu, symmetry around mu, determinism
+    ll_mu = lik.logpdf1(mu)
+    assert ll_mu == c - 0.5 * lik.logdet_sigma and np.all(ll <= ll_mu)
+    ll_ref = lik.logpdf(2 * mu[None, :] - X)
+    assert np.max(np.abs(ll_ref - ll) / np.abs(ll)) <= 1e-12
+    assert np.array_equal(lik.logpdf(X), ll)
+    # gradient is linear in (x - mu):  G(mu + a d) = a G(mu + d);  G(mu) = 0
+    _, G1 = lik.grad(X[:8])
+    _, G2 = lik.grad(mu + 2.0 * (X[:8] - mu))
+    assert np.max(np.abs(G2 - 2.0 * G1)) <= 1e-9 * np.abs(G1).max()
+    _, G0 = lik.grad(mu[None, :])
+    assert np.all(G0 == 0.0)
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases and error behaviour
+# ------------------------------------------------------------------------------------------
+def test_nonfinite_inputs_flow_through(gpu, golden):
+    """NaN/Inf in a proposal must come out as NaN / -Inf (never finite, never an error): the sampler
+    rejects such proposals (lib/Mcmc/Tree/Proposal/Unconstrained.hs:304-306)."""
+    fx = golden["24-leaves-braces"]
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"])))
+    X = fx["X"][:6].copy()
+    X[1, 3] = np.nan
+    X[2, 0] = np.inf
+    X[3, -1] = -np.inf
+    X[4, 7] = 1e308
+    ll = lik.logpdf(X)
+    assert np.isfinite(ll[0]) and np.isfinite(ll[5])
+    assert np.isnan(ll[1])
+    for b in (2, 3, 4):
+        assert not np.isfinite(ll[b]) and not (ll[b] > 0)
+        ref = O.logpdf_full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]), X[b])
+        assert not np.isfinite(ref)
+    # untouched neighbours are bit-identical to a clean run
+    assert ll[0] == lik.logpdf(fx["X"][:1])[0]
+
+
+def test_empty_batch_and_errors(gpu, golden):
+    fx = golden["06-leaves-constant-rate"]
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"])))
+    assert lik.logpdf(np.zeros((0, 9))).shape == (0,)
+    with pytest.raises(ValueError):
+        lik.logpdf(np.zeros((2, 8)))
+    bad = fx["sigma"].copy()
+    bad[0, 0] = -1.0
+    with pytest.raises(M.NotPositiveDefinite):
+        M.MvnLikelihood.from_covariance(fx["mu"], bad)
+    with pytest.raises(M.McdError):
+        M.MvnLikelihood.from_covariance(np.zeros(1025), np.eye(1025))
+    # non-bifurcating root: app/Tools.hs:43
+    tri = M.Topology(np.array([-1, 0, 0, 0, 3, 3, 3, 3, 3, 3, 3], np.int32))
+    with pytest.raises(M.RootNotBifurcating):
+        lik.bind_tree(tri)
+    # wrong number of branches
+    with pytest.raises(M.McdError):
+        lik.bind_tree(M.Topology(np.array([-1, 0, 0], np.int32)))
+
+
+def test_concurrent_callers(gpu, golden):
+    """The closure is called from several OS threads in the reference (-threaded -N, Parallel)."""
+    import threading
+
+    fx = golden["24-leaves-braces"]
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"])))
+    expect = lik.logpdf(fx["X"])
+    errs = []
+
+    def work(k):
+        for _ in range(20):
+            out = lik.logpdf(fx["X"][k::4])
+            if not np.array_equal(out, expect[k::4]):
+                errs.append(k)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
