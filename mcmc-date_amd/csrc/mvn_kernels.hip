@@ -25,6 +25,7 @@
 // No MFMA on purpose: this is TRSV + DOT (north_star), fp64 FMA on the vector ALU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mvn_kernels.h"
 
@@ -73,37 +74,47 @@ __device__ __forceinline__ double2 load_pair(const double* __restrict__ F, int p
     return *p;
 }
 
+// Streaming schedule.  The factor is consumed in CHUNKS of PAIRS column pairs; a ring of NB
+// register chunks keeps NB-1 chunks of loads in flight ahead of the FMAs (one wave has nobody
+// else to hide its L2 latency behind at the batch sizes a sampler uses: measured ~800 cycles per
+// 16-KiB burst, MI355X).  NB * 2 * PAIRS columns are consumed per loop trip and must divide 64.
 template <int R>
 struct Cfg {
-    // column pairs per register buffer: keep (pairs * R) ~ 16 double2 (= 64 VGPRs) per buffer
-    static constexpr int PAIRS = (R <= 2) ? 8 : (R <= 4) ? 4 : (R <= 8) ? 2 : 1;
+    static constexpr int PAIRS = (R <= 1) ? 4 : (R <= 4) ? 2 : 1;
+    static constexpr int CH = 2 * PAIRS;    // columns per chunk
+    static constexpr int NB = (R <= 8) ? 8 : 4;   // ring depth: <= 64 loads (256 VGPRs) in flight
     static constexpr int NP = 64 * R;
 };
 
-// One buffer = PAIRS column pairs x (R - KMIN) row blocks.
-template <int R, int KMIN>
-struct PairBuf {
-    double2 v[Cfg<R>::PAIRS][R - KMIN];
+// One chunk = PAIRS column pairs x row blocks [KLO, KHI).
+template <int R, int KLO, int KHI>
+struct Chunk {
+    double2 v[Cfg<R>::PAIRS][KHI - KLO];
+};
+template <int R, int KLO, int KHI, int NB>
+struct Ring {
+    Chunk<R, KLO, KHI> b[NB];
 };
 
-// ------------------------------- forward sweep ----------------------------------------
-// Processes column pairs [pair0, pair0 + PAIRS) which all belong to column block JB.
-template <int R, int BT, int JB>
-__device__ __forceinline__ void fwd_load(PairBuf<R, JB>& buf, const double* __restrict__ Ft, int pair0, int lane)
+template <int R, int KLO, int KHI>
+__device__ __forceinline__ void chunk_load(Chunk<R, KLO, KHI>& c, const double* __restrict__ F, int pair_first, int step,
+                                           int lane)
 {
+    // pairs pair_first, pair_first + step, ... (step = +1 forward, -1 backward), clamped in bounds
     constexpr int PAIRS = Cfg<R>::PAIRS;
     constexpr int MAXPAIR = 32 * R - 1;
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
-        int pr = pair0 + p;
-        pr = pr > MAXPAIR ? MAXPAIR : pr;  // redundant in-bounds reload past the end
+        int pr = pair_first + step * p;
+        pr = pr > MAXPAIR ? MAXPAIR : (pr < 0 ? 0 : pr);   // redundant in-bounds reload past either end
 #pragma unroll
-        for (int k = JB; k < R; ++k) buf.v[p][k - JB] = load_pair<R>(Ft, pr, k, lane);
+        for (int k = KLO; k < KHI; ++k) c.v[p][k - KLO] = load_pair<R>(F, pr, k, lane);
     }
 }
 
+// ------------------------------- forward sweep ----------------------------------------
 template <int R, int BT, int JB>
-__device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const PairBuf<R, JB>& buf, int jj0 /* column offset inside block JB */)
+__device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const Chunk<R, JB, R>& c, int jj0 /* column offset inside block JB */)
 {
     constexpr int PAIRS = Cfg<R>::PAIRS;
 #pragma unroll
@@ -113,75 +124,62 @@ __device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const PairBuf<R, J
             const int jj = jj0 + 2 * p + h;
             double z[BT];
 #pragma unroll
-            for (int c = 0; c < BT; ++c) z[c] = readlane64(d[JB][c], jj);
+            for (int b = 0; b < BT; ++b) z[b] = readlane64(d[JB][b], jj);
 #pragma unroll
             for (int k = JB; k < R; ++k) {
-                const double l = h ? buf.v[p][k - JB].y : buf.v[p][k - JB].x;
+                const double l = h ? c.v[p][k - JB].y : c.v[p][k - JB].x;
 #pragma unroll
-                for (int c = 0; c < BT; ++c) d[k][c] = fma(-l, z[c], d[k][c]);
+                for (int b = 0; b < BT; ++b) d[k][b] = fma(-l, z[b], d[k][b]);
             }
         }
     }
 }
 
-// Column block JB of the forward sweep.  `A` arrives pre-loaded with the block's first chunk
-// (by the kernel prologue for JB = 0, by the previous block's last prefetch otherwise).
-template <int R, int BT, int JB>
+// Column block JB of the forward sweep.  `ring` arrives holding the block's first NB chunks
+// (loaded by the kernel prologue for JB = 0, by the previous block's prefetches otherwise).
+template <int R, int BT, int NB, int JB>
 __device__ __forceinline__ void fwd_block(double (&d)[R][BT], const double* __restrict__ Ft, int lane, int ncols,
-                                          PairBuf<R, JB>& A)
+                                          Ring<R, JB, R, NB>& ring)
 {
     constexpr int PAIRS = Cfg<R>::PAIRS;
-    constexpr int CH = 2 * PAIRS;           // columns per buffer; ncols is a multiple of CH
+    constexpr int CH = Cfg<R>::CH;
     if (64 * JB < ncols) {                  // wave-uniform
-        PairBuf<R, JB> B;
-        int lim = ncols - 64 * JB;
+        int lim = ncols - 64 * JB;          // multiple of NB * CH
         lim = lim > 64 ? 64 : lim;
-        for (int jj0 = 0; jj0 < lim; jj0 += 2 * CH) {
-            // sched_barrier: keep each prefetch ahead of the FMAs that hide its latency
-            fwd_load<R, BT, JB>(B, Ft, 32 * JB + ((jj0 + CH) >> 1), lane);
-            __builtin_amdgcn_sched_barrier(0);
-            fwd_apply<R, BT, JB>(d, A, jj0);
-            __builtin_amdgcn_sched_barrier(0);
-            fwd_load<R, BT, JB>(A, Ft, 32 * JB + ((jj0 + 2 * CH) >> 1), lane);  // may be block JB+1's first chunk
-            __builtin_amdgcn_sched_barrier(0);
-            if (jj0 + CH < lim) fwd_apply<R, BT, JB>(d, B, jj0 + CH);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int jj0 = 0; jj0 < lim; jj0 += NB * CH) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                fwd_apply<R, BT, JB>(d, ring.b[i], jj0 + i * CH);
+                __builtin_amdgcn_sched_barrier(0);   // keep the refill right behind its consumer
+                chunk_load<R, JB, R>(ring.b[i], Ft, 32 * JB + ((jj0 + (i + NB) * CH) >> 1), 1, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if constexpr (JB + 1 < R) {
-            PairBuf<R, JB + 1> A2;
+            Ring<R, JB + 1, R, NB> next;
 #pragma unroll
-            for (int p = 0; p < PAIRS; ++p)
+            for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int k = JB + 1; k < R; ++k) A2.v[p][k - JB - 1] = A.v[p][k - JB];
-            fwd_block<R, BT, JB + 1>(d, Ft, lane, ncols, A2);
+                for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+                    for (int k = JB + 1; k < R; ++k) next.b[i].v[p][k - JB - 1] = ring.b[i].v[p][k - JB];
+            fwd_block<R, BT, NB, JB + 1>(d, Ft, lane, ncols, next);
         }
     }
+}
+
+template <int R, int BT, int NB>
+__device__ __forceinline__ void fwd_prologue(Ring<R, 0, R, NB>& ring, const double* __restrict__ Ft, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) chunk_load<R, 0, R>(ring.b[i], Ft, i * Cfg<R>::PAIRS, 1, lane);
 }
 
 // ------------------------------- backward sweep ---------------------------------------
 // Ut holds the scaled transpose: element (row r, column i) = L[i][r] / L[r][r] for r < i, zero
 // otherwise; column block IB touches row blocks k <= IB.  Columns are visited from high to low.
-template <int R, int IB>
-struct PairBufB {
-    double2 v[Cfg<R>::PAIRS][IB + 1];
-};
-
 template <int R, int BT, int IB>
-__device__ __forceinline__ void bwd_load(PairBufB<R, IB>& buf, const double* __restrict__ Ut, int pair_hi, int lane)
-{
-    // loads pairs pair_hi, pair_hi-1, ..., pair_hi-PAIRS+1
-    constexpr int PAIRS = Cfg<R>::PAIRS;
-#pragma unroll
-    for (int p = 0; p < PAIRS; ++p) {
-        int pr = pair_hi - p;
-        pr = pr < 0 ? 0 : pr;
-#pragma unroll
-        for (int k = 0; k <= IB; ++k) buf.v[p][k] = load_pair<R>(Ut, pr, k, lane);
-    }
-}
-
-template <int R, int BT, int IB>
-__device__ __forceinline__ void bwd_apply(double (&d)[R][BT], const PairBufB<R, IB>& buf, int ii_hi /* highest column offset inside block IB */)
+__device__ __forceinline__ void bwd_apply(double (&d)[R][BT], const Chunk<R, 0, IB + 1>& c, int ii_hi /* highest (odd) column offset of the chunk */)
 {
     constexpr int PAIRS = Cfg<R>::PAIRS;
 #pragma unroll
@@ -191,49 +189,53 @@ __device__ __forceinline__ void bwd_apply(double (&d)[R][BT], const PairBufB<R, 
             const int ii = ii_hi - 2 * p - (1 - h);
             double y[BT];
 #pragma unroll
-            for (int c = 0; c < BT; ++c) y[c] = readlane64(d[IB][c], ii);
+            for (int b = 0; b < BT; ++b) y[b] = readlane64(d[IB][b], ii);
 #pragma unroll
             for (int k = 0; k <= IB; ++k) {
-                const double u = h ? buf.v[p][k].y : buf.v[p][k].x;
+                const double u = h ? c.v[p][k].y : c.v[p][k].x;
 #pragma unroll
-                for (int c = 0; c < BT; ++c) d[k][c] = fma(-u, y[c], d[k][c]);
+                for (int b = 0; b < BT; ++b) d[k][b] = fma(-u, y[b], d[k][b]);
             }
         }
     }
 }
 
 // Column block IB of the backward sweep (blocks are visited from the top one down).  The top
-// active block loads its first chunk itself; lower blocks receive it prefetched in `A`.
-template <int R, int BT, int IB>
+// active block fills the ring itself; lower blocks receive it prefetched.
+template <int R, int BT, int NB, int IB>
 __device__ __forceinline__ void bwd_block(double (&d)[R][BT], const double* __restrict__ Ut, int lane, int ncols,
-                                          PairBufB<R, IB>& A)
+                                          Ring<R, 0, IB + 1, NB>& ring)
 {
     constexpr int PAIRS = Cfg<R>::PAIRS;
-    constexpr int CH = 2 * PAIRS;
+    constexpr int CH = Cfg<R>::CH;
     if (64 * IB < ncols) {
-        int lim = ncols - 64 * IB;          // columns of this block in use (multiple of CH)
+        int lim = ncols - 64 * IB;          // columns of this block in use (multiple of NB * CH)
         const bool top = lim <= 64;
         lim = lim > 64 ? 64 : lim;
-        if (top) bwd_load<R, BT, IB>(A, Ut, 32 * IB + ((lim - 1) >> 1), lane);
-        PairBufB<R, IB> B;
-        for (int hi = lim - 1; hi >= 0; hi -= 2 * CH) {
-            bwd_load<R, BT, IB>(B, Ut, 32 * IB + ((hi - CH) >> 1), lane);
-            __builtin_amdgcn_sched_barrier(0);
-            bwd_apply<R, BT, IB>(d, A, hi);
-            __builtin_amdgcn_sched_barrier(0);
-            bwd_load<R, BT, IB>(A, Ut, 32 * IB + ((hi - 2 * CH) >> 1), lane);  // may be block IB-1's first chunk
-            __builtin_amdgcn_sched_barrier(0);
-            if (hi - CH >= 0) bwd_apply<R, BT, IB>(d, B, hi - CH);
-            __builtin_amdgcn_sched_barrier(0);
+        if (top) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                chunk_load<R, 0, IB + 1>(ring.b[i], Ut, 32 * IB + ((lim - 1 - i * CH) >> 1), -1, lane);
+        }
+        for (int hi = lim - 1; hi >= 0; hi -= NB * CH) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                bwd_apply<R, BT, IB>(d, ring.b[i], hi - i * CH);
+                __builtin_amdgcn_sched_barrier(0);
+                chunk_load<R, 0, IB + 1>(ring.b[i], Ut, 32 * IB + ((hi - (i + NB) * CH) >> 1), -1, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     if constexpr (IB > 0) {
-        PairBufB<R, IB - 1> A2;
+        Ring<R, 0, IB, NB> next;
 #pragma unroll
-        for (int p = 0; p < PAIRS; ++p)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int k = 0; k < IB; ++k) A2.v[p][k] = A.v[p][k];
-        bwd_block<R, BT, IB - 1>(d, Ut, lane, ncols, A2);
+            for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+                for (int k = 0; k < IB; ++k) next.b[i].v[p][k] = ring.b[i].v[p][k];
+        bwd_block<R, BT, NB, IB - 1>(d, Ut, lane, ncols, next);
     }
 }
 
@@ -318,15 +320,16 @@ template <int R, int BT>
 __global__ void __launch_bounds__(256) k_logpdf(MvnDev M, const double* __restrict__ X, int64_t ldx, int64_t batch,
                                                 double* __restrict__ ll)
 {
+    constexpr int NB = Cfg<R>::NB;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t b0 = wave * BT;
     if (b0 >= batch) return;  // wave-uniform exit
-    PairBuf<R, 0> A;
-    fwd_load<R, BT, 0>(A, M.Ft, 0, lane);   // factor stream starts before the state arrives
+    Ring<R, 0, R, NB> ring;
+    fwd_prologue<R, BT, NB>(ring, M.Ft, lane);   // factor stream starts before the state arrives
     double d[R][BT];
     load_rawx<R, BT>(d, M, X, ldx, b0, batch, lane);
-    fwd_block<R, BT, 0>(d, M.Ft, lane, M.ncols, A);
+    fwd_block<R, BT, NB, 0>(d, M.Ft, lane, M.ncols, ring);
     finish_ll<R, BT>(d, M, b0, batch, ll, lane);
 }
 
@@ -334,15 +337,16 @@ template <int R, int BT>
 __global__ void __launch_bounds__(256) k_grad(MvnDev M, const double* __restrict__ X, int64_t ldx, int64_t batch,
                                               double* __restrict__ ll, double* __restrict__ G, int64_t ldg)
 {
+    constexpr int NB = Cfg<R>::NB;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t b0 = wave * BT;
     if (b0 >= batch) return;
-    PairBuf<R, 0> A;
-    fwd_load<R, BT, 0>(A, M.Ft, 0, lane);   // factor stream starts before the state arrives
+    Ring<R, 0, R, NB> ring;
+    fwd_prologue<R, BT, NB>(ring, M.Ft, lane);   // factor stream starts before the state arrives
     double d[R][BT];
     load_rawx<R, BT>(d, M, X, ldx, b0, batch, lane);
-    fwd_block<R, BT, 0>(d, M.Ft, lane, M.ncols, A);
+    fwd_block<R, BT, NB, 0>(d, M.Ft, lane, M.ncols, ring);
     finish_ll<R, BT>(d, M, b0, batch, ll, lane);
     // backward: y = L^-T z.  Row scaling first (z_r / L_rr), then the mirrored sweep.
 #pragma unroll
@@ -352,8 +356,8 @@ __global__ void __launch_bounds__(256) k_grad(MvnDev M, const double* __restrict
         for (int c = 0; c < BT; ++c) d[k][c] *= iv;
     }
     {
-        PairBufB<R, R - 1> Ab;
-        bwd_block<R, BT, R - 1>(d, M.Ut, lane, M.ncols, Ab);
+        Ring<R, 0, R, NB> rb;
+        bwd_block<R, BT, NB, R - 1>(d, M.Ut, lane, M.ncols, rb);
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -370,12 +374,13 @@ __global__ void __launch_bounds__(256) k_tree_logpdf(MvnDev M, TreeDev T, const 
                                                      const double* __restrict__ tH, const double* __restrict__ rMu,
                                                      int64_t batch, double* __restrict__ ll, double* __restrict__ logjac)
 {
+    constexpr int NB = Cfg<R>::NB;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t b0 = wave * BT;
     if (b0 >= batch) return;
-    PairBuf<R, 0> A;
-    fwd_load<R, BT, 0>(A, M.Ft, 0, lane);
+    Ring<R, 0, R, NB> ring;
+    fwd_prologue<R, BT, NB>(ring, M.Ft, lane);
     double d[R][BT], dist[R][BT];
     load_tree<R, BT>(d, dist, M, T, H, Rt, lds, tH, rMu, b0, batch, lane);
     if (logjac != nullptr && lane == 0) {
@@ -383,7 +388,7 @@ __global__ void __launch_bounds__(256) k_tree_logpdf(MvnDev M, TreeDev T, const 
         for (int c = 0; c < BT; ++c)
             if (b0 + c < batch) logjac[b0 + c] = log(1.0 / dist[0][c]);  // app/Probability.hs:394, 409
     }
-    fwd_block<R, BT, 0>(d, M.Ft, lane, M.ncols, A);
+    fwd_block<R, BT, NB, 0>(d, M.Ft, lane, M.ncols, ring);
     finish_ll<R, BT>(d, M, b0, batch, ll, lane);
 }
 
@@ -399,22 +404,23 @@ __global__ void __launch_bounds__(256) k_tree_grad(MvnDev M, TreeDev T, const do
                                                    double* __restrict__ grMu)
 {
     extern __shared__ double smem[];       // [waves per block][n_nodes_padded]
+    constexpr int NB = Cfg<R>::NB;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= batch) return;
     double* e = smem + (size_t)wib * T.n_nodes_pad;
-    PairBuf<R, 0> A;
-    fwd_load<R, 1, 0>(A, M.Ft, 0, lane);
+    Ring<R, 0, R, NB> ring;
+    fwd_prologue<R, 1, NB>(ring, M.Ft, lane);
     double d[R][1], dist[R][1];
     load_tree<R, 1>(d, dist, M, T, H, Rt, lds, tH, rMu, b, batch, lane);
-    fwd_block<R, 1, 0>(d, M.Ft, lane, M.ncols, A);
+    fwd_block<R, 1, NB, 0>(d, M.Ft, lane, M.ncols, ring);
     finish_ll<R, 1>(d, M, b, batch, ll, lane);
 #pragma unroll
     for (int k = 0; k < R; ++k) d[k][0] *= M.invdiag[64 * k + lane];
     {
-        PairBufB<R, R - 1> Ab;
-        bwd_block<R, 1, R - 1>(d, M.Ut, lane, M.ncols, Ab);
+        Ring<R, 0, R, NB> rb;
+        bwd_block<R, 1, NB, R - 1>(d, M.Ut, lane, M.ncols, rb);
     }
     // now d = y = Sigma^-1 (dist - mu); g = -y
     const double s = tH[b] * rMu[b];
@@ -472,7 +478,7 @@ template <int R>
 static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
 {
     const int bt = pick_bt(R, batch);
-    const int wpb = 2;  // waves per block
+    const int wpb = getenv("MCD_WPB") ? atoi(getenv("MCD_WPB")) : 2;  // waves per block
     const int64_t waves = (batch + bt - 1) / bt;
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
     if (bt == 1)
@@ -532,7 +538,11 @@ static hipError_t launch_tree_grad_R(const MvnDev& M, const TreeDev& T, const do
 
 int sweep_chunk_columns(int R)
 {
-    return (R <= 2) ? 16 : (R <= 4) ? 8 : (R <= 8) ? 4 : 2;   // 2 * Cfg<R>::PAIRS
+    // columns consumed per loop trip of the sweeps = Cfg<R>::NB * Cfg<R>::CH; the swept column
+    // count is rounded up to it (extra columns are zero padding).
+    const int pairs = (R <= 1) ? 4 : (R <= 4) ? 2 : 1;
+    const int nb = (R <= 8) ? 8 : 4;
+    return nb * 2 * pairs;
 }
 
 int padded_blocks(int n)
