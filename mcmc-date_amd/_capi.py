@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcmcdate_mvn.so")
+# MCD_LIB_PATH: load another build of the same C ABI (diagnostic / tuning builds under tools/)
+LIB_PATH = os.environ.get("MCD_LIB_PATH") or os.path.join(_HERE, "libmcmcdate_mvn.so")
 
 MCD_OK = 0
 MCD_ERR_INVALID_ARG = -1

@@ -1,0 +1,78 @@
+// k_grad.hip -- log-density + gradient wrt x (gfx950).  Device code: mvn_device.hpp.
+#include "mvn_device.hpp"
+
+namespace mcd {
+
+template <int R, int BT, int CW, int LW>
+__global__ void __launch_bounds__(64 * (CW + LW)) k_grad(MvnDev M, const double* __restrict__ X, int64_t ldx,
+                                                         int64_t batch, double* __restrict__ ll, double* __restrict__ G,
+                                                         int64_t ldg)
+{
+    MCD_KERNEL_HEAD
+    MCD_ACC_DECL
+    if (wave >= CW) {                                      // loader role
+        Stage<R, LW> st;
+        const int lw = wave - CW;
+        fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
+        lds_barrier();
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        bool started = false;
+        bwd_loader<R, LW, R - 1>(M.Ut, ring, st, lw, lane, M.ncols, started);
+        return;
+    }
+    double d[R][BT];
+    load_rawx<R, BT>(d, M, X, ldx, b0, batch, lane);
+    lds_barrier();
+    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    finish_ll<R, BT>(d, M, b0, batch, ll, lane);
+    // backward: y = L^-T z.  Row scaling first (z_r / L_rr), then the mirrored sweep.
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const double iv = M.invdiag[64 * k + lane];
+#pragma unroll
+        for (int c = 0; c < BT; ++c) d[k][c] *= iv;
+    }
+    bool started = false;
+    bwd_compute<R, BT, R - 1>(d, ring, lane, M.ncols, started);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int row = 64 * k + lane;
+#pragma unroll
+        for (int c = 0; c < BT; ++c)
+            if (row < M.n && b0 + c < batch) G[(b0 + c) * ldg + row] = -d[k][c];
+    }
+}
+
+template <int R>
+static hipError_t launch_grad_R(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G,
+                                int64_t ldg, hipStream_t st)
+{
+    constexpr int CW = 2, LW = 2;
+    const unsigned grid = (unsigned)((batch + CW - 1) / CW);
+    hipLaunchKernelGGL((k_grad<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, X, ldx, batch, ll, G, ldg);
+    return hipGetLastError();
+}
+
+#define MCD_DISPATCH_R(R_, CALL)                    \
+    switch (R_) {                                   \
+        case 1: return CALL(1);                     \
+        case 2: return CALL(2);                     \
+        case 3: return CALL(3);                     \
+        case 4: return CALL(4);                     \
+        case 6: return CALL(6);                     \
+        case 8: return CALL(8);                     \
+        case 12: return CALL(12);                   \
+        case 16: return CALL(16);                   \
+        default: return hipErrorInvalidValue;       \
+    }
+
+hipError_t launch_grad(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
+                       hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+#define CALL(R) launch_grad_R<R>(M, X, ldx, batch, ll, G, ldg, st)
+    MCD_DISPATCH_R(M.R, CALL)
+#undef CALL
+}
+
+}  // namespace mcd

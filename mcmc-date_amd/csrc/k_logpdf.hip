@@ -1,0 +1,139 @@
+// k_logpdf.hip -- batched log-density, raw x (gfx950).  Device code: mvn_device.hpp.
+#include "mvn_device.hpp"
+#include <stdio.h>
+
+namespace mcd {
+
+template <int R, int BT, int CW, int LW>
+__global__ void __launch_bounds__(64 * (CW + LW)) k_logpdf(MvnDev M, const double* __restrict__ X, int64_t ldx,
+                                                           int64_t batch, double* __restrict__ ll)
+{
+    MCD_KERNEL_HEAD
+    MCD_ACC_DECL
+    MCD_T(0);
+    if (wave >= CW) {                                      // loader role
+        Stage<R, LW> st;
+        const int lw = wave - CW;
+        fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
+        MCD_T(1);
+        lds_barrier();
+        MCD_T(2);
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        MCD_T(3);
+#ifdef MCD_EXP_TWICE   // timing experiment: a second, identical sweep in the same launch (warm caches)
+        lds_barrier();
+        fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
+        lds_barrier();
+        MCD_T(5);
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        MCD_T(6);
+#endif
+#ifndef MCD_EXP_TWICE
+        MCD_ACC_FLUSH(5);
+#endif
+        return;
+    }
+    double d[R][BT];
+    load_rawx<R, BT>(d, M, X, ldx, b0, batch, lane);
+    MCD_T(1);
+    lds_barrier();
+    MCD_T(2);
+    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    MCD_T(3);
+#ifdef MCD_EXP_TWICE
+    lds_barrier();
+    lds_barrier();
+    MCD_T(5);
+    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    MCD_T(6);
+#endif
+    finish_ll<R, BT>(d, M, b0, batch, ll, lane);
+    MCD_T(4);
+#ifndef MCD_EXP_TWICE
+    MCD_ACC_FLUSH(5);
+#endif
+}
+
+template <int R, int BT, int CW, int LW>
+static void launch_geom(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
+{
+    const int64_t per_wg = (int64_t)CW * BT;
+    const unsigned grid = (unsigned)((batch + per_wg - 1) / per_wg);
+    hipLaunchKernelGGL((k_logpdf<R, BT, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, X, ldx, batch, ll);
+}
+
+template <int R>
+static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
+{
+    Geometry g = pick_geometry(batch);
+#ifdef MCD_GEOM_EXPERIMENT   // tuning builds only: MCD_GEOM="cw,lw,bt" selects a geometry (R = 4 only)
+    if constexpr (R == 4) {
+        if (const char* e = getenv("MCD_GEOM")) {
+            int cw = 0, lw = 0, bt = 0;
+            sscanf(e, "%d,%d,%d", &cw, &lw, &bt);
+            if (cw == 8 && lw == 4 && bt == 1) { launch_geom<R, 1, 8, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 8 && lw == 4 && bt == 2) { launch_geom<R, 2, 8, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 4 && lw == 4 && bt == 1) { launch_geom<R, 1, 4, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 4 && lw == 4 && bt == 2) { launch_geom<R, 2, 4, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 6 && lw == 2 && bt == 1) { launch_geom<R, 1, 6, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 6 && lw == 2 && bt == 2) { launch_geom<R, 2, 6, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 4 && lw == 2 && bt == 1) { launch_geom<R, 1, 4, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 2 && lw == 2 && bt == 2) { launch_geom<R, 2, 2, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 3 && lw == 1 && bt == 1) { launch_geom<R, 1, 3, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 2 && lw == 1 && bt == 1) { launch_geom<R, 1, 2, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 1 && lw == 1 && bt == 1) { launch_geom<R, 1, 1, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+        }
+    }
+#endif
+    if (g.cw == 2)
+        launch_geom<R, 1, 2, 2>(M, X, ldx, batch, ll, st);
+    else
+        launch_geom<R, 2, 4, 2>(M, X, ldx, batch, ll, st);
+    return hipGetLastError();
+}
+
+#define MCD_DISPATCH_R(R_, CALL)                    \
+    switch (R_) {                                   \
+        case 1: return CALL(1);                     \
+        case 2: return CALL(2);                     \
+        case 3: return CALL(3);                     \
+        case 4: return CALL(4);                     \
+        case 6: return CALL(6);                     \
+        case 8: return CALL(8);                     \
+        case 12: return CALL(12);                   \
+        case 16: return CALL(16);                   \
+        default: return hipErrorInvalidValue;       \
+    }
+
+int sweep_chunk_columns(int R)
+{
+    // columns per chunk (Cfg<R>::CCOLS): the swept column count is rounded up to it (extra columns
+    // are zero padding).
+    return 2 * ((R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : (R <= 8) ? 4 : 2);
+}
+
+int padded_blocks(int n)
+{
+    const int r = (n + 63) / 64;
+    const int allowed[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int a : allowed)
+        if (r <= a) return a;
+    return -1;
+}
+
+hipError_t launch_logpdf(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+#define CALL(R) launch_logpdf_R<R>(M, X, ldx, batch, ll, st)
+    MCD_DISPATCH_R(M.R, CALL)
+#undef CALL
+}
+
+}  // namespace mcd
+
+#ifdef MCD_STAMP
+extern "C" int mcd_debug_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_dbg), 64 * sizeof(unsigned long long));
+}
+#endif

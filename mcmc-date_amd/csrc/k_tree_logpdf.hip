@@ -1,0 +1,70 @@
+// k_tree_logpdf.hip -- tree state -> log-likelihood (+ root-branch Jacobian) (gfx950).  Device code: mvn_device.hpp.
+#include "mvn_device.hpp"
+
+namespace mcd {
+
+template <int R, int BT, int CW, int LW>
+__global__ void __launch_bounds__(64 * (CW + LW)) k_tree_logpdf(MvnDev M, TreeDev T, const double* __restrict__ H,
+                                                                const double* __restrict__ Rt, int64_t lds,
+                                                                const double* __restrict__ tH,
+                                                                const double* __restrict__ rMu, int64_t batch,
+                                                                double* __restrict__ ll, double* __restrict__ logjac)
+{
+    MCD_KERNEL_HEAD
+    MCD_ACC_DECL
+    if (wave >= CW) {                                      // loader role
+        Stage<R, LW> st;
+        const int lw = wave - CW;
+        fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
+        lds_barrier();
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        return;
+    }
+    double d[R][BT], dist[R][BT];
+    load_tree<R, BT>(d, dist, M, T, H, Rt, lds, tH, rMu, b0, batch, lane);
+    if (logjac != nullptr && lane == 0) {
+#pragma unroll
+        for (int c = 0; c < BT; ++c)
+            if (b0 + c < batch) logjac[b0 + c] = log(1.0 / dist[0][c]);  // app/Probability.hs:394, 409
+    }
+    lds_barrier();
+    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    finish_ll<R, BT>(d, M, b0, batch, ll, lane);
+}
+
+template <int R>
+static hipError_t launch_tree_logpdf_R(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                                       const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
+                                       hipStream_t st)
+{
+    constexpr int CW = 2, LW = 2;
+    const unsigned grid = (unsigned)((batch + CW - 1) / CW);
+    hipLaunchKernelGGL((k_tree_logpdf<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu,
+                       batch, ll, logjac);
+    return hipGetLastError();
+}
+
+#define MCD_DISPATCH_R(R_, CALL)                    \
+    switch (R_) {                                   \
+        case 1: return CALL(1);                     \
+        case 2: return CALL(2);                     \
+        case 3: return CALL(3);                     \
+        case 4: return CALL(4);                     \
+        case 6: return CALL(6);                     \
+        case 8: return CALL(8);                     \
+        case 12: return CALL(12);                   \
+        case 16: return CALL(16);                   \
+        default: return hipErrorInvalidValue;       \
+    }
+
+hipError_t launch_tree_logpdf(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                              const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
+                              hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+#define CALL(R) launch_tree_logpdf_R<R>(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st)
+    MCD_DISPATCH_R(M.R, CALL)
+#undef CALL
+}
+
+}  // namespace mcd
