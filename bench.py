@@ -39,6 +39,21 @@ def algorithmic_flops_per_eval(n: int) -> float:
     return float(n) * n + 5.0 * n
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction applied): profiles/*_pmc_traffic.json of the
+    latest round, or None."""
+    import glob
+
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not fs:
+        return None
+    try:
+        return float(json.load(open(fs[-1]))["per_launch_bytes_corrected"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
     """The oracle in the reference's own algebra (Sigma^-1 dgemv + ddot, one evaluation per call,
     fresh dx buffer per call -- app/Probability.hs:167-173) on one host core."""
@@ -55,7 +70,7 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
         O.logpdf_full_batch(mu, P, logdet, sample, native=True)
         evals += len(sample)
         dt = time.perf_counter() - t0
-        if dt >= budget_s or evals >= 400 * len(sample):
+        if dt >= budget_s:
             break
     return {"value": evals / dt, "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": f"{evals} evaluations (sweeps over {len(sample)} of the bench's chains, n={n}) in {dt:.1f} s; "
@@ -226,7 +241,8 @@ def main():
                        "swap_period": args.swap_period, "parallelism": (f"chains sharded x{world}, no data-path collective" if gathered is None
                                        else f"chains sharded x{world} + ll all-gather every {args.swap_period} steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic() if (n == 256 and B == 512 and args.kind == "logpdf") else None,
                          "kernel_us_per_launch": per_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_b,
                          "fp64_tflops": flops, "fp64_frac": flops / FP64_PEAK_TFLOPS},

@@ -3,8 +3,8 @@
 
 namespace mcd {
 
-// Chain rule from g = d ll / d distances back to heights, rates, tH, rMu (SURVEY.md 8a A7;
-// oracle/mvn_oracle.c orc_tree_grad_full states the same formulas).  One chain per compute wave;
+// Chain rule from g = d ll / d distances back to heights, rates, tH, rMu (SURVEY.md 8a A7:
+// d ll/d r_v = s g t_v, d ll/d h_v = s (sum_children g_c r_c - g_v r_v), d ll/d tH = g.d / tH).  One chain per compute wave;
 // e[v] = s * g[row(v)] * rate[v] is exchanged through the (by then idle) LDS ring, one private
 // region per wave.
 template <int R, int CW, int LW>

@@ -1,0 +1,62 @@
+"""Chain sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+Chains are independent (each evaluation depends only on its own state and the shared immutable
+operands), so the likelihood path itself needs NO collective: every rank creates its own
+`MvnLikelihood` (operands replicated, <= 16 MB at N = 1024) and evaluates a contiguous block of chains.
+The only exchange is the sampler-level one of BASELINE.json config 5: an all-gather of the per-chain
+log-likelihoods every `swap_period` steps (MC3 swap / convergence diagnostics; the reference's
+in-process analogue is `MC3Settings (NChains 4) (SwapPeriod 2) (NSwaps 3)`, app/Main.hs:477).  It is
+a few KB per rank, latency bound: one all-gather (RCCL over xGMI on GPUs, gloo on CPU), no ring of
+small sends.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class ChainShard:
+    """Contiguous block [lo, hi) of the global chain index range owned by one rank."""
+    rank: int
+    world: int
+    n_chains: int
+
+    @property
+    def lo(self) -> int:
+        q, r = divmod(self.n_chains, self.world)
+        return self.rank * q + min(self.rank, r)
+
+    @property
+    def hi(self) -> int:
+        q, r = divmod(self.n_chains, self.world)
+        return self.lo + q + (1 if self.rank < r else 0)
+
+    @property
+    def size(self) -> int:
+        return self.hi - self.lo
+
+    def counts(self):
+        return [ChainShard(r, self.world, self.n_chains).size for r in range(self.world)]
+
+
+def gather_loglik(ll_local, shard: ChainShard):
+    """All-gather of per-chain log-likelihoods in global chain order (ragged shards allowed).
+
+    ll_local: 1-D torch tensor (CUDA with the nccl/RCCL backend, CPU with gloo) of length shard.size.
+    Returns a 1-D tensor of length shard.n_chains on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if shard.world == 1:
+        return ll_local.clone()
+    counts = shard.counts()
+    if len(set(counts)) == 1:
+        out = torch.empty(shard.n_chains, dtype=ll_local.dtype, device=ll_local.device)
+        dist.all_gather_into_tensor(out, ll_local.contiguous())
+        return out
+    m = max(counts)
+    pad = torch.zeros(m, dtype=ll_local.dtype, device=ll_local.device)
+    pad[: shard.size] = ll_local
+    out = torch.empty(shard.world * m, dtype=ll_local.dtype, device=ll_local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m: r * m + c] for r, c in enumerate(counts)])

@@ -1,0 +1,128 @@
+"""CPU tests of the host-side mirror (tree / state / data-file plumbing) and of the C-ABI surface."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mcmc_date_amd as M
+import oracle as O
+from mcmc_date_amd import _capi, synthetic as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------
+# C ABI: the library loads and exports exactly what include/mcmcdate_mvn.h declares
+# ---------------------------------------------------------------------------------------------
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mcmcdate_mvn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcd_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 15 and "mcd_mvn_logpdf_batch" in names and "mcd_tree_grad_batch" in names
+    lib = _capi.lib()                                   # raises if the .so is missing: no fallback
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mcmcdate_mvn.h but not exported"
+    assert sorted(_capi.SYMBOLS) == names               # the ctypes table covers the header exactly
+    assert b"gfx950" in lib.mcd_version()
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    lib = _capi.lib()
+    if lib.mcd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(M.NoDevice, match="no CPU path"):
+        M.MvnLikelihood.from_covariance(np.zeros(3), np.eye(3))
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "mcmc-date_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt and "mvn_oracle" not in txt, f
+
+
+# ---------------------------------------------------------------------------------------------
+# tree mirror (app/Tools.hs, lib/Mcmc/Tree/Types.hs) against the oracle
+# ---------------------------------------------------------------------------------------------
+def test_newick_and_branch_order():
+    topo, ln = M.parse_newick("((a:0.4,b:0.4)x:0.6,c:1.0):0.0;")
+    assert list(topo.parent) == [-1, 0, 1, 1, 0] and topo.names == ["", "x", "a", "b", "c"]
+    assert np.array_equal(M.get_branches(topo, ln), [0.6, 1.0, 0.4, 0.4])
+    assert np.array_equal(M.sum_first_two(M.get_branches(topo, ln)), [1.6, 0.4, 0.4])
+    assert list(M.branch_slots(topo)) == [-1, 0, 1, 2, 0]
+    h = np.array([1.0, 0.4, 0.0, 0.0, 0.0])
+    assert np.array_equal(M.height_tree_to_length_tree(topo, h), O.height_to_length(topo.parent, h))
+    with pytest.raises(M.TreeError, match="not bifurcating"):
+        M.get_branches(M.parse_newick("(a:1,b:1,c:1);")[0], np.zeros(4))
+    with pytest.raises(M.TreeError):
+        M.Topology(np.array([-1, 0, 3, 0], np.int32))          # not pre-order
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_topologies_match_oracle(seed):
+    topo = S.random_topology(7 + 5 * seed, seed)
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(topo.n_nodes)
+    assert np.array_equal(M.get_branches(topo, v), O.get_branches(topo.parent, v))
+    st = S.random_states(topo, 3, seed)
+    for b in range(3):
+        x = M.State(1.0, 1.0, st.time_height[b], st.heights[b], st.rate_mean[b], 1.0, st.rates[b])
+        x.rate_tree = x.rate_tree.copy()
+        x.rate_tree[0] = 0.0
+        assert x.is_valid(topo)
+        d = M.sum_first_two(M.get_branches(topo, M.height_tree_to_length_tree(topo, st.heights[b])) *
+                            M.get_branches(topo, st.rates[b])) * (st.time_height[b] * st.rate_mean[b])
+        assert np.allclose(d, O.distances(topo.parent, st.heights[b], st.rates[b], st.time_height[b], st.rate_mean[b]),
+                           rtol=1e-15)
+    bad = M.State(1.0, 1.0, 1.0, np.zeros(topo.n_nodes), 1.0, 1.0, np.ones(topo.n_nodes))
+    assert not bad.is_valid(topo)
+
+
+def test_fixture_trees_are_valid_states(golden):
+    fx = golden["12-leaves-variable-rate"]
+    topo = M.Topology(fx["parent"], list(fx["names"]))
+    assert topo.n_nodes == 23 and int(topo.leaves.sum()) == 12
+    for b in (0, 1, 63):
+        x = M.State(1.0, 1.0, fx["tH"][b], fx["H"][b], fx["rMu"][b], 1.0, fx["R"][b])
+        assert x.is_valid(topo)
+
+
+# ---------------------------------------------------------------------------------------------
+# .data files (app/Main.hs:75-99, 240, 286)
+# ---------------------------------------------------------------------------------------------
+def test_data_file_round_trip(tmp_path, golden):
+    fx = golden["06-leaves-constant-rate"]
+    full = M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))
+    p = tmp_path / "t.data"
+    M.write_data_file(str(p), full)
+    raw = json.load(open(p))
+    assert raw["tag"] == "FullS" and len(raw["contents"]) == 3 and len(raw["contents"][1]) == 9
+    back = M.read_data_file(str(p))
+    assert isinstance(back, M.Full) and np.array_equal(back.sigma_inv, fx["sigma_inv"]) and back.logdet_sigma == float(fx["logdet"])
+    for lhd in (M.Univariate(fx["mu"], np.diag(fx["sigma"])), M.Sparse(fx["mu"], [((0, 0), 2.0), ((1, 2), -0.5)], -3.0), M.NoData()):
+        M.write_data_file(str(p), lhd)
+        assert type(M.read_data_file(str(p))) is type(lhd)
+    p.write_text('{"tag": "Bogus"}')
+    with pytest.raises(ValueError, match="Could not decode"):
+        M.read_data_file(str(p))
+
+
+def test_synthetic_generators_are_deterministic():
+    mu1, s1 = S.random_spd_problem(64, 7)
+    mu2, s2 = S.random_spd_problem(64, 7)
+    assert np.array_equal(mu1, mu2) and np.array_equal(s1, s2)
+    assert np.all(np.linalg.eigvalsh(s1) > 0) and 1e-4 <= np.diag(s1).min() and np.diag(s1).max() <= 1e-3
+    X = S.sample_chains(mu1, s1, 8, 7)
+    assert X.shape == (8, 64) and np.array_equal(X, S.sample_chains(mu1, s1, 8, 7))
+    t = S.random_topology(129, 256)
+    assert t.n_nodes == 257 and t.n_nodes - 2 == 255
