@@ -1,0 +1,114 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+
+-- |
+-- Module      :  McmcDate.Gpu
+-- Description :  FFI shim: McmcDate's likelihood closure evaluated on an MI355X
+--
+-- SOURCE ONLY.  This file is the binding a maintainer of dschrempf/mcmc-date would add to
+-- @app/@ to use libmcmcdate_mvn.so (include/mcmcdate_mvn.h) as a drop-in for
+-- 'Probability.likelihoodFunction'.  It is NOT compiled in this repository: the build image has no
+-- GHC / cabal / stack.  INTEGRATION.md explains the three lines of @app/Main.hs@ that change.
+--
+-- The closure handed to the sampler keeps its type: @LikelihoodFunction I = I -> Log Double@
+-- (mcmc library), see app/Probability.hs:277 and app/Main.hs:333-347.
+module McmcDate.Gpu
+  ( McdMvn,
+    McdTree,
+    withGpuLikelihood,
+    likelihoodFunctionGpu,
+    jacobianRootBranchGpu,
+  )
+where
+
+import Control.Lens ((^.))
+import qualified Data.Vector.Storable as VS
+import Foreign
+import Foreign.C.String
+import Foreign.C.Types
+import Mcmc (LikelihoodFunction, JacobianFunction)
+import Mcmc.Tree (getHeightTree, getLengthTree)
+import qualified ELynx.Tree as T
+import qualified Numeric.LinearAlgebra as L
+import Numeric.Log (Log (Exp))
+import State (I, rateMean, rateTree, timeHeight, timeTree)
+import System.IO.Unsafe (unsafePerformIO)
+
+data McdMvn
+
+data McdTree
+
+-- include/mcmcdate_mvn.h
+foreign import ccall unsafe "mcd_mvn_create"
+  c_mvn_create :: Ptr (Ptr McdMvn) -> CInt -> Ptr CDouble -> Ptr CDouble -> CInt -> CDouble -> CInt -> IO CInt
+
+foreign import ccall unsafe "&mcd_mvn_destroy"
+  p_mvn_destroy :: FunPtr (Ptr McdMvn -> IO ())
+
+foreign import ccall unsafe "mcd_tree_create"
+  c_tree_create :: Ptr (Ptr McdTree) -> Ptr McdMvn -> CInt -> Ptr Int32 -> IO CInt
+
+foreign import ccall unsafe "&mcd_tree_destroy"
+  p_tree_destroy :: FunPtr (Ptr McdTree -> IO ())
+
+-- One state in, log-likelihood and log root-branch Jacobian out (batch = 1, host pointers).
+foreign import ccall unsafe "mcd_tree_loglik_batch"
+  c_tree_loglik ::
+    Ptr McdTree -> Ptr CDouble -> Ptr CDouble -> Int64 -> Ptr CDouble -> Ptr CDouble -> Int64 -> CInt -> Ptr () -> Ptr CDouble -> Ptr CDouble -> IO CInt
+
+foreign import ccall unsafe "mcd_last_error"
+  c_last_error :: IO CString
+
+check :: String -> CInt -> IO ()
+check _ 0 = pure ()
+check ctx _ = c_last_error >>= peekCString >>= \m -> error (ctx <> ": " <> m)
+
+-- | Pre-order parent array of a tree (root = 0, parent of the root = -1): the order of 'branches'.
+parents :: T.Tree e a -> [Int32]
+parents t = go (-1) 0 t `seq` reverse (snd (walk (-1) (0, []) t))
+  where
+    walk p (i, acc) (T.Node _ _ ts) = foldl (walk i) (i + 1, p : acc) ts
+    go _ _ _ = ()
+
+-- | Stage mu, Sigma^-1 and log det Sigma on GPU @dev@ once (replaces 'getLikelihoodFunction',
+-- app/Main.hs:333-347) and bind the topology of the mean tree.
+withGpuLikelihood ::
+  Int -> L.Vector Double -> L.Matrix Double -> Double -> T.Tree e a -> IO (ForeignPtr McdMvn, ForeignPtr McdTree)
+withGpuLikelihood dev mu sigmaInv logDetSigma tr = do
+  let n = VS.length mu
+      flat = L.flatten sigmaInv -- row-major
+  hm <- alloca $ \pp -> do
+    rc <- VS.unsafeWith (VS.map realToFrac mu) $ \pmu ->
+      VS.unsafeWith (VS.map realToFrac flat) $ \pm ->
+        c_mvn_create pp (fromIntegral n) pmu pm 1 (realToFrac logDetSigma) (fromIntegral dev)
+    check "mcd_mvn_create" rc
+    peek pp >>= newForeignPtr p_mvn_destroy
+  ht <- withForeignPtr hm $ \m -> alloca $ \pp -> do
+    let ps = VS.fromList (parents tr)
+    rc <- VS.unsafeWith ps $ \pps -> c_tree_create pp m (fromIntegral (VS.length ps)) pps
+    check "mcd_tree_create" rc
+    peek pp >>= newForeignPtr p_tree_destroy
+  pure (hm, ht)
+
+evalState :: ForeignPtr McdTree -> I -> (Double, Double)
+evalState ht x = unsafePerformIO $
+  withForeignPtr ht $ \t ->
+    VS.unsafeWith hs $ \ph -> VS.unsafeWith rs $ \pr ->
+      with (realToFrac (x ^. timeHeight)) $ \pth -> with (realToFrac (x ^. rateMean)) $ \prm ->
+        alloca $ \pll -> alloca $ \plj -> do
+          rc <- c_tree_loglik t ph pr (fromIntegral nn) pth prm 1 0 nullPtr pll plj
+          check "mcd_tree_loglik_batch" rc
+          (,) <$> (realToFrac <$> peek pll) <*> (realToFrac <$> peek plj)
+  where
+    -- pre-order node labels: relative heights of the time tree, relative rates of the rate tree
+    hs = VS.fromList $ map realToFrac $ T.branches $ getHeightTree (x ^. timeTree)
+    rs = VS.fromList $ map realToFrac $ T.branches $ getLengthTree (x ^. rateTree)
+    nn = VS.length hs
+{-# NOINLINE evalState #-}
+
+-- | Drop-in for @likelihoodFunction (Full mu sigmaInv logDetSigma)@ (app/Probability.hs:277-278).
+likelihoodFunctionGpu :: ForeignPtr McdTree -> LikelihoodFunction I
+likelihoodFunctionGpu ht = Exp . fst . evalState ht
+
+-- | Drop-in for 'jacobianRootBranch' (app/Probability.hs:408-410).
+jacobianRootBranchGpu :: ForeignPtr McdTree -> JacobianFunction I
+jacobianRootBranchGpu ht = Exp . snd . evalState ht

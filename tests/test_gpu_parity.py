@@ -300,3 +300,27 @@ def test_concurrent_callers(gpu, golden):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs
+
+
+def test_cpp_host_mirror(gpu, golden, tmp_path):
+    """The C++ mirror of the reference's plugin surface (mcmc-date_amd/host/mcmcdate.hpp) through the C ABI."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_host_mirror")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    fx = golden["12-leaves-variable-rate"]
+    b = 5
+    p = tmp_path / "fixture.txt"
+    with open(p, "w") as f:
+        f.write(f"{len(fx['parent'])}\n" + " ".join(map(str, fx["parent"])) + "\n")
+        f.write(" ".join(repr(float(v)) for v in fx["mu"]) + "\n")
+        f.write(" ".join(repr(float(v)) for v in fx["sigma_inv"].ravel()) + "\n")
+        f.write(repr(float(fx["logdet"])) + "\n")
+        f.write(f"{float(fx['tH'][b])!r} {float(fx['rMu'][b])!r}\n")
+        f.write(" ".join(repr(float(v)) for v in fx["H"][b]) + "\n")
+        f.write(" ".join(repr(float(v)) for v in fx["R"][b]) + "\n")
+        f.write(f"{float(fx['ll_S'][b])!r} {float(fx['lj_S'][b])!r}\n")
+    r = subprocess.run([exe, str(p)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("ok")
