@@ -1,5 +1,6 @@
 // k_grad.hip -- log-density + gradient wrt x (gfx950).  Device code: mvn_device.hpp.
 #include "mvn_device.hpp"
+#include <type_traits>
 
 namespace mcd {
 
@@ -15,15 +16,15 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_grad(MvnDev M, const double*
         const int lw = wave - CW;
         fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
         lds_barrier();
-        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
         bool started = false;
-        bwd_loader<R, LW, R - 1>(M.Ut, ring, st, lw, lane, M.ncols, started);
+        bwd_loader<R, LW, R - 1>(M.Ut, ring, st, lw, lane, ncols, started);
         return;
     }
     double d[R][BT];
     load_rawx<R, BT>(d, M, X, ldx, b0, batch, lane);
     lds_barrier();
-    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    fwd_compute<R, BT, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
     finish_ll<R, BT>(d, M, b0, batch, ll, lane);
     // backward: y = L^-T z.  Row scaling first (z_r / L_rr), then the mirrored sweep.
 #pragma unroll
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_grad(MvnDev M, const double*
         for (int c = 0; c < BT; ++c) d[k][c] *= iv;
     }
     bool started = false;
-    bwd_compute<R, BT, R - 1>(d, ring, lane, M.ncols, started);
+    bwd_compute<R, BT, R - 1>(d, ring, lane, ncols, started);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int row = 64 * k + lane;
@@ -47,9 +48,15 @@ template <int R>
 static hipError_t launch_grad_R(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G,
                                 int64_t ldg, hipStream_t st)
 {
-    constexpr int CW = 2, LW = 2;
-    const unsigned grid = (unsigned)((batch + CW - 1) / CW);
-    hipLaunchKernelGGL((k_grad<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, X, ldx, batch, ll, G, ldg);
+    auto go = [&](auto cw_tag) {
+        constexpr int CW = decltype(cw_tag)::value, LW = 2;
+        const unsigned grid = (unsigned)((batch + CW - 1) / CW);
+        hipLaunchKernelGGL((k_grad<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, X, ldx, batch, ll, G, ldg);
+    };
+    if (pick_geometry(batch).cw == 2)
+        go(std::integral_constant<int, 2>{});
+    else
+        go(std::integral_constant<int, 4>{});
     return hipGetLastError();
 }
 

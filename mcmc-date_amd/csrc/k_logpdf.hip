@@ -18,14 +18,14 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_logpdf(MvnDev M, const doubl
         MCD_T(1);
         lds_barrier();
         MCD_T(2);
-        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
         MCD_T(3);
 #ifdef MCD_EXP_TWICE   // timing experiment: a second, identical sweep in the same launch (warm caches)
         lds_barrier();
         fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
         lds_barrier();
         MCD_T(5);
-        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
         MCD_T(6);
 #endif
 #ifndef MCD_EXP_TWICE
@@ -38,13 +38,13 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_logpdf(MvnDev M, const doubl
     MCD_T(1);
     lds_barrier();
     MCD_T(2);
-    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    fwd_compute<R, BT, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
     MCD_T(3);
 #ifdef MCD_EXP_TWICE
     lds_barrier();
     lds_barrier();
     MCD_T(5);
-    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    fwd_compute<R, BT, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
     MCD_T(6);
 #endif
     finish_ll<R, BT>(d, M, b0, batch, ll, lane);
@@ -67,7 +67,7 @@ static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx,
 {
     Geometry g = pick_geometry(batch);
 #ifdef MCD_GEOM_EXPERIMENT   // tuning builds only: MCD_GEOM="cw,lw,bt" selects a geometry (R = 4 only)
-    if constexpr (R == 4) {
+    if constexpr (R == 4 || R == 16) {
         if (const char* e = getenv("MCD_GEOM")) {
             int cw = 0, lw = 0, bt = 0;
             sscanf(e, "%d,%d,%d", &cw, &lw, &bt);
@@ -82,11 +82,15 @@ static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx,
             if (cw == 3 && lw == 1 && bt == 1) { launch_geom<R, 1, 3, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
             if (cw == 2 && lw == 1 && bt == 1) { launch_geom<R, 1, 2, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
             if (cw == 1 && lw == 1 && bt == 1) { launch_geom<R, 1, 1, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 2 && lw == 4 && bt == 1) { launch_geom<R, 1, 2, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
+            if (cw == 2 && lw == 3 && bt == 1) { launch_geom<R, 1, 2, 3>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
         }
     }
 #endif
     if (g.cw == 2)
         launch_geom<R, 1, 2, 2>(M, X, ldx, batch, ll, st);
+    else if (g.bt == 1)
+        launch_geom<R, 1, 4, 2>(M, X, ldx, batch, ll, st);
     else
         launch_geom<R, 2, 4, 2>(M, X, ldx, batch, ll, st);
     return hipGetLastError();

@@ -1,5 +1,6 @@
 // k_tree_grad.hip -- tree state -> log-likelihood + gradient wrt the state (gfx950).  Device code: mvn_device.hpp.
 #include "mvn_device.hpp"
+#include <type_traits>
 
 namespace mcd {
 
@@ -24,21 +25,21 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_tree_grad(MvnDev M, TreeDev 
         const int lw = wave - CW;
         fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
         lds_barrier();
-        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
         bool started = false;
-        bwd_loader<R, LW, R - 1>(M.Ut, ring, st, lw, lane, M.ncols, started);
+        bwd_loader<R, LW, R - 1>(M.Ut, ring, st, lw, lane, ncols, started);
         return;
     }
     double d[R][1], dist[R][1];
     load_tree<R, 1>(d, dist, M, T, H, Rt, lds, tH, rMu, b0, batch, lane);
     lds_barrier();
-    fwd_compute<R, 1, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    fwd_compute<R, 1, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
     finish_ll<R, 1>(d, M, b0, batch, ll, lane);
 #pragma unroll
     for (int k = 0; k < R; ++k) d[k][0] *= M.invdiag[64 * k + lane];
     {
         bool started = false;
-        bwd_compute<R, 1, R - 1>(d, ring, lane, M.ncols, started);
+        bwd_compute<R, 1, R - 1>(d, ring, lane, ncols, started);
     }
     // now d = y = Sigma^-1 (dist - mu); g = -y.  The last barrier of the sweep has passed: the ring
     // is free.  n_nodes_pad <= 64 R + 64 doubles per compute wave fit in it (CW * 8.5 KiB <= 64 KiB).
@@ -87,10 +88,16 @@ static hipError_t launch_tree_grad_R(const MvnDev& M, const TreeDev& T, const do
                                      const double* tH, const double* rMu, int64_t batch, double* ll, double* gH,
                                      double* gR, double* gtH, double* grMu, hipStream_t st)
 {
-    constexpr int CW = 2, LW = 2;
-    const unsigned grid = (unsigned)((batch + CW - 1) / CW);
-    hipLaunchKernelGGL((k_tree_grad<R, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch,
+    auto go = [&](auto cw_tag) {
+        constexpr int CW = decltype(cw_tag)::value, LW = 2;
+        const unsigned grid = (unsigned)((batch + CW - 1) / CW);
+        hipLaunchKernelGGL((k_tree_grad<R, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch,
                        ll, gH, gR, gtH, grMu);
+    };
+    if (pick_geometry(batch).cw == 2)
+        go(std::integral_constant<int, 2>{});
+    else
+        go(std::integral_constant<int, 4>{});
     return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 // k_tree_logpdf.hip -- tree state -> log-likelihood (+ root-branch Jacobian) (gfx950).  Device code: mvn_device.hpp.
 #include "mvn_device.hpp"
+#include <type_traits>
 
 namespace mcd {
 
@@ -17,7 +18,7 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_tree_logpdf(MvnDev M, TreeDe
         const int lw = wave - CW;
         fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
         lds_barrier();
-        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, M.ncols MCD_ACC_ARGS);
+        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
         return;
     }
     double d[R][BT], dist[R][BT];
@@ -28,7 +29,7 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_tree_logpdf(MvnDev M, TreeDe
             if (b0 + c < batch) logjac[b0 + c] = log(1.0 / dist[0][c]);  // app/Probability.hs:394, 409
     }
     lds_barrier();
-    fwd_compute<R, BT, 0>(d, ring, lane, M.ncols MCD_ACC_ARGS);
+    fwd_compute<R, BT, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
     finish_ll<R, BT>(d, M, b0, batch, ll, lane);
 }
 
@@ -37,10 +38,16 @@ static hipError_t launch_tree_logpdf_R(const MvnDev& M, const TreeDev& T, const 
                                        const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
                                        hipStream_t st)
 {
-    constexpr int CW = 2, LW = 2;
-    const unsigned grid = (unsigned)((batch + CW - 1) / CW);
-    hipLaunchKernelGGL((k_tree_logpdf<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu,
+    auto go = [&](auto cw_tag) {
+        constexpr int CW = decltype(cw_tag)::value, LW = 2;
+        const unsigned grid = (unsigned)((batch + CW - 1) / CW);
+        hipLaunchKernelGGL((k_tree_logpdf<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu,
                        batch, ll, logjac);
+    };
+    if (pick_geometry(batch).cw == 2)
+        go(std::integral_constant<int, 2>{});
+    else
+        go(std::integral_constant<int, 4>{});
     return hipGetLastError();
 }
 

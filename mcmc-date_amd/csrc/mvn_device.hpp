@@ -42,7 +42,10 @@ namespace mcd {
 // memcpy, which pins register arrays to scratch)
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int SLOT_UNITS = 32;       // 1-KiB units per LDS ring slot
+#ifndef MCD_SLOT_UNITS
+#define MCD_SLOT_UNITS 32
+#endif
+constexpr int SLOT_UNITS = MCD_SLOT_UNITS;       // 1-KiB units per LDS ring slot
 constexpr int RING_BYTES = 2 * SLOT_UNITS * 1024;
 
 // ---------------------------------------------------------------------------------------
@@ -77,6 +80,9 @@ __device__ __forceinline__ double wave_sum(double v)
 
 // All LDS operations of this wave done, then workgroup barrier.  Deliberately NOT __syncthreads():
 // that would also drain vmcnt and serialise the global prefetch that is still in flight.
+// NOTE: pointers into the LDS ring must never be __restrict__: other waves rewrite the ring between
+// barriers, and with a noalias pointer the compiler may keep values loaded from a slot across the
+// barrier (seen once: chunk ci+2 computed with chunk ci's factor values when registers allowed it).
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -130,7 +136,8 @@ __device__ __forceinline__ void mcd_acc(int idx, unsigned long long& tprev, unsi
 template <int R>
 struct Cfg {
     // column pairs per chunk: CP * R <= SLOT_UNITS
-    static constexpr int CP = (R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : (R <= 8) ? 4 : 2;
+    static constexpr int CP0 = (R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : (R <= 8) ? 4 : 2;
+    static constexpr int CP = (CP0 * (SLOT_UNITS / 32) > 32) ? 32 : CP0 * (SLOT_UNITS / 32);
     static constexpr int CPB = 32 / CP;                     // chunks per 64-column block
     static constexpr int NCHUNK = R * CPB;
     static constexpr int CCOLS = 2 * CP;                    // columns per chunk
@@ -164,7 +171,7 @@ __device__ __forceinline__ void stage_load(Stage<R, LW>& st, const double* __res
 }
 
 template <int R, int LW, int KLO, int KHI, int SET>
-__device__ __forceinline__ void stage_store(const Stage<R, LW>& st, d2* __restrict__ slot, int lw, int lane)
+__device__ __forceinline__ void stage_store(const Stage<R, LW>& st, d2* slot, int lw, int lane)
 {
     constexpr int NU = Cfg<R>::CP * (KHI - KLO);
 #pragma unroll
@@ -192,7 +199,7 @@ constexpr int LDS_PD = 2;
 // =======================================================================================
 // Apply one chunk (CP column pairs starting at column offset jj0 of block JB) from an LDS slot.
 template <int R, int BT, int JB, int JJ0>
-__device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const d2* __restrict__ slot, int lane)
+__device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const d2* slot, int lane)
 {
     constexpr int jj0 = JJ0;
     constexpr int CP = Cfg<R>::CP;
@@ -260,7 +267,7 @@ __device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const d2* __restri
 // The chunk index is a compile-time constant so that every v_readlane has an immediate lane
 // select (a lane select in a freshly written SGPR costs ~9 cycles per column, lat2.hip).
 template <int R, int BT, int JB, int LC>
-__device__ __forceinline__ bool fwd_compute_chunks(double (&d)[R][BT], const d2* __restrict__ ring, int lane, int ncols MCD_ACC_PARAMS)
+__device__ __forceinline__ bool fwd_compute_chunks(double (&d)[R][BT], const d2* ring, int lane, int ncols MCD_ACC_PARAMS)
 {
     using C = Cfg<R>;
     if constexpr (LC < C::CPB) {
@@ -278,7 +285,7 @@ __device__ __forceinline__ bool fwd_compute_chunks(double (&d)[R][BT], const d2*
 }
 
 template <int R, int BT, int JB>
-__device__ __forceinline__ void fwd_compute(double (&d)[R][BT], const d2* __restrict__ ring, int lane, int ncols MCD_ACC_PARAMS)
+__device__ __forceinline__ void fwd_compute(double (&d)[R][BT], const d2* ring, int lane, int ncols MCD_ACC_PARAMS)
 {
     if constexpr (JB < R) {
         if (!fwd_compute_chunks<R, BT, JB, 0>(d, ring, lane, ncols MCD_ACC_ARGS)) return;
@@ -292,7 +299,7 @@ __device__ __forceinline__ void fwd_compute(double (&d)[R][BT], const d2* __rest
 // here.  The LDS write of chunk ci+1 goes to slot SLOT^1, which every compute wave has finished
 // reading (barrier of chunk ci-1).
 template <int R, int LW, int JB, int JB1, int JB3, int SLOT>
-__device__ __forceinline__ bool fwd_loader_chunk(const double* __restrict__ Ft, d2* __restrict__ ring, Stage<R, LW>& st,
+__device__ __forceinline__ bool fwd_loader_chunk(const double* __restrict__ Ft, d2* ring, Stage<R, LW>& st,
                                                  int lw, int lane, int ncols, int lc MCD_ACC_PARAMS)
 {
     using C = Cfg<R>;
@@ -309,7 +316,7 @@ __device__ __forceinline__ bool fwd_loader_chunk(const double* __restrict__ Ft, 
 }
 
 template <int R, int LW, int JB, int LC>
-__device__ __forceinline__ bool fwd_loader_tail(const double* __restrict__ Ft, d2* __restrict__ ring, Stage<R, LW>& st,
+__device__ __forceinline__ bool fwd_loader_tail(const double* __restrict__ Ft, d2* ring, Stage<R, LW>& st,
                                                 int lw, int lane, int ncols MCD_ACC_PARAMS)
 {
     constexpr int CPB = Cfg<R>::CPB;
@@ -325,7 +332,7 @@ __device__ __forceinline__ bool fwd_loader_tail(const double* __restrict__ Ft, d
 }
 
 template <int R, int LW, int JB>
-__device__ __forceinline__ void fwd_loader(const double* __restrict__ Ft, d2* __restrict__ ring, Stage<R, LW>& st, int lw,
+__device__ __forceinline__ void fwd_loader(const double* __restrict__ Ft, d2* ring, Stage<R, LW>& st, int lw,
                                            int lane, int ncols MCD_ACC_PARAMS)
 {
     constexpr int CPB = Cfg<R>::CPB;
@@ -342,7 +349,7 @@ __device__ __forceinline__ void fwd_loader(const double* __restrict__ Ft, d2* __
 
 // chunks 0, 1, 2 requested, chunk 0 written to slot 0 (the caller's barrier publishes it)
 template <int R, int LW>
-__device__ __forceinline__ void fwd_loader_prologue(const double* __restrict__ Ft, d2* __restrict__ ring,
+__device__ __forceinline__ void fwd_loader_prologue(const double* __restrict__ Ft, d2* ring,
                                                     Stage<R, LW>& st, int lw, int lane)
 {
     using C = Cfg<R>;
@@ -358,7 +365,7 @@ __device__ __forceinline__ void fwd_loader_prologue(const double* __restrict__ F
 // one that holds column ncols-1 down to chunk 0, columns inside a chunk from high to low.
 // =======================================================================================
 template <int R, int BT, int IB, int II0>
-__device__ __forceinline__ void bwd_apply(double (&d)[R][BT], const d2* __restrict__ slot, int lane)
+__device__ __forceinline__ void bwd_apply(double (&d)[R][BT], const d2* slot, int lane)
 {
     constexpr int ii0 = II0;
     constexpr int CP = Cfg<R>::CP;
@@ -419,7 +426,7 @@ __device__ __forceinline__ void bwd_apply(double (&d)[R][BT], const d2* __restri
 // `started` is false until the top chunk (the first one with columns < ncols) is reached; the
 // loaders publish it with one extra barrier that the compute waves match here.
 template <int R, int BT, int IB, int LC>
-__device__ __forceinline__ void bwd_compute_chunks(double (&d)[R][BT], const d2* __restrict__ ring, int lane, int ncols,
+__device__ __forceinline__ void bwd_compute_chunks(double (&d)[R][BT], const d2* ring, int lane, int ncols,
                                                    bool& started)
 {
     using C = Cfg<R>;
@@ -438,7 +445,7 @@ __device__ __forceinline__ void bwd_compute_chunks(double (&d)[R][BT], const d2*
 }
 
 template <int R, int BT, int IB>
-__device__ __forceinline__ void bwd_compute(double (&d)[R][BT], const d2* __restrict__ ring, int lane, int ncols,
+__device__ __forceinline__ void bwd_compute(double (&d)[R][BT], const d2* ring, int lane, int ncols,
                                             bool& started)
 {
     if constexpr (IB >= 0) {
@@ -449,7 +456,7 @@ __device__ __forceinline__ void bwd_compute(double (&d)[R][BT], const d2* __rest
 
 // ---- loader role --------------------------------------------------------------------------
 template <int R, int LW, int IB, int IB1, int IB2, int IB3, int SLOT>
-__device__ __forceinline__ void bwd_loader_chunk(const double* __restrict__ Ut, d2* __restrict__ ring, Stage<R, LW>& st,
+__device__ __forceinline__ void bwd_loader_chunk(const double* __restrict__ Ut, d2* ring, Stage<R, LW>& st,
                                                  int lw, int lane, int ncols, int lc, bool& started)
 {
     using C = Cfg<R>;
@@ -469,7 +476,7 @@ __device__ __forceinline__ void bwd_loader_chunk(const double* __restrict__ Ut, 
 }
 
 template <int R, int LW, int IB, int LC>
-__device__ __forceinline__ void bwd_loader_tail(const double* __restrict__ Ut, d2* __restrict__ ring, Stage<R, LW>& st,
+__device__ __forceinline__ void bwd_loader_tail(const double* __restrict__ Ut, d2* ring, Stage<R, LW>& st,
                                                 int lw, int lane, int ncols, bool& started)
 {
     constexpr int CPB = Cfg<R>::CPB;
@@ -484,7 +491,7 @@ __device__ __forceinline__ void bwd_loader_tail(const double* __restrict__ Ut, d
 }
 
 template <int R, int LW, int IB>
-__device__ __forceinline__ void bwd_loader(const double* __restrict__ Ut, d2* __restrict__ ring, Stage<R, LW>& st, int lw,
+__device__ __forceinline__ void bwd_loader(const double* __restrict__ Ut, d2* ring, Stage<R, LW>& st, int lw,
                                            int lane, int ncols, bool& started)
 {
     constexpr int CPB = Cfg<R>::CPB;
@@ -581,7 +588,8 @@ __device__ __forceinline__ void finish_ll(const double (&d)[R][BT], const MvnDev
     __shared__ d2 ring[RING_BYTES / sizeof(d2)];                                \
     const int lane = threadIdx.x & 63;                                          \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          \
-    const int64_t b0 = ((int64_t)blockIdx.x * CW + wave) * BT;
+    const int64_t b0 = ((int64_t)blockIdx.x * CW + wave) * BT;                   \
+    const int ncols = M.ncols;   /* swept columns: N rounded up to whole chunks (host: sweep_chunk_columns) */
 
 // launch geometry by batch size (host side)
 struct Geometry {
@@ -589,10 +597,13 @@ struct Geometry {
 };
 static inline Geometry pick_geometry(int64_t batch)
 {
-    // Few chains (a sampler's usual batch): 2 compute waves + 2 loaders per workgroup so that every
+    // <= 512 chains (a sampler's usual batch): 2 compute waves + 2 loaders per workgroup, so that every
     // chain gets a SIMD to itself and all 256 CUs take part in pulling the factor out of L2.
-    // Many chains: 4 compute waves x 2 chains share each pass over the factor.
-    if (batch <= 2048) return {2, 2, 1};
+    // Up to 4096 chains: 4 compute waves per workgroup keep the grid within one wave of workgroups
+    // per CU for longer (measured at N = 256, B = 1024: 9.5 us against 14.4 us).
+    // More: 4 compute waves x 2 chains share each pass over the factor.
+    if (batch <= 512) return {2, 2, 1};
+    if (batch <= 4096) return {4, 2, 1};
     return {4, 2, 2};
 }
 

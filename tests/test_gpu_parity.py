@@ -181,6 +181,27 @@ def test_large_batch_two_chains_per_wave(gpu):
     assert np.max(rel_err(ll[-50:], ref)) <= 1e-9
 
 
+@pytest.mark.parametrize("n", [100, 200, 300, 500])
+def test_every_launch_geometry(gpu, n):
+    """The three workgroup geometries (<= 512, <= 4096, > 4096 chains) must agree chain by chain.
+    Regression: a noalias pointer into the LDS ring once let the compiler reuse a slot's values across
+    the barrier in some instantiations only."""
+    mu, sigma = S.random_spd_problem(n, seed=n)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    X = S.sample_chains(mu, sigma, 5000, seed=n)
+    ref = O.logpdf_full_batch(mu, P, logdet, X[:40])
+    outs = [lik.logpdf(X[:B])[:40] for B in (40, 600, 5000)]
+    for o in outs:
+        assert np.max(rel_err(o, ref)) <= 1e-9
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    ll, G = lik.grad(X[:600])
+    Gref = O.grad_full_batch(mu, P, X[:8])
+    assert np.max(np.abs(G[:8] - Gref)) <= 1e-9 * np.abs(Gref).max()
+    assert np.array_equal(ll[:40], outs[0])
+
+
 def test_synthetic_tree_256(gpu):
     """Config 3 tree variant: L = 129 leaves -> N = 255 (2L-3 is odd; 256 itself cannot be a tree)."""
     topo = S.random_topology(129, seed=256)
