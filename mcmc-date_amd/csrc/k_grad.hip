@@ -60,23 +60,46 @@ static hipError_t launch_grad_R(const MvnDev& M, const double* X, int64_t ldx, i
     return hipGetLastError();
 }
 
-#define MCD_DISPATCH_R(R_, CALL)                    \
-    switch (R_) {                                   \
-        case 1: return CALL(1);                     \
-        case 2: return CALL(2);                     \
-        case 3: return CALL(3);                     \
-        case 4: return CALL(4);                     \
-        case 6: return CALL(6);                     \
-        case 8: return CALL(8);                     \
-        case 12: return CALL(12);                   \
-        case 16: return CALL(16);                   \
-        default: return hipErrorInvalidValue;       \
-    }
+// Each kernel file is compiled four times (-DMCD_RGROUP=0: R in {1,2,3,4}; 1: {6,8}; 2: {12}; 3: {16}) so that
+// the template instantiations build in parallel and the big ones never share a translation unit.
+#ifndef MCD_RGROUP
+#define MCD_RGROUP 0
+#endif
+#if MCD_RGROUP == 0
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4); default: return hipErrorInvalidValue; }
+#elif MCD_RGROUP == 1
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 6: return CALL(6); case 8: return CALL(8); default: return hipErrorInvalidValue; }
+#elif MCD_RGROUP == 2
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 12: return CALL(12); default: return hipErrorInvalidValue; }
+#else
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 16: return CALL(16); default: return hipErrorInvalidValue; }
+#endif
+#define MCD_CAT2(a, b) a##b
+#define MCD_CAT(a, b) MCD_CAT2(a, b)
 
+#if MCD_RGROUP == 0
+hipError_t launch_grad_g1(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
+                       hipStream_t st);
+hipError_t launch_grad_g2(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
+                       hipStream_t st);
+hipError_t launch_grad_g3(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
+                       hipStream_t st);
 hipError_t launch_grad(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
                        hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (M.R == 6 || M.R == 8) return launch_grad_g1(M, X, ldx, batch, ll, G, ldg, st);
+    if (M.R == 12) return launch_grad_g2(M, X, ldx, batch, ll, G, ldg, st);
+    if (M.R == 16) return launch_grad_g3(M, X, ldx, batch, ll, G, ldg, st);
+#else
+hipError_t MCD_CAT(launch_grad_g, MCD_RGROUP)(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
+                       hipStream_t st)
+{
+#endif
 #define CALL(R) launch_grad_R<R>(M, X, ldx, batch, ll, G, ldg, st)
     MCD_DISPATCH_R(M.R, CALL)
 #undef CALL

@@ -51,24 +51,51 @@ static hipError_t launch_tree_logpdf_R(const MvnDev& M, const TreeDev& T, const 
     return hipGetLastError();
 }
 
-#define MCD_DISPATCH_R(R_, CALL)                    \
-    switch (R_) {                                   \
-        case 1: return CALL(1);                     \
-        case 2: return CALL(2);                     \
-        case 3: return CALL(3);                     \
-        case 4: return CALL(4);                     \
-        case 6: return CALL(6);                     \
-        case 8: return CALL(8);                     \
-        case 12: return CALL(12);                   \
-        case 16: return CALL(16);                   \
-        default: return hipErrorInvalidValue;       \
-    }
+// Each kernel file is compiled four times (-DMCD_RGROUP=0: R in {1,2,3,4}; 1: {6,8}; 2: {12}; 3: {16}) so that
+// the template instantiations build in parallel and the big ones never share a translation unit.
+#ifndef MCD_RGROUP
+#define MCD_RGROUP 0
+#endif
+#if MCD_RGROUP == 0
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4); default: return hipErrorInvalidValue; }
+#elif MCD_RGROUP == 1
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 6: return CALL(6); case 8: return CALL(8); default: return hipErrorInvalidValue; }
+#elif MCD_RGROUP == 2
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 12: return CALL(12); default: return hipErrorInvalidValue; }
+#else
+#define MCD_DISPATCH_R(R_, CALL) \
+    switch (R_) { case 16: return CALL(16); default: return hipErrorInvalidValue; }
+#endif
+#define MCD_CAT2(a, b) a##b
+#define MCD_CAT(a, b) MCD_CAT2(a, b)
 
+#if MCD_RGROUP == 0
+hipError_t launch_tree_logpdf_g1(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                              const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
+                              hipStream_t st);
+hipError_t launch_tree_logpdf_g2(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                              const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
+                              hipStream_t st);
+hipError_t launch_tree_logpdf_g3(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                              const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
+                              hipStream_t st);
 hipError_t launch_tree_logpdf(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
                               const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
                               hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (M.R == 6 || M.R == 8) return launch_tree_logpdf_g1(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st);
+    if (M.R == 12) return launch_tree_logpdf_g2(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st);
+    if (M.R == 16) return launch_tree_logpdf_g3(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st);
+#else
+hipError_t MCD_CAT(launch_tree_logpdf_g, MCD_RGROUP)(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
+                              const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
+                              hipStream_t st)
+{
+#endif
 #define CALL(R) launch_tree_logpdf_R<R>(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st)
     MCD_DISPATCH_R(M.R, CALL)
 #undef CALL
