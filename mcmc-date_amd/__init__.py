@@ -8,6 +8,7 @@ from . import _capi
 from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating
 from .likelihood import (Full, LikelihoodData, MvnLikelihood, NoData, Sparse, TreeLikelihood, Univariate,
                          jacobian_root_branch, likelihood_function, read_data_file, write_data_file)
+from .hamiltonian import from_vector_with, get_mask, grad_to_vector, to_vector
 from .state import State, StateBatch
 from .tree import (Topology, TreeError, branch_slots, get_branches, height_tree_to_length_tree, parse_newick,
                    read_newick_file, sum_first_two)
@@ -17,5 +18,6 @@ __all__ = [
     "likelihood_function", "jacobian_root_branch", "read_data_file", "write_data_file",
     "State", "StateBatch", "Topology", "TreeError", "parse_newick", "read_newick_file", "get_branches",
     "sum_first_two", "branch_slots", "height_tree_to_length_tree",
+    "get_mask", "to_vector", "from_vector_with", "grad_to_vector",
     "McdError", "NotPositiveDefinite", "RootNotBifurcating", "NoDevice",
 ]

@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_tree_grad(MvnDev M, TreeDev 
         const int lw = wave - CW;
         fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
         lds_barrier();
+        fwd_loader_start<R, LW>(M.Ft, st, lw, lane);
         fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
         bool started = false;
         bwd_loader<R, LW, R - 1>(M.Ut, ring, st, lw, lane, ncols, started);

@@ -347,15 +347,23 @@ __device__ __forceinline__ void fwd_loader(const double* __restrict__ Ft, d2* ri
     }
 }
 
-// chunks 0, 1, 2 requested, chunk 0 written to slot 0 (the caller's barrier publishes it)
+// Start of the stream.  Only chunk 0 is requested before the first barrier: the compute waves' state loads
+// share the CU's memory pipeline with the loaders, and a deeper initial burst (chunks 0-2 = 96 KiB)
+// held the first barrier back by ~1.5k cycles.  Chunks 1 and 2 are requested right after the barrier
+// (fwd_loader_start), while the compute waves apply chunk 0.
 template <int R, int LW>
-__device__ __forceinline__ void fwd_loader_prologue(const double* __restrict__ Ft, d2* ring,
-                                                    Stage<R, LW>& st, int lw, int lane)
+__device__ __forceinline__ void fwd_loader_prologue(const double* __restrict__ Ft, d2* ring, Stage<R, LW>& st, int lw,
+                                                    int lane)
+{
+    stage_load<R, LW, 0, R, 0>(st, Ft, 0, lw, lane);
+    stage_store<R, LW, 0, R, 0>(st, ring, lw, lane);
+}
+
+template <int R, int LW>
+__device__ __forceinline__ void fwd_loader_start(const double* __restrict__ Ft, Stage<R, LW>& st, int lw, int lane)
 {
     using C = Cfg<R>;
-    stage_load<R, LW, 0, R, 0>(st, Ft, 0, lw, lane);
     if constexpr (C::NCHUNK > 1) stage_load<R, LW, 1 / C::CPB, R, 1>(st, Ft, C::CP, lw, lane);
-    stage_store<R, LW, 0, R, 0>(st, ring, lw, lane);
     if constexpr (C::NCHUNK > 2) stage_load<R, LW, 2 / C::CPB, R, 0>(st, Ft, 2 * C::CP, lw, lane);
 }
 

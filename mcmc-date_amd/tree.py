@@ -9,6 +9,7 @@ evaluation of the same formulas happens inside the HIP kernels (csrc/mvn_kernels
 from __future__ import annotations
 
 import gzip
+import re
 from dataclasses import dataclass, field
 from typing import List, Sequence
 
@@ -73,7 +74,7 @@ class Topology:
 
 def parse_newick(s: str):
     """Newick string -> (Topology, branch lengths per pre-order node)."""
-    s = s.strip()
+    s = re.sub(r"\[[^\]]*\]", "", s).strip()      # Newick comments / annotations such as [&index=25]
     if not s.endswith(";"):
         raise TreeError("newick: missing ';'")
     pos = 0
@@ -115,7 +116,7 @@ def read_newick_file(path: str):
     """All trees of a Newick file (gz aware, cf. lib/Mcmc/Tree/Import.hs:61-76)."""
     op = gzip.open if path.endswith(".gz") else open
     with op(path, "rt") as f:
-        txt = f.read().replace("\n", "")
+        txt = re.sub(r"\[[^\]]*\]", "", f.read()).replace("\n", "")
     return [parse_newick(t + ";") for t in txt.split(";") if t.strip()]
 
 

@@ -12,6 +12,7 @@ Trees are held as pre-order arrays (see oracle/mvn_oracle.c header).
 from __future__ import annotations
 
 import gzip
+import re
 from dataclasses import dataclass
 
 import numpy as np
@@ -53,7 +54,7 @@ def subtree_size(parent, v):
 
 def parse_newick(s: str) -> PTree:
     """Minimal Newick reader (names, branch lengths, no comments/quotes)."""
-    s = s.strip()
+    s = re.sub(r"\[[^\]]*\]", "", s).strip()      # drop Newick comments / annotations
     assert s.endswith(";"), "newick string must end with ';'"
     pos = 0
     parent, length, name = [], [], []
@@ -94,6 +95,7 @@ def read_trees(path: str):
     op = gzip.open if path.endswith(".gz") else open
     with op(path, "rt") as f:
         txt = f.read()
+    txt = re.sub(r"\[[^\]]*\]", "", txt)
     return [parse_newick(t + ";") for t in txt.replace("\n", "").split(";") if t.strip()]
 
 

@@ -33,10 +33,11 @@ DATASETS = {
     "10-leaves-autocorrelated-rate": ("data/test.treelist", "data/time.alpha.tree"),
     "12-leaves-variable-rate": ("data/test.treelist", "data/time.alpha.rotated.tree"),
     "24-leaves-braces": ("data/test.treelist", "data/time.relabelled.tree"),
+    "25-leaves-bastien": ("data/alignment.fasta.trees.only", "data/time.tree"),
 }
 N_SAMPLES = 48
 N_STATES = {"06-leaves-constant-rate": 16, "10-leaves-autocorrelated-rate": 16,
-            "12-leaves-variable-rate": 64, "24-leaves-braces": 128}
+            "12-leaves-variable-rate": 64, "24-leaves-braces": 128, "25-leaves-bastien": 32}
 
 
 def jittered_states(prep, n_states, seed):

@@ -25,7 +25,7 @@ def rel_err(a, b):
 # golden fixtures (reference test inputs -> restated prepare -> oracle)
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["06-leaves-constant-rate", "10-leaves-autocorrelated-rate",
-                                  "12-leaves-variable-rate", "24-leaves-braces"])
+                                  "12-leaves-variable-rate", "24-leaves-braces", "25-leaves-bastien"])
 def test_fixture_rawx_host_and_device(gpu, golden, name):
     import torch
 
@@ -46,7 +46,7 @@ def test_fixture_rawx_host_and_device(gpu, golden, name):
 
 
 @pytest.mark.parametrize("name", ["06-leaves-constant-rate", "10-leaves-autocorrelated-rate",
-                                  "12-leaves-variable-rate", "24-leaves-braces"])
+                                  "12-leaves-variable-rate", "24-leaves-braces", "25-leaves-bastien"])
 def test_fixture_tree_states(gpu, golden, name):
     fx = golden[name]
     topo = M.Topology(fx["parent"])

@@ -126,3 +126,29 @@ def test_synthetic_generators_are_deterministic():
     assert X.shape == (8, 64) and np.array_equal(X, S.sample_chains(mu1, s1, 8, 7))
     t = S.random_topology(129, 256)
     assert t.n_nodes == 257 and t.n_nodes - 2 == 255
+
+
+# ---------------------------------------------------------------------------------------------
+# Hamiltonian glue (app/Hamiltonian.hs:33-60)
+# ---------------------------------------------------------------------------------------------
+def test_hamiltonian_position_vector(golden):
+    fx = golden["24-leaves-braces"]
+    topo = M.Topology(fx["parent"])
+    mask = M.get_mask(True, topo)
+    # 2 + [tH] + (L-2) + 2 + (2L-2) = 73 for L = 24 with calibrations
+    assert int(mask.sum()) == 73 and int(M.get_mask(False, topo).sum()) == 72
+    x = M.State(0.7, 1.3, float(fx["tH"][4]), fx["H"][4], float(fx["rMu"][4]), 0.9, fx["R"][4])
+    v = M.to_vector(mask, x)
+    assert len(v) == 73
+    # reverse fold order: the last rate-tree branch comes first, timeBirthRate last
+    assert v[0] == fx["R"][4][-1] and v[-1] == 0.7 and v[-2] == 1.3 and v[-3] == float(fx["tH"][4])
+    y = M.from_vector_with(mask, x, v * 2.0)
+    assert y.time_birth_rate == 1.4 and y.rate_variance == 1.8 and y.time_tree[0] == x.time_tree[0]   # root height untouched
+    assert np.array_equal(y.rate_tree[1:], 2.0 * np.asarray(x.rate_tree)[1:]) and y.rate_tree[0] == x.rate_tree[0]
+    assert np.array_equal(np.asarray(y.time_tree)[topo.leaves], np.zeros(24))                        # leaves untouched
+    z = M.from_vector_with(mask, y, v)
+    assert np.array_equal(M.to_vector(mask, z), v)
+    g = M.grad_to_vector(mask, fx["gH"][4], fx["gR"][4], float(fx["gtH"][4]), float(fx["grMu"][4]))
+    assert len(g) == 73 and g[0] == fx["gR"][4][-1] and g[-1] == 0.0 and g[-3] == float(fx["gtH"][4])
+    with pytest.raises(ValueError):
+        M.to_vector(mask[:-1], x)
