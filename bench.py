@@ -105,18 +105,26 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box: MCD_BENCH_REHEARSAL=1 maps every rank to cuda:0 and uses gloo for the control
+    # collectives (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("MCD_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctl_dev = torch.device("cpu") if rehearsal else dev   # where the control tensors of the collectives live
 
     n, B = args.n, args.chains
     if args.kind in ("tree", "tree_grad"):
         topo = S.random_topology((n + 3) // 2, seed=n)
         n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=n)
-    lik = M.MvnLikelihood.from_covariance(mu, sigma, device=local_rank)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index)
     X_host = S.sample_chains(mu, sigma, B, seed=n + 1000 * rank)
     X = torch.as_tensor(X_host, device=dev)
     ll = torch.empty(B, dtype=torch.float64, device=dev)
@@ -149,7 +157,7 @@ def main():
                                                       torch.cuda.current_stream().cuda_stream, ll.data_ptr(), gH.data_ptr(),
                                                       gR.data_ptr(), gt.data_ptr(), gm.data_ptr()))
 
-    gathered = torch.empty(world * B, dtype=torch.float64, device=dev) if (world > 1 and args.swap_period > 0) else None
+    gathered = torch.empty(world * B, dtype=torch.float64, device=ctl_dev) if (world > 1 and args.swap_period > 0) else None
     use_graph = (not args.no_graph) and gathered is None
     K, W = args.steps, args.warmup
 
@@ -185,7 +193,10 @@ def main():
             for i in range(k):
                 step()
                 if gathered is not None and (i + 1) % args.swap_period == 0:
-                    dist.all_gather_into_tensor(gathered, ll)
+                    if rehearsal:
+                        dist.all_gather_into_tensor(gathered, ll.cpu())
+                    else:
+                        dist.all_gather_into_tensor(gathered, ll)
 
     def fence():
         torch.cuda.synchronize()
@@ -208,7 +219,7 @@ def main():
     elapsed = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
