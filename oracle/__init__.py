@@ -38,7 +38,9 @@ def lib(native: bool = False):
         return _LIBS[key]
     path = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
     src = os.path.join(_HERE, "mvn_oracle.c")
-    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+    src2 = os.path.join(_HERE, "prior_oracle.c")
+    newest = max(os.path.getmtime(p) for p in (src, src2) if os.path.exists(p))
+    if not os.path.exists(path) or newest > os.path.getmtime(path):
         build(native)
     L = C.CDLL(path)
     L.orc_logpdf_full.restype = C.c_double
@@ -81,6 +83,24 @@ def lib(native: bool = False):
     L.orc_grad_full_batch.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int64, C.c_int64, _dp, C.c_int64]
     L.orc_tree_loglik_full_batch.restype = C.c_int
     L.orc_tree_loglik_full_batch.argtypes = [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int64, _dp, _dp]
+    # prior_oracle.c
+    L.orp_ln_exponential.restype = C.c_double; L.orp_ln_exponential.argtypes = [C.c_double, C.c_double]
+    L.orp_ln_gamma.restype = C.c_double; L.orp_ln_gamma.argtypes = [C.c_double] * 3
+    L.orp_ln_normal.restype = C.c_double; L.orp_ln_normal.argtypes = [C.c_double] * 3
+    L.orp_calibrate_soft.restype = C.c_double
+    L.orp_calibrate_soft.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.orp_constrain_soft.restype = C.c_double; L.orp_constrain_soft.argtypes = [C.c_double] * 3
+    L.orp_brace_soft.restype = C.c_double; L.orp_brace_soft.argtypes = [C.c_double, C.c_int, _dp]
+    L.orp_compute_de.restype = None; L.orp_compute_de.argtypes = [C.c_double] * 5 + [_dp, _dp]
+    L.orp_compute_de_near_critical.restype = None; L.orp_compute_de_near_critical.argtypes = [C.c_double] * 5 + [_dp, _dp]
+    L.orp_birth_death.restype = C.c_double
+    L.orp_birth_death.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _ip, _dp]
+    L.orp_ln_lognormal_prime.restype = C.c_double; L.orp_ln_lognormal_prime.argtypes = [C.c_double] * 3
+    L.orp_relaxed_clock.restype = C.c_double
+    L.orp_relaxed_clock.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]
+    L.orp_prior.restype = C.c_double
+    L.orp_prior.argtypes = ([C.c_double, C.c_int, C.c_int, _ip, C.c_double, C.c_double, C.c_double, _dp, C.c_double, C.c_double, _dp]
+                            + [C.c_int, _ip, _ip, _dp, _dp, _ip, _dp, _dp] + [C.c_int, _ip, _ip, _dp] + [C.c_int, _ip, _ip, _dp] + [_dp])
     _LIBS[key] = L
     return L
 
@@ -207,3 +227,66 @@ def tree_grad_full(parent, heights, rates, tH, rMu, mu, sigma_inv):
     _check(lib().orc_tree_grad_full(len(parent), pp, ph, pr, float(tH), float(rMu), pmu, pP,
                                     gh.ctypes.data_as(_dp), gr.ctypes.data_as(_dp), C.byref(gt), C.byref(gm)))
     return gh, gr, gt.value, gm.value
+
+
+# ---- prior (prior_oracle.c) -------------------------------------------------------------------
+CLOCK_MODELS = {"UncorrelatedGamma": 0, "UncorrelatedLogNormal": 1, "UncorrelatedWhiteNoise": 2, "AutocorrelatedLogNormal": 3}
+
+
+def compute_de(la, mu, rho, dt, e0, near_critical=False):
+    d, e = C.c_double(), C.c_double()
+    f = lib().orp_compute_de_near_critical if near_critical else lib().orp_compute_de
+    f(la, mu, rho, dt, e0, C.byref(d), C.byref(e))
+    return d.value, e.value
+
+
+def birth_death(cond_mrca, la, mu, rho, parent, lengths) -> float:
+    """ln birthDeath; cond_mrca False = ConditionOnTimeOfOrigin (old API: WithStem), True = ...OfMrca (WithoutStem)."""
+    parent, pp = _i(parent); ln, pl = _d(lengths)
+    return float(lib().orp_birth_death(int(bool(cond_mrca)), la, mu, rho, len(parent), pp, pl))
+
+
+def relaxed_clock(model, m, v, tlen, rates) -> float:
+    t, pt = _d(tlen); r, pr = _d(rates)
+    return float(lib().orp_relaxed_clock(CLOCK_MODELS[model] if isinstance(model, str) else int(model), m, v, len(t), pt, pr))
+
+
+class PriorSpec:
+    """Everything `priorFunction ht md cb cs bs` closes over (app/Probability.hs:127-150), on pre-order node ids.
+    calibrations: (node, lo or None, lo_p, hi or None, hi_p); constraints: (young, old, p); braces: (nodes, sd)."""
+
+    def __init__(self, parent, ht, model, calibrations=(), constraints=(), braces=()):
+        self.parent = np.ascontiguousarray(parent, np.int32)
+        self.ht = float(ht)
+        self.model = CLOCK_MODELS[model] if isinstance(model, str) else int(model)
+        c = list(calibrations)
+        self.cal_node = np.array([x[0] for x in c], np.int32)
+        self.cal_has_lo = np.array([x[1] is not None for x in c], np.int32)
+        self.cal_lo = np.array([x[1] if x[1] is not None else 0.0 for x in c], np.float64)
+        self.cal_lo_p = np.array([x[2] if x[1] is not None else 0.0 for x in c], np.float64)
+        self.cal_has_hi = np.array([x[3] is not None for x in c], np.int32)
+        self.cal_hi = np.array([x[3] if x[3] is not None else 0.0 for x in c], np.float64)
+        self.cal_hi_p = np.array([x[4] if x[3] is not None else 0.0 for x in c], np.float64)
+        k = list(constraints)
+        self.con_young = np.array([x[0] for x in k], np.int32)
+        self.con_old = np.array([x[1] for x in k], np.int32)
+        self.con_p = np.array([x[2] for x in k], np.float64)
+        b = list(braces)
+        self.br_ptr = np.concatenate([[0], np.cumsum([len(x[0]) for x in b])]).astype(np.int32)
+        self.br_nodes = np.array([n for x in b for n in x[0]], np.int32)
+        self.br_sd = np.array([x[1] for x in b], np.float64)
+
+
+def prior(spec: PriorSpec, birth, death, tH, heights, rMu, rVar, rates):
+    """(ln prior, [node priors, birth-death block, relaxed-clock block]) for one state."""
+    h, ph = _d(heights); r, pr = _d(rates)
+    comp = np.empty(3)
+    ip = lambda a: a.ctypes.data_as(_ip)
+    dp = lambda a: a.ctypes.data_as(_dp)
+    v = lib().orp_prior(spec.ht, spec.model, len(spec.parent), ip(spec.parent), float(birth), float(death), float(tH), ph,
+                        float(rMu), float(rVar), pr,
+                        len(spec.cal_node), ip(spec.cal_node), ip(spec.cal_has_lo), dp(spec.cal_lo), dp(spec.cal_lo_p),
+                        ip(spec.cal_has_hi), dp(spec.cal_hi), dp(spec.cal_hi_p),
+                        len(spec.con_young), ip(spec.con_young), ip(spec.con_old), dp(spec.con_p),
+                        len(spec.br_sd), ip(spec.br_ptr), ip(spec.br_nodes), dp(spec.br_sd), dp(comp))
+    return float(v), comp
