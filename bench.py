@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
     ap.add_argument("--graph-chunk", type=int, default=100, help="steps captured per hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad"])
+    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior"])
     args = ap.parse_args()
 
     import torch
@@ -120,7 +120,7 @@ def main():
     ctl_dev = torch.device("cpu") if rehearsal else dev   # where the control tensors of the collectives live
 
     n, B = args.n, args.chains
-    if args.kind in ("tree", "tree_grad"):
+    if args.kind in ("tree", "tree_grad", "prior", "posterior"):
         topo = S.random_topology((n + 3) // 2, seed=n)
         n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=n)
@@ -145,7 +145,33 @@ def main():
         lj = torch.empty(B, dtype=torch.float64, device=dev)
         gH, gR = torch.empty_like(st.heights), torch.empty_like(st.rates)
         gt, gm = torch.empty_like(st.time_height), torch.empty_like(st.rate_mean)
-        if args.kind == "tree":
+        if args.kind in ("prior", "posterior"):
+            rng = np.random.default_rng(n)
+            st.time_birth_rate = torch.as_tensor(np.exp(0.3 * rng.standard_normal(B)), device=dev)
+            st.time_death_rate = torch.as_tensor(np.exp(0.3 * rng.standard_normal(B)), device=dev)
+            st.rate_variance = torch.as_tensor(0.2 + rng.random(B), device=dev)
+            pf = M.PriorFunction(1.0, "UncorrelatedLogNormal", [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025)],
+                                 [M.Constraint("k", 7, 3, 0.025)], [], topo, device=dev_index)
+            lp = torch.empty(B, dtype=torch.float64, device=dev)
+
+            def prior_step():
+                M._capi.check(lib.mcd_prior_logprior_batch(pf._p, st.time_birth_rate.data_ptr(), st.time_death_rate.data_ptr(),
+                                                           st.time_height.data_ptr(), st.heights.data_ptr(), st.rate_mean.data_ptr(),
+                                                           st.rate_variance.data_ptr(), st.rates.data_ptr(), st.heights.stride(0), B, 1,
+                                                           torch.cuda.current_stream().cuda_stream, lp.data_ptr(), None))
+
+            def lik_step():
+                M._capi.check(lib.mcd_tree_loglik_batch(tl._t, st.heights.data_ptr(), st.rates.data_ptr(), st.heights.stride(0),
+                                                        st.time_height.data_ptr(), st.rate_mean.data_ptr(), B, 1,
+                                                        torch.cuda.current_stream().cuda_stream, ll.data_ptr(), lj.data_ptr()))
+
+            if args.kind == "prior":
+                step = prior_step
+            else:
+                def step():
+                    prior_step()
+                    lik_step()
+        elif args.kind == "tree":
             def step():
                 M._capi.check(lib.mcd_tree_loglik_batch(tl._t, st.heights.data_ptr(), st.rates.data_ptr(), st.heights.stride(0),
                                                         st.time_height.data_ptr(), st.rate_mean.data_ptr(), B, 1,

@@ -130,6 +130,42 @@ int mcd_tree_grad_batch(const mcd_tree_t* t, const double* heights, const double
                         const double* tH, const double* rMu, int64_t batch, int on_device, void* stream,
                         double* ll, double* g_heights, double* g_rates, double* g_tH, double* g_rMu);
 
+/* ------------------------------------------------------------------------------------------------
+ * Prior (built after the likelihood rows): the batched log prior of the state.
+ * Replaces  priorFunction ht md cb cs bs :: PriorFunction I  (app/Probability.hs:127-150), i.e.
+ *   calibrateConstrainBraceSoft (lib/Mcmc/Tree/Prior/Node/Combined.hs:70-92)
+ *   * exponential 1 birth * exponential 1 death * birthDeath ConditionOnTimeOfMrca birth death 1 t'
+ *                                                                  (lib/Mcmc/Tree/Prior/BirthDeath.hs:158-239)
+ *   * exponential ht rMu * gamma (3/2) (1/6) rVar * relaxed clock model 1 rVar t' rateTree
+ *                                                                  (lib/Mcmc/Tree/Prior/Branch/RelaxedClock.hs)
+ * Node indices are pre-order ids (the reference's `identify`, Calibration.hs:173).  Calibration boundaries are
+ * absolute ages; cal_has_lo/hi = 0 encodes `Zero` / `Infinity`.  Braces: CSR (brace_ptr[n_brace+1], brace_nodes).
+ * State-dependent faults for which the reference calls `error` (variance <= 0, negative birth/death rate)
+ * come back as NaN for that chain; probability 0 is -Inf.
+ * ---------------------------------------------------------------------------------------------- */
+#define MCD_CLOCK_UNCORRELATED_GAMMA 0
+#define MCD_CLOCK_UNCORRELATED_LOGNORMAL 1
+#define MCD_CLOCK_UNCORRELATED_WHITE_NOISE 2
+#define MCD_CLOCK_AUTOCORRELATED_LOGNORMAL 3
+
+typedef struct mcd_prior mcd_prior_t;
+
+int mcd_prior_create(mcd_prior_t** out, int n_nodes, const int32_t* parent, double ht, int clock_model,
+                     int n_cal, const int32_t* cal_node, const int32_t* cal_has_lo, const double* cal_lo,
+                     const double* cal_lo_p, const int32_t* cal_has_hi, const double* cal_hi, const double* cal_hi_p,
+                     int n_con, const int32_t* con_young, const int32_t* con_old, const double* con_p,
+                     int n_brace, const int32_t* brace_ptr, const int32_t* brace_nodes, const double* brace_sd,
+                     int device_id);
+void mcd_prior_destroy(mcd_prior_t* p);
+
+/* Per chain b: birth[b], death[b], tH[b], heights[b*ld_state + v], rMu[b], rVar[b], rates[b*ld_state + v]
+ * (the seven fields of `I`, app/State.hs:70-89).  lp[b] = log prior; components (may be NULL): [b][3] =
+ * node priors, birth-death block, relaxed-clock block (what app/Monitor.hs:27-57 monitors). */
+int mcd_prior_logprior_batch(const mcd_prior_t* p, const double* birth, const double* death, const double* tH,
+                             const double* heights, const double* rMu, const double* rVar, const double* rates,
+                             int64_t ld_state, int64_t batch, int on_device, void* stream, double* lp,
+                             double* components);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,8 @@ from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating
 from .likelihood import (Full, LikelihoodData, MvnLikelihood, NoData, Sparse, TreeLikelihood, Univariate,
                          jacobian_root_branch, likelihood_function, read_data_file, write_data_file)
 from .hamiltonian import from_vector_with, get_mask, grad_to_vector, to_vector
+from .prior import (Brace, Calibration, Constraint, PriorFunction, get_mean_root_height, load_braces,
+                    load_calibrations, load_constraints, prior_function)
 from .state import State, StateBatch
 from .tree import (Topology, TreeError, branch_slots, get_branches, height_tree_to_length_tree, parse_newick,
                    read_newick_file, sum_first_two)
@@ -18,6 +20,8 @@ __all__ = [
     "likelihood_function", "jacobian_root_branch", "read_data_file", "write_data_file",
     "State", "StateBatch", "Topology", "TreeError", "parse_newick", "read_newick_file", "get_branches",
     "sum_first_two", "branch_slots", "height_tree_to_length_tree",
+    "Calibration", "Constraint", "Brace", "PriorFunction", "prior_function", "load_calibrations", "load_constraints",
+    "load_braces", "get_mean_root_height",
     "get_mask", "to_vector", "from_vector_with", "grad_to_vector",
     "McdError", "NotPositiveDefinite", "RootNotBifurcating", "NoDevice",
 ]

@@ -45,6 +45,12 @@ SYMBOLS = {
     "mcd_tree_n_nodes": (C.c_int, [_vp]),
     "mcd_tree_loglik_batch": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "mcd_tree_grad_batch": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcd_prior_create": (C.c_int, [C.POINTER(_vp), C.c_int, _ip, C.c_double, C.c_int,
+                                   C.c_int, _ip, _ip, _dp, _dp, _ip, _dp, _dp,
+                                   C.c_int, _ip, _ip, _dp,
+                                   C.c_int, _ip, _ip, _dp, C.c_int]),
+    "mcd_prior_destroy": (None, [_vp]),
+    "mcd_prior_logprior_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp]),
 }
 
 

@@ -142,6 +142,13 @@ struct mcd_tree {
     }
 };
 
+// shared with prior_capi.cpp: set this thread's error message, return the code
+extern "C" int mcd_set_last_error_(int code, const char* msg)
+{
+    g_last_error = msg ? msg : "";
+    return code;
+}
+
 extern "C" {
 
 const char* mcd_version(void) { return "mcmc-date_amd 0.1 (gfx950, column-sweep TRSV)"; }

@@ -30,6 +30,25 @@ struct TreeDev {
     const int32_t* child_idx; // [n_nodes - 1]
 };
 
+// Everything `priorFunction ht md cb cs bs` closes over (app/Probability.hs:127-150), on pre-order node ids.
+struct PriorDev {
+    int n_nodes;
+    int clock_model;          // 0 UncorrelatedGamma, 1 UncorrelatedLogNormal, 2 UncorrelatedWhiteNoise, 3 AutocorrelatedLogNormal
+    double ht;                // initial, constant, approximate absolute time tree height
+    const int32_t* parent;    // [n_nodes]
+    const int32_t* first_child;   // [n_nodes], -1 for tips
+    const int32_t* n_children;    // [n_nodes]
+    int n_cal;
+    const int32_t *cal_node, *cal_has_lo, *cal_has_hi;
+    const double *cal_lo, *cal_lo_p, *cal_hi, *cal_hi_p;
+    int n_con;
+    const int32_t *con_young, *con_old;
+    const double* con_p;
+    int n_brace;
+    const int32_t *brace_ptr, *brace_nodes;
+    const double* brace_sd;
+};
+
 int padded_blocks(int n);          // supported R for dimension n, or -1
 int sweep_chunk_columns(int R);    // columns per register buffer (ncols granularity)
 
@@ -42,5 +61,9 @@ hipError_t launch_tree_logpdf(const MvnDev& M, const TreeDev& T, const double* H
 hipError_t launch_tree_grad(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
                             const double* tH, const double* rMu, int64_t batch, double* ll, double* gH, double* gR,
                             double* gtH, double* grMu, hipStream_t st);
+
+hipError_t launch_prior(const PriorDev& P, const double* birth, const double* death, const double* tH, const double* H,
+                        const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
+                        double* comp, hipStream_t st);
 
 }  // namespace mcd

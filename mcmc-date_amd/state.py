@@ -42,6 +42,10 @@ class StateBatch:
     rates: "np.ndarray"          # [B, n_nodes]
     time_height: "np.ndarray"    # [B]
     rate_mean: "np.ndarray"      # [B]
+    # the three fields only the prior reads (None when only the likelihood is evaluated)
+    time_birth_rate: "np.ndarray" = None   # [B]
+    time_death_rate: "np.ndarray" = None   # [B]
+    rate_variance: "np.ndarray" = None     # [B]
 
     @classmethod
     def from_states(cls, xs: Iterable[State]) -> "StateBatch":
@@ -51,6 +55,9 @@ class StateBatch:
             np.stack([np.asarray(x.rate_tree, np.float64) for x in xs]),
             np.asarray([x.time_height for x in xs], np.float64),
             np.asarray([x.rate_mean for x in xs], np.float64),
+            np.asarray([x.time_birth_rate for x in xs], np.float64),
+            np.asarray([x.time_death_rate for x in xs], np.float64),
+            np.asarray([x.rate_variance for x in xs], np.float64),
         )
 
     def __len__(self):
@@ -61,7 +68,11 @@ class StateBatch:
         import torch
 
         f = lambda a: torch.as_tensor(np.asarray(a) if not hasattr(a, "device") else a, dtype=torch.float64).to(device).contiguous()
-        return StateBatch(f(self.heights), f(self.rates), f(self.time_height), f(self.rate_mean))
+        o = lambda a: None if a is None else f(a)
+        return StateBatch(f(self.heights), f(self.rates), f(self.time_height), f(self.rate_mean), o(self.time_birth_rate),
+                          o(self.time_death_rate), o(self.rate_variance))
 
     def slice(self, lo: int, hi: int) -> "StateBatch":
-        return StateBatch(self.heights[lo:hi], self.rates[lo:hi], self.time_height[lo:hi], self.rate_mean[lo:hi])
+        o = lambda a: None if a is None else a[lo:hi]
+        return StateBatch(self.heights[lo:hi], self.rates[lo:hi], self.time_height[lo:hi], self.rate_mean[lo:hi],
+                          o(self.time_birth_rate), o(self.time_death_rate), o(self.rate_variance))

@@ -82,3 +82,21 @@ def test_prepare_other_specs(tmp_path):
     assert isinstance(PP.prepare(a, b, "NoLikelihood").lhd, M.NoData)
     with pytest.raises(NotImplementedError):
         PP.prepare(a, b, "SparseMultivariateNormal 0.1")
+
+
+def test_node_prior_loaders_match_fixtures(golden):
+    """calibrations.csv / constraints.csv / braces.json of the reference's test directories -> pre-order node ids."""
+    for name in ("12-leaves-variable-rate", "24-leaves-braces"):
+        fx = golden[name]
+        topo = M.Topology(fx["parent"], list(fx["names"]))
+        d = os.path.join(REF, name, "data")
+        cals = M.load_calibrations(topo, os.path.join(d, "calibrations.csv"))
+        assert [c.node for c in cals] == [int(r[0]) for r in fx["cal"]]
+        assert [c.lower for c in cals] == [r[2] for r in fx["cal"]] and [c.upper for c in cals] == [r[5] for r in fx["cal"]]
+        cons = M.load_constraints(topo, os.path.join(d, "constraints.csv"))
+        assert [(k.young, k.old, k.p) for k in cons] == [(int(r[0]), int(r[1]), r[2]) for r in fx["con"]]
+        assert M.get_mean_root_height(cals) == float(fx["prior_ht"])
+    br = M.load_braces(topo, os.path.join(d, "braces.json"))
+    assert [b.nodes for b in br] == [[int(n) for n in fx["brace_nodes"]]] and br[0].sd == 1e-4
+    assert cals[0].name == "CladeRoot" and cals[0].node == 0
+    assert M.get_mean_root_height(cals[1:]) is None
