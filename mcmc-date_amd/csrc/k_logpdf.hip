@@ -21,18 +21,7 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_logpdf(MvnDev M, const doubl
         fwd_loader_start<R, LW>(M.Ft, st, lw, lane);
         fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
         MCD_T(3);
-#ifdef MCD_EXP_TWICE   // timing experiment: a second, identical sweep in the same launch (warm caches)
-        lds_barrier();
-        fwd_loader_prologue<R, LW>(M.Ft, ring, st, lw, lane);
-        lds_barrier();
-        fwd_loader_start<R, LW>(M.Ft, st, lw, lane);
-        MCD_T(5);
-        fwd_loader<R, LW, 0>(M.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
-        MCD_T(6);
-#endif
-#ifndef MCD_EXP_TWICE
         MCD_ACC_FLUSH(5);
-#endif
         return;
     }
     double d[R][BT];
@@ -42,18 +31,9 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_logpdf(MvnDev M, const doubl
     MCD_T(2);
     fwd_compute<R, BT, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
     MCD_T(3);
-#ifdef MCD_EXP_TWICE
-    lds_barrier();
-    lds_barrier();
-    MCD_T(5);
-    fwd_compute<R, BT, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
-    MCD_T(6);
-#endif
     finish_ll<R, BT>(d, M, b0, batch, ll, lane);
     MCD_T(4);
-#ifndef MCD_EXP_TWICE
     MCD_ACC_FLUSH(5);
-#endif
 }
 
 template <int R, int BT, int CW, int LW>
@@ -68,27 +48,6 @@ template <int R>
 static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
 {
     Geometry g = pick_geometry(batch);
-#ifdef MCD_GEOM_EXPERIMENT   // tuning builds only: MCD_GEOM="cw,lw,bt" selects a geometry (R = 4 only)
-    if constexpr (R == 4 || R == 16) {
-        if (const char* e = getenv("MCD_GEOM")) {
-            int cw = 0, lw = 0, bt = 0;
-            sscanf(e, "%d,%d,%d", &cw, &lw, &bt);
-            if (cw == 8 && lw == 4 && bt == 1) { launch_geom<R, 1, 8, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 8 && lw == 4 && bt == 2) { launch_geom<R, 2, 8, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 4 && lw == 4 && bt == 1) { launch_geom<R, 1, 4, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 4 && lw == 4 && bt == 2) { launch_geom<R, 2, 4, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 6 && lw == 2 && bt == 1) { launch_geom<R, 1, 6, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 6 && lw == 2 && bt == 2) { launch_geom<R, 2, 6, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 4 && lw == 2 && bt == 1) { launch_geom<R, 1, 4, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 2 && lw == 2 && bt == 2) { launch_geom<R, 2, 2, 2>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 3 && lw == 1 && bt == 1) { launch_geom<R, 1, 3, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 2 && lw == 1 && bt == 1) { launch_geom<R, 1, 2, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 1 && lw == 1 && bt == 1) { launch_geom<R, 1, 1, 1>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 2 && lw == 4 && bt == 1) { launch_geom<R, 1, 2, 4>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-            if (cw == 2 && lw == 3 && bt == 1) { launch_geom<R, 1, 2, 3>(M, X, ldx, batch, ll, st); return hipGetLastError(); }
-        }
-    }
-#endif
     if (g.cw == 2)
         launch_geom<R, 1, 2, 2>(M, X, ldx, batch, ll, st);
     else if (g.bt == 1)

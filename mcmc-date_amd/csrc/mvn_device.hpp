@@ -177,15 +177,11 @@ __device__ __forceinline__ void stage_store(const Stage<R, LW>& st, d2* slot, in
 #pragma unroll
     for (int i = 0; i < (NU + LW - 1) / LW; ++i) {
         const int u = i * LW + lw;
-#ifdef MCD_EXP_NOSTORE   // timing experiment only: keep the loads alive, skip the LDS write
-        asm volatile("" ::"v"(st.v[SET][i]));
-#else
         if constexpr (NU % LW != 0) {
             if (u < NU) slot[u * 64 + lane] = st.v[SET][i];
         } else {
             slot[u * 64 + lane] = st.v[SET][i];
         }
-#endif
     }
 }
 
@@ -209,11 +205,7 @@ __device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const d2* slot, in
 #pragma unroll
     for (int p = 0; p < LDS_PD && p < CP; ++p)
 #pragma unroll
-#ifdef MCD_EXP_NOREAD
-        for (int k = 0; k < NK; ++k) l[p % NBUF][k] = d2{1e-9 * lane, 2e-9 * lane};
-#else
         for (int k = 0; k < NK; ++k) l[p % NBUF][k] = slot[(p * NK + k) * 64 + lane];
-#endif
     double z[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) z[b] = readlane64(d[JB][b], jj0);
@@ -221,11 +213,7 @@ __device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const d2* slot, in
     for (int p = 0; p < CP; ++p) {
         if (p + LDS_PD < CP) {
 #pragma unroll
-#ifdef MCD_EXP_NOREAD
-            for (int k = 0; k < NK; ++k) l[(p + LDS_PD) % NBUF][k] = d2{1e-9 * lane, 2e-9 * lane};
-#else
             for (int k = 0; k < NK; ++k) l[(p + LDS_PD) % NBUF][k] = slot[((p + LDS_PD) * NK + k) * 64 + lane];
-#endif
         }
         MCD_SB;
 #pragma unroll
