@@ -50,7 +50,7 @@ static hipError_t launch_grad_R(const MvnDev& M, const double* X, int64_t ldx, i
                                 int64_t ldg, hipStream_t st)
 {
     auto go = [&](auto cw_tag) {
-        constexpr int CW = decltype(cw_tag)::value, LW = 2;
+        constexpr int CW = decltype(cw_tag)::value, LW = Cfg<R>::LW;
         const unsigned grid = (unsigned)((batch + CW - 1) / CW);
         hipLaunchKernelGGL((k_grad<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, X, ldx, batch, ll, G, ldg);
     };

@@ -49,11 +49,11 @@ static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx,
 {
     Geometry g = pick_geometry(batch);
     if (g.cw == 2)
-        launch_geom<R, 1, 2, 2>(M, X, ldx, batch, ll, st);
+        launch_geom<R, 1, 2, Cfg<R>::LW>(M, X, ldx, batch, ll, st);
     else if (g.bt == 1)
-        launch_geom<R, 1, 4, 2>(M, X, ldx, batch, ll, st);
+        launch_geom<R, 1, 4, Cfg<R>::LW>(M, X, ldx, batch, ll, st);
     else
-        launch_geom<R, 2, 4, 2>(M, X, ldx, batch, ll, st);
+        launch_geom<R, 2, 4, Cfg<R>::LW>(M, X, ldx, batch, ll, st);
     return hipGetLastError();
 }
 
@@ -83,7 +83,7 @@ int sweep_chunk_columns(int R)
 {
     // columns per chunk (Cfg<R>::CCOLS): the swept column count is rounded up to it (extra columns
     // are zero padding).
-    return 2 * ((R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : (R <= 8) ? 4 : 2);
+    return 2 * ((R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : 4);
 }
 
 int padded_blocks(int n)

@@ -90,7 +90,7 @@ static hipError_t launch_tree_grad_R(const MvnDev& M, const TreeDev& T, const do
                                      double* gR, double* gtH, double* grMu, hipStream_t st)
 {
     auto go = [&](auto cw_tag) {
-        constexpr int CW = decltype(cw_tag)::value, LW = 2;
+        constexpr int CW = decltype(cw_tag)::value, LW = Cfg<R>::LW;
         const unsigned grid = (unsigned)((batch + CW - 1) / CW);
         hipLaunchKernelGGL((k_tree_grad<R, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch,
                        ll, gH, gR, gtH, grMu);

@@ -42,11 +42,6 @@ namespace mcd {
 // memcpy, which pins register arrays to scratch)
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#ifndef MCD_SLOT_UNITS
-#define MCD_SLOT_UNITS 32
-#endif
-constexpr int SLOT_UNITS = MCD_SLOT_UNITS;       // 1-KiB units per LDS ring slot
-constexpr int RING_BYTES = 2 * SLOT_UNITS * 1024;
 
 // ---------------------------------------------------------------------------------------
 // cross-lane helpers (wave64)
@@ -135,9 +130,14 @@ __device__ __forceinline__ void mcd_acc(int idx, unsigned long long& tprev, unsi
 // ---------------------------------------------------------------------------------------
 template <int R>
 struct Cfg {
-    // column pairs per chunk: CP * R <= SLOT_UNITS
-    static constexpr int CP0 = (R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : (R <= 8) ? 4 : 2;
-    static constexpr int CP = (CP0 * (SLOT_UNITS / 32) > 32) ? 32 : CP0 * (SLOT_UNITS / 32);
+    // 1-KiB units per LDS ring slot (two slots): 32 KiB slots up to N = 512; above that a chunk of 32 units is
+    // only 4 columns and the per-chunk barrier + loader bookkeeping dominate (measured at N = 1024: the compute
+    // waves spent half of the sweep waiting at barriers), so 64-unit slots (128 KiB of LDS, one workgroup per CU).
+    static constexpr int SU = (R >= 12) ? 64 : 32;
+    // loader waves per workgroup
+    static constexpr int LW = (R >= 12) ? 4 : 2;
+    // column pairs per chunk: CP * R <= SU
+    static constexpr int CP = (R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : (R <= 8) ? 4 : (SU / 16);
     static constexpr int CPB = 32 / CP;                     // chunks per 64-column block
     static constexpr int NCHUNK = R * CPB;
     static constexpr int CCOLS = 2 * CP;                    // columns per chunk
@@ -262,7 +262,7 @@ __device__ __forceinline__ bool fwd_compute_chunks(double (&d)[R][BT], const d2*
         constexpr int CI = JB * C::CPB + LC;
         if (CI * C::CCOLS >= ncols) return false;        // workgroup-uniform
         MCD_ACC(-1);
-        fwd_apply<R, BT, JB, LC * C::CCOLS>(d, ring + (CI & 1) * SLOT_UNITS * 64, lane);
+        fwd_apply<R, BT, JB, LC * C::CCOLS>(d, ring + (CI & 1) * C::SU * 64, lane);
         MCD_ACC(0);
         lds_barrier();
         MCD_ACC(1);
@@ -294,7 +294,7 @@ __device__ __forceinline__ bool fwd_loader_chunk(const double* __restrict__ Ft, 
     const int ci = JB * C::CPB + lc;
     if (ci * C::CCOLS >= ncols) return false;
     MCD_ACC(-1);
-    if constexpr (JB1 < R) stage_store<R, LW, JB1, R, SLOT ^ 1>(st, ring + (SLOT ^ 1) * SLOT_UNITS * 64, lw, lane);
+    if constexpr (JB1 < R) stage_store<R, LW, JB1, R, SLOT ^ 1>(st, ring + (SLOT ^ 1) * C::SU * 64, lw, lane);
     MCD_ACC(0);
     if constexpr (JB3 < R) stage_load<R, LW, JB3, R, SLOT ^ 1>(st, Ft, (ci + 3) * C::CP, lw, lane);
     MCD_ACC(2);
@@ -433,7 +433,7 @@ __device__ __forceinline__ void bwd_compute_chunks(double (&d)[R][BT], const d2*
                 lds_barrier();                             // top chunk published by the loaders
                 started = true;
             }
-            bwd_apply<R, BT, IB, LC * C::CCOLS>(d, ring + (CI & 1) * SLOT_UNITS * 64, lane);
+            bwd_apply<R, BT, IB, LC * C::CCOLS>(d, ring + (CI & 1) * C::SU * 64, lane);
             lds_barrier();
         }
         bwd_compute_chunks<R, BT, IB, LC - 1>(d, ring, lane, ncols, started);
@@ -461,12 +461,12 @@ __device__ __forceinline__ void bwd_loader_chunk(const double* __restrict__ Ut, 
     if (!started) {                                        // top chunk: fill the pipeline
         stage_load<R, LW, 0, IB + 1, SLOT>(st, Ut, ci * C::CP, lw, lane);
         if constexpr (IB1 >= 0) stage_load<R, LW, 0, IB1 + 1, SLOT ^ 1>(st, Ut, (ci - 1) * C::CP, lw, lane);
-        stage_store<R, LW, 0, IB + 1, SLOT>(st, ring + SLOT * SLOT_UNITS * 64, lw, lane);
+        stage_store<R, LW, 0, IB + 1, SLOT>(st, ring + SLOT * C::SU * 64, lw, lane);
         if constexpr (IB2 >= 0) stage_load<R, LW, 0, IB2 + 1, SLOT>(st, Ut, (ci - 2) * C::CP, lw, lane);
         lds_barrier();
         started = true;
     }
-    if constexpr (IB1 >= 0) stage_store<R, LW, 0, IB1 + 1, SLOT ^ 1>(st, ring + (SLOT ^ 1) * SLOT_UNITS * 64, lw, lane);
+    if constexpr (IB1 >= 0) stage_store<R, LW, 0, IB1 + 1, SLOT ^ 1>(st, ring + (SLOT ^ 1) * C::SU * 64, lw, lane);
     if constexpr (IB3 >= 0) stage_load<R, LW, 0, IB3 + 1, SLOT ^ 1>(st, Ut, (ci - 3) * C::CP, lw, lane);
     lds_barrier();
 }
@@ -581,7 +581,7 @@ __device__ __forceinline__ void finish_ll(const double (&d)[R][BT], const MvnDev
 // (they work on clamped inputs and store nothing): no early exits before the last barrier.
 // ---------------------------------------------------------------------------------------
 #define MCD_KERNEL_HEAD                                                         \
-    __shared__ d2 ring[RING_BYTES / sizeof(d2)];                                \
+    __shared__ d2 ring[2 * Cfg<R>::SU * 64];                                    \
     const int lane = threadIdx.x & 63;                                          \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          \
     const int64_t b0 = ((int64_t)blockIdx.x * CW + wave) * BT;                   \
