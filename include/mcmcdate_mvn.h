@@ -166,6 +166,65 @@ int mcd_prior_logprior_batch(const mcd_prior_t* p, const double* birth, const do
                              int64_t ld_state, int64_t batch, int on_device, void* stream, double* lp,
                              double* components);
 
+/* ------------------------------------------------------------------------------------------------
+ * Batched Metropolis-Hastings-Green driver (FIRST SLICE).  `mcmc`'s `mhg` evaluates one state
+ * per call (app/Main.hs:474); here `batch` independent chains execute the same proposal of the cycle at the same
+ * time, each with its own random numbers, tuning parameter and accept/reject decision.  The state never leaves
+ * the device between calls.  A proposal is a row of the table below; the caller builds the table and the
+ * per-iteration order (the reference: app/Definitions.hs:127-278 `proposals`, weights replicated and shuffled by
+ * `mcmc`).  Kinds built so far (the contrary and braced proposals of lib/Mcmc/Tree/Proposal/{Contrary,Brace}.hs
+ * and NUTS are not: DESIGN.md section 9):
+ * ---------------------------------------------------------------------------------------------- */
+#define MCD_PROP_SCALE_SCALAR 0        /* scaleUnbiased k [mcmc]: node = 0 birth, 1 death, 2 tH, 3 rMu, 4 rVar; p0 = k          */
+#define MCD_PROP_SLIDE_NODE 1          /* slideNodeAtUltrametric (Ultrametric.hs:50-59): node; p0 = sd                          */
+#define MCD_PROP_SCALE_SUBTREE_TIME 2  /* scaleSubTreeAtUltrametric (:126-149): node; p0 = sd; n1 = inner nodes of the sub tree  */
+#define MCD_PROP_PULLEY 3              /* pulleyUltrametric (:221-286): p0 = sd; n1, n2 = inner nodes left / right               */
+#define MCD_PROP_SCALE_BRANCH_RATE 4   /* scaleBranch (Unconstrained.hs:40-66): node; p0 = shape                                 */
+#define MCD_PROP_SCALE_SUBTREE_RATE 5  /* scaleTree on a sub tree (:84-130): node; p0 = shape; n1 = nodes of the sub tree        */
+#define MCD_PROP_SCALE_NORM_TREE 6     /* scaleNormAndTreeContrarily (:221-256): node = 2 (tH) or 3 (rMu); p0 = shape            */
+#define MCD_PROP_SCALE_VAR_TREE 7      /* scaleVarianceAndTree (:286-316): p0 = shape                                            */
+#define MCD_PROP_SCALE_VAR_TREE_AUTO 8 /* scaleVarianceAndTreeAutocorrelated (:354-386): p0 = shape                              */
+#define MCD_PROP_SCALE_CONTRARILY 9    /* scaleContrarily k th [mcmc] on (tH, rMu): p0 = k, p1 = th                              */
+
+typedef struct mcd_mh mcd_mh_t;
+
+/*
+ * tree, prior: handles on the same device; they must outlive the driver.  Proposal table, n_prop rows: kind, node,
+ * n1, n2 (see above), jac_root = 1 for proposals lifted with jacobianRootBranch (the "[R]" proposals of
+ * app/Definitions.hs:145-278), dim = PDimension (selects the optimal acceptance rate of the auto tuner), p0, p1.
+ * All chains start with tuning parameter 1.  Random numbers are Philox4x32-10 keyed by `seed`, counter =
+ * (draw, chain, step): results do not depend on batch size, launch geometry or GPU count.
+ */
+int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
+                  const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
+                  const double* p0, const double* p1, int64_t batch, uint64_t seed);
+void mcd_mh_destroy(mcd_mh_t* m);
+/* first_chain: global index of this handle's chain 0 (chain shards on several GPUs draw disjoint random streams). */
+int mcd_mh_set_chain_offset(mcd_mh_t* m, int64_t first_chain);
+/* Host arrays, the seven fields of `I` per chain (as mcd_prior_logprior_batch); evaluates the posterior. */
+int mcd_mh_set_state(mcd_mh_t* m, const double* birth, const double* death, const double* tH, const double* heights,
+                     const double* rMu, const double* rVar, const double* rates, int64_t ld_state);
+int mcd_mh_get_state(const mcd_mh_t* m, double* birth, double* death, double* tH, double* heights, double* rMu,
+                     double* rVar, double* rates, int64_t ld_state);
+/* post: [batch][3] = ln prior, ln likelihood, ln jacobianRootBranch of the current states. */
+int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
+/*
+ * n_iter iterations of steps_per_iter proposals; schedule[n_iter * steps_per_iter] = proposal row per step (host).
+ * accumulate != 0: after every iteration add the absolute node ages tH * h_v to the running sums.
+ * trace_alpha / trace_accept (host, may be NULL): [n_iter * steps_per_iter][batch] ln acceptance ratio / decision.
+ */
+int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t steps_per_iter, int accumulate,
+               double* trace_alpha, int8_t* trace_accept);
+/* Auto tuning at the end of a tuning period [mcmc]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3). */
+int mcd_mh_tune(mcd_mh_t* m);
+/* tune: [batch][n_prop]; accepted / tried: counters since the last mcd_mh_tune / mcd_mh_reset_counters. */
+int mcd_mh_get_tuning(const mcd_mh_t* m, double* tune, int32_t* accepted, int32_t* tried);
+int mcd_mh_set_tuning(mcd_mh_t* m, const double* tune);
+int mcd_mh_reset_counters(mcd_mh_t* m);
+/* age_sum / age_sq: [batch][n_nodes] running sums over *n_samples accumulated iterations; reset with the call below. */
+int mcd_mh_get_age_sums(const mcd_mh_t* m, double* age_sum, double* age_sq, int64_t* n_samples);
+int mcd_mh_reset_age_sums(mcd_mh_t* m);
+
 #ifdef __cplusplus
 }
 #endif

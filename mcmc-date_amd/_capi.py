@@ -51,6 +51,19 @@ SYMBOLS = {
                                    C.c_int, _ip, _ip, _dp, C.c_int]),
     "mcd_prior_destroy": (None, [_vp]),
     "mcd_prior_logprior_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "mcd_mh_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
+    "mcd_mh_destroy": (None, [_vp]),
+    "mcd_mh_set_chain_offset": (C.c_int, [_vp, C.c_int64]),
+    "mcd_mh_set_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64]),
+    "mcd_mh_get_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64]),
+    "mcd_mh_get_posterior": (C.c_int, [_vp, _dp]),
+    "mcd_mh_run": (C.c_int, [_vp, _ip, C.c_int64, C.c_int32, C.c_int, _dp, C.POINTER(C.c_int8)]),
+    "mcd_mh_tune": (C.c_int, [_vp]),
+    "mcd_mh_get_tuning": (C.c_int, [_vp, _dp, _ip, _ip]),
+    "mcd_mh_set_tuning": (C.c_int, [_vp, _dp]),
+    "mcd_mh_reset_counters": (C.c_int, [_vp]),
+    "mcd_mh_get_age_sums": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64)]),
+    "mcd_mh_reset_age_sums": (C.c_int, [_vp]),
 }
 
 

@@ -1,0 +1,373 @@
+// mh_capi.cpp -- C ABI of the lock-step Metropolis-Hastings-Green driver (include/mcmcdate_mvn.h, "mcd_mh_*").
+// One step = propose (k_mh.hip) -> batched prior (k_prior.hip) -> batched likelihood + root-branch Jacobian
+// (k_tree_logpdf.hip) -> accept (k_mh.hip), all enqueued on one stream; the state stays on the device.  No CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "../../include/mcmcdate_mvn.h"
+#include "mvn_kernels.h"
+
+extern "C" int mcd_set_last_error_(int code, const char* msg);   // mvn_capi.cpp
+
+namespace {
+
+int mfail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return mcd_set_last_error_(code, buf);
+}
+
+#define MHIP_TRY(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return mfail(MCD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+}  // namespace
+
+struct mcd_mh {
+    int device = 0;
+    const mcd::MvnDev* mvn = nullptr;
+    const mcd::TreeDev* tree = nullptr;
+    const mcd::PriorDev* prior = nullptr;
+    mcd::MhDev dev{};
+    uint64_t seed = 0, step = 0;
+    int64_t n_samples = 0;
+    bool have_state = false;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    int32_t* d_sched = nullptr;
+    size_t sched_cap = 0;
+    double* d_trace_alpha = nullptr;
+    int8_t* d_trace_accept = nullptr;
+    size_t trace_cap = 0;
+
+    ~mcd_mh()
+    {
+        (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+        if (d_sched) (void)hipFree(d_sched);
+        if (d_trace_alpha) (void)hipFree(d_trace_alpha);
+        if (d_trace_accept) (void)hipFree(d_trace_accept);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(mcd_mh* m, T** p, size_t count, bool zero)
+{
+    *p = nullptr;
+    MHIP_TRY(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+    m->allocs.push_back(*p);
+    if (zero) MHIP_TRY(hipMemset(*p, 0, sizeof(T) * (count ? count : 1)));
+    return MCD_OK;
+}
+
+template <class T>
+int dev_upload(mcd_mh* m, const T** p, const T* src, size_t count)
+{
+    T* d = nullptr;
+    if (int rc = dev_alloc(m, &d, count, false)) return rc;
+    if (count) MHIP_TRY(hipMemcpy(d, src, sizeof(T) * count, hipMemcpyHostToDevice));
+    *p = d;
+    return MCD_OK;
+}
+
+// ln prior, ln likelihood and ln jacobianRootBranch of a state batch -> post[3][batch]
+int eval_posterior(mcd_mh* m, const double* sc, const double* H, const double* R, double* post)
+{
+    const mcd::MhDev& D = m->dev;
+    const int64_t B = D.batch;
+    MHIP_TRY(mcd::launch_prior(*m->prior, sc + 0 * B, sc + 1 * B, sc + 2 * B, H, sc + 3 * B, sc + 4 * B, R, D.ld, B, post, nullptr,
+                               m->stream));
+    MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, H, R, D.ld, sc + 2 * B, sc + 3 * B, B, post + B, post + 2 * B, m->stream));
+    return MCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
+                  const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
+                  const double* p0, const double* p1, int64_t batch, uint64_t seed)
+{
+    if (!out) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: out is NULL");
+    *out = nullptr;
+    if (!tree || !prior) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: NULL tree or prior handle");
+    if (n_prop <= 0 || !kind || !node || !n1 || !n2 || !jac_root || !dim || !p0 || !p1)
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: empty or NULL proposal table");
+    if (batch <= 0 || batch > (int64_t)1 << 31) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: batch must be in [1, 2^31]");
+    std::unique_ptr<mcd_mh> m(new mcd_mh());
+    int dev_t = 0, dev_p = 0;
+    const int32_t* parent = nullptr;
+    if (mcd_tree_internal_(tree, &m->mvn, &m->tree, &dev_t, &parent) || mcd_prior_internal_(prior, &m->prior, &dev_p))
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: invalid handle");
+    if (dev_t != dev_p) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree (device %d) and prior (device %d) live on different GPUs", dev_t, dev_p);
+    const int n = m->tree->n_nodes;
+    if (m->prior->n_nodes != n) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree has %d nodes, prior %d", n, m->prior->n_nodes);
+    std::vector<int32_t> size(n, 1);
+    for (int v = n - 1; v > 0; --v) size[parent[v]] += size[v];
+    // proposal table checks: the reference raises `error` for a path to a leaf / an invalid path when the proposal is built
+    const int root_right = 1 + size[1];
+    for (int i = 0; i < n_prop; ++i) {
+        const int k = kind[i], v = node[i];
+        if (!(p0[i] > 0) || !std::isfinite(p0[i])) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: p0 must be positive", i);
+        if (dim[i] < 1) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: dimension must be >= 1", i);
+        switch (k) {
+            case MCD_PROP_SCALE_SCALAR:
+                if (v < 0 || v > 4) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: scalar index %d", i, v);
+                break;
+            case MCD_PROP_SCALE_NORM_TREE:
+                if (v != 2 && v != 3) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: norm must be tH (2) or rMu (3)", i);
+                break;
+            case MCD_PROP_SLIDE_NODE:
+            case MCD_PROP_SCALE_SUBTREE_TIME:
+                if (v < 1 || v >= n) return mfail(MCD_ERR_INVALID_ARG, "slideNodeAtUltrametric: Path is invalid (proposal %d, node %d).", i, v);
+                if (size[v] == 1) return mfail(MCD_ERR_INVALID_ARG, "slideNodeAtUltrametric: Path leads to a leaf (proposal %d, node %d).", i, v);
+                break;
+            case MCD_PROP_PULLEY:
+                if (size[1] == 1) return mfail(MCD_ERR_INVALID_ARG, "pulleyUltrametric: Left sub tree is a leaf.");
+                if (size[root_right] == 1) return mfail(MCD_ERR_INVALID_ARG, "pulleyUltrametric: Right sub tree is a leaf.");
+                break;
+            case MCD_PROP_SCALE_BRANCH_RATE:
+            case MCD_PROP_SCALE_SUBTREE_RATE:
+                if (v < 1 || v >= n) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: node %d out of range", i, v);
+                break;
+            case MCD_PROP_SCALE_VAR_TREE:
+            case MCD_PROP_SCALE_VAR_TREE_AUTO: break;
+            case MCD_PROP_SCALE_CONTRARILY:
+                if (!(p1[i] > 0)) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: p1 must be positive", i);
+                break;
+            default: return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_create: proposal %d: unknown kind %d", i, k);
+        }
+    }
+    m->device = dev_t;
+    m->seed = seed;
+    MHIP_TRY(hipSetDevice(m->device));
+    MHIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    mcd::MhDev& D = m->dev;
+    D.n_nodes = n;
+    D.n_prop = n_prop;
+    D.batch = batch;
+    D.ld = (n + 7) / 8 * 8;
+    D.chain0 = 0;
+    D.parent = m->tree->parent;
+    int rc = MCD_OK;
+    const size_t B = (size_t)batch, BL = B * (size_t)D.ld, BP = B * (size_t)n_prop, BN = B * (size_t)n;
+    if ((rc = dev_upload(m.get(), &D.size, size.data(), (size_t)n)) || (rc = dev_upload(m.get(), &D.kind, kind, (size_t)n_prop)) ||
+        (rc = dev_upload(m.get(), &D.node, node, (size_t)n_prop)) || (rc = dev_upload(m.get(), &D.n1, n1, (size_t)n_prop)) ||
+        (rc = dev_upload(m.get(), &D.n2, n2, (size_t)n_prop)) || (rc = dev_upload(m.get(), &D.jac_root, jac_root, (size_t)n_prop)) ||
+        (rc = dev_upload(m.get(), &D.dim, dim, (size_t)n_prop)) || (rc = dev_upload(m.get(), &D.p0, p0, (size_t)n_prop)) ||
+        (rc = dev_upload(m.get(), &D.p1, p1, (size_t)n_prop)) || (rc = dev_alloc(m.get(), &D.sc, 5 * B, true)) ||
+        (rc = dev_alloc(m.get(), &D.H, BL, true)) || (rc = dev_alloc(m.get(), &D.R, BL, true)) ||
+        (rc = dev_alloc(m.get(), &D.sc1, 5 * B, true)) || (rc = dev_alloc(m.get(), &D.H1, BL, true)) ||
+        (rc = dev_alloc(m.get(), &D.R1, BL, true)) || (rc = dev_alloc(m.get(), &D.post, 3 * B, true)) ||
+        (rc = dev_alloc(m.get(), &D.post1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.lnqj, B, true)) ||
+        (rc = dev_alloc(m.get(), &D.tune, BP, false)) || (rc = dev_alloc(m.get(), &D.acc, BP, true)) ||
+        (rc = dev_alloc(m.get(), &D.tried, BP, true)) || (rc = dev_alloc(m.get(), &D.age_sum, BN, true)) ||
+        (rc = dev_alloc(m.get(), &D.age_sq, BN, true)))
+        return rc;
+    {
+        std::vector<double> ones(BP, 1.0);
+        MHIP_TRY(hipMemcpy(D.tune, ones.data(), sizeof(double) * BP, hipMemcpyHostToDevice));
+    }
+    *out = m.release();
+    return MCD_OK;
+}
+
+void mcd_mh_destroy(mcd_mh_t* m) { delete m; }
+
+int mcd_mh_set_chain_offset(mcd_mh_t* m, int64_t first_chain)
+{
+    if (!m || first_chain < 0 || first_chain + m->dev.batch > ((int64_t)1 << 32))
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_set_chain_offset: chain indices must stay below 2^32");
+    m->dev.chain0 = first_chain;
+    return MCD_OK;
+}
+
+int mcd_mh_set_state(mcd_mh_t* m, const double* birth, const double* death, const double* tH, const double* heights,
+                     const double* rMu, const double* rVar, const double* rates, int64_t ld_state)
+{
+    if (!m || !birth || !death || !tH || !heights || !rMu || !rVar || !rates) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_set_state: NULL argument");
+    mcd::MhDev& D = m->dev;
+    if (ld_state < D.n_nodes) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_set_state: ld_state < n_nodes");
+    MHIP_TRY(hipSetDevice(m->device));
+    const size_t B = (size_t)D.batch;
+    const double* sc_src[5] = {birth, death, tH, rMu, rVar};
+    for (int i = 0; i < 5; ++i) MHIP_TRY(hipMemcpyAsync(D.sc + i * B, sc_src[i], sizeof(double) * B, hipMemcpyHostToDevice, m->stream));
+    MHIP_TRY(hipMemcpy2DAsync(D.H, sizeof(double) * D.ld, heights, sizeof(double) * ld_state, sizeof(double) * D.n_nodes, B, hipMemcpyHostToDevice, m->stream));
+    MHIP_TRY(hipMemcpy2DAsync(D.R, sizeof(double) * D.ld, rates, sizeof(double) * ld_state, sizeof(double) * D.n_nodes, B, hipMemcpyHostToDevice, m->stream));
+    if (int rc = eval_posterior(m, D.sc, D.H, D.R, D.post)) return rc;
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    m->have_state = true;
+    return MCD_OK;
+}
+
+int mcd_mh_get_state(const mcd_mh_t* cm, double* birth, double* death, double* tH, double* heights, double* rMu, double* rVar,
+                     double* rates, int64_t ld_state)
+{
+    if (!cm || !birth || !death || !tH || !heights || !rMu || !rVar || !rates) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_get_state: NULL argument");
+    const mcd::MhDev& D = cm->dev;
+    if (ld_state < D.n_nodes) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_get_state: ld_state < n_nodes");
+    MHIP_TRY(hipSetDevice(cm->device));
+    MHIP_TRY(hipStreamSynchronize(cm->stream));
+    const size_t B = (size_t)D.batch;
+    double* sc_dst[5] = {birth, death, tH, rMu, rVar};
+    for (int i = 0; i < 5; ++i) MHIP_TRY(hipMemcpy(sc_dst[i], D.sc + i * B, sizeof(double) * B, hipMemcpyDeviceToHost));
+    MHIP_TRY(hipMemcpy2D(heights, sizeof(double) * ld_state, D.H, sizeof(double) * D.ld, sizeof(double) * D.n_nodes, B, hipMemcpyDeviceToHost));
+    MHIP_TRY(hipMemcpy2D(rates, sizeof(double) * ld_state, D.R, sizeof(double) * D.ld, sizeof(double) * D.n_nodes, B, hipMemcpyDeviceToHost));
+    return MCD_OK;
+}
+
+int mcd_mh_get_posterior(const mcd_mh_t* cm, double* post)
+{
+    if (!cm || !post) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_get_posterior: NULL argument");
+    const mcd::MhDev& D = cm->dev;
+    MHIP_TRY(hipSetDevice(cm->device));
+    MHIP_TRY(hipStreamSynchronize(cm->stream));
+    const size_t B = (size_t)D.batch;
+    std::vector<double> tmp(3 * B);
+    MHIP_TRY(hipMemcpy(tmp.data(), D.post, sizeof(double) * 3 * B, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < B; ++b)
+        for (int i = 0; i < 3; ++i) post[b * 3 + i] = tmp[i * B + b];
+    return MCD_OK;
+}
+
+int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, int accumulate, double* trace_alpha,
+               int8_t* trace_accept)
+{
+    if (!m) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_run: NULL handle");
+    if (!m->have_state) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_run: call mcd_mh_set_state first");
+    if (n_iter < 0 || S <= 0 || (n_iter > 0 && !schedule)) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_run: bad schedule");
+    if (n_iter == 0) return MCD_OK;
+    mcd::MhDev& D = m->dev;
+    const size_t steps = (size_t)n_iter * (size_t)S;
+    for (size_t i = 0; i < steps; ++i)
+        if (schedule[i] < 0 || schedule[i] >= D.n_prop) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_run: schedule[%zu] = %d is not a proposal row", i, schedule[i]);
+    MHIP_TRY(hipSetDevice(m->device));
+    if (steps > m->sched_cap) {
+        if (m->d_sched) (void)hipFree(m->d_sched);
+        m->d_sched = nullptr;
+        m->sched_cap = 0;
+        MHIP_TRY(hipMalloc((void**)&m->d_sched, sizeof(int32_t) * steps));
+        m->sched_cap = steps;
+    }
+    MHIP_TRY(hipMemcpyAsync(m->d_sched, schedule, sizeof(int32_t) * steps, hipMemcpyHostToDevice, m->stream));
+    const bool trace = trace_alpha || trace_accept;
+    const size_t B = (size_t)D.batch;
+    if (trace && steps * B > m->trace_cap) {
+        if (m->d_trace_alpha) (void)hipFree(m->d_trace_alpha);
+        if (m->d_trace_accept) (void)hipFree(m->d_trace_accept);
+        m->d_trace_alpha = nullptr;
+        m->d_trace_accept = nullptr;
+        m->trace_cap = 0;
+        MHIP_TRY(hipMalloc((void**)&m->d_trace_alpha, sizeof(double) * steps * B));
+        MHIP_TRY(hipMalloc((void**)&m->d_trace_accept, steps * B));
+        m->trace_cap = steps * B;
+    }
+    for (int64_t it = 0; it < n_iter; ++it) {
+        for (int s = 0; s < S; ++s) {
+            const int64_t gs = it * S + s;
+            MHIP_TRY(mcd::launch_mh_propose(D, m->d_sched, gs, m->step, m->seed, m->stream));
+            if (int rc = eval_posterior(m, D.sc1, D.H1, D.R1, D.post1)) return rc;
+            MHIP_TRY(mcd::launch_mh_accept(D, m->d_sched, gs, m->step, m->seed, trace ? m->d_trace_alpha + gs * B : nullptr,
+                                           trace ? m->d_trace_accept + gs * B : nullptr, m->stream));
+            m->step += 1;
+        }
+        if (accumulate) {
+            MHIP_TRY(mcd::launch_mh_accumulate(D, m->stream));
+            m->n_samples += 1;
+        }
+    }
+    if (trace_alpha) MHIP_TRY(hipMemcpyAsync(trace_alpha, m->d_trace_alpha, sizeof(double) * steps * B, hipMemcpyDeviceToHost, m->stream));
+    if (trace_accept) MHIP_TRY(hipMemcpyAsync(trace_accept, m->d_trace_accept, steps * B, hipMemcpyDeviceToHost, m->stream));
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    return MCD_OK;
+}
+
+int mcd_mh_tune(mcd_mh_t* m)
+{
+    if (!m) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_tune: NULL handle");
+    MHIP_TRY(hipSetDevice(m->device));
+    MHIP_TRY(mcd::launch_mh_tune(m->dev, m->stream));
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    return MCD_OK;
+}
+
+int mcd_mh_get_tuning(const mcd_mh_t* cm, double* tune, int32_t* accepted, int32_t* tried)
+{
+    if (!cm) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_get_tuning: NULL handle");
+    const mcd::MhDev& D = cm->dev;
+    MHIP_TRY(hipSetDevice(cm->device));
+    MHIP_TRY(hipStreamSynchronize(cm->stream));
+    const size_t BP = (size_t)D.batch * (size_t)D.n_prop;
+    if (tune) MHIP_TRY(hipMemcpy(tune, D.tune, sizeof(double) * BP, hipMemcpyDeviceToHost));
+    if (accepted) MHIP_TRY(hipMemcpy(accepted, D.acc, sizeof(int32_t) * BP, hipMemcpyDeviceToHost));
+    if (tried) MHIP_TRY(hipMemcpy(tried, D.tried, sizeof(int32_t) * BP, hipMemcpyDeviceToHost));
+    return MCD_OK;
+}
+
+int mcd_mh_set_tuning(mcd_mh_t* m, const double* tune)
+{
+    if (!m || !tune) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_set_tuning: NULL argument");
+    const mcd::MhDev& D = m->dev;
+    const size_t BP = (size_t)D.batch * (size_t)D.n_prop;
+    for (size_t i = 0; i < BP; ++i)
+        if (!(tune[i] > 0) || !std::isfinite(tune[i])) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_set_tuning: tuning parameters must be positive");
+    MHIP_TRY(hipSetDevice(m->device));
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    MHIP_TRY(hipMemcpy(D.tune, tune, sizeof(double) * BP, hipMemcpyHostToDevice));
+    return MCD_OK;
+}
+
+int mcd_mh_reset_counters(mcd_mh_t* m)
+{
+    if (!m) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_reset_counters: NULL handle");
+    const mcd::MhDev& D = m->dev;
+    const size_t BP = (size_t)D.batch * (size_t)D.n_prop;
+    MHIP_TRY(hipSetDevice(m->device));
+    MHIP_TRY(hipMemsetAsync(D.acc, 0, sizeof(int32_t) * BP, m->stream));
+    MHIP_TRY(hipMemsetAsync(D.tried, 0, sizeof(int32_t) * BP, m->stream));
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    return MCD_OK;
+}
+
+int mcd_mh_get_age_sums(const mcd_mh_t* cm, double* age_sum, double* age_sq, int64_t* n_samples)
+{
+    if (!cm) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_get_age_sums: NULL handle");
+    const mcd::MhDev& D = cm->dev;
+    MHIP_TRY(hipSetDevice(cm->device));
+    MHIP_TRY(hipStreamSynchronize(cm->stream));
+    const size_t BN = (size_t)D.batch * (size_t)D.n_nodes;
+    if (age_sum) MHIP_TRY(hipMemcpy(age_sum, D.age_sum, sizeof(double) * BN, hipMemcpyDeviceToHost));
+    if (age_sq) MHIP_TRY(hipMemcpy(age_sq, D.age_sq, sizeof(double) * BN, hipMemcpyDeviceToHost));
+    if (n_samples) *n_samples = cm->n_samples;
+    return MCD_OK;
+}
+
+int mcd_mh_reset_age_sums(mcd_mh_t* m)
+{
+    if (!m) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_reset_age_sums: NULL handle");
+    const mcd::MhDev& D = m->dev;
+    const size_t BN = (size_t)D.batch * (size_t)D.n_nodes;
+    MHIP_TRY(hipSetDevice(m->device));
+    MHIP_TRY(hipMemsetAsync(D.age_sum, 0, sizeof(double) * BN, m->stream));
+    MHIP_TRY(hipMemsetAsync(D.age_sq, 0, sizeof(double) * BN, m->stream));
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    m->n_samples = 0;
+    return MCD_OK;
+}
+
+}  // extern "C"

@@ -131,6 +131,7 @@ struct mcd_tree {
     int n_nodes = 0;
     mcd::TreeDev dev{};
     int32_t *d_parent = nullptr, *d_slot = nullptr, *d_cptr = nullptr, *d_cidx = nullptr;
+    std::vector<int32_t> parent;   // host copy
 
     ~mcd_tree()
     {
@@ -147,6 +148,16 @@ extern "C" int mcd_set_last_error_(int code, const char* msg)
 {
     g_last_error = msg ? msg : "";
     return code;
+}
+
+int mcd_tree_internal_(const mcd_tree* t, const mcd::MvnDev** mvn, const mcd::TreeDev** tree, int* device, const int32_t** host_parent)
+{
+    if (!t || !t->mvn) return MCD_ERR_INVALID_ARG;
+    *mvn = &t->mvn->dev;
+    *tree = &t->dev;
+    *device = t->mvn->device;
+    *host_parent = t->parent.data();
+    return MCD_OK;
 }
 
 extern "C" {
@@ -358,6 +369,7 @@ int mcd_tree_create(mcd_tree_t** out, const mcd_mvn_t* h, int n_nodes, const int
     std::unique_ptr<mcd_tree> t(new mcd_tree());
     t->mvn = h;
     t->n_nodes = n_nodes;
+    t->parent.assign(parent, parent + n_nodes);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMalloc((void**)&t->d_parent, sizeof(int32_t) * n_nodes));
     HIP_TRY(hipMalloc((void**)&t->d_slot, sizeof(int32_t) * NP));

@@ -49,6 +49,24 @@ struct PriorDev {
     const double* brace_sd;
 };
 
+// Lock-step Metropolis-Hastings workspace of one batch of chains (k_mh.hip); all pointers are device memory.
+struct MhDev {
+    int n_nodes, n_prop;
+    int64_t batch, ld;
+    int64_t chain0;          // global index of chain 0 (random stream id = chain0 + b)
+    const int32_t* parent;   // [n_nodes]
+    const int32_t* size;     // [n_nodes] nodes in the sub tree of v (pre-order: the range [v, v + size[v]))
+    const int32_t *kind, *node, *n1, *n2, *jac_root, *dim;   // [n_prop] proposal table (MCD_PROP_*)
+    const double *p0, *p1;
+    double *sc, *H, *R;        // current state: scalars [5][batch] (birth, death, tH, rMu, rVar), heights/rates [batch][ld]
+    double *sc1, *H1, *R1;     // proposed state
+    double *post, *post1;      // [3][batch] ln prior, ln likelihood, ln jacobianRootBranch (current, proposed)
+    double* lnqj;              // [batch] ln (q-ratio * Jacobian) of the pending proposal
+    double* tune;              // [batch][n_prop]
+    int32_t *acc, *tried;      // [batch][n_prop]
+    double *age_sum, *age_sq;  // [batch][n_nodes]
+};
+
 int padded_blocks(int n);          // supported R for dimension n, or -1
 int sweep_chunk_columns(int R);    // columns per register buffer (ncols granularity)
 
@@ -66,4 +84,16 @@ hipError_t launch_prior(const PriorDev& P, const double* birth, const double* de
                         const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
                         double* comp, hipStream_t st);
 
+hipError_t launch_mh_propose(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed, hipStream_t st);
+hipError_t launch_mh_accept(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
+                            double* trace_alpha, int8_t* trace_accept, hipStream_t st);
+hipError_t launch_mh_accumulate(const MhDev& M, hipStream_t st);
+hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
+
 }  // namespace mcd
+
+// handle internals shared between the translation units of the C ABI (mvn_capi.cpp, prior_capi.cpp, mh_capi.cpp)
+struct mcd_tree;
+struct mcd_prior;
+int mcd_tree_internal_(const mcd_tree* t, const mcd::MvnDev** mvn, const mcd::TreeDev** tree, int* device, const int32_t** host_parent);
+int mcd_prior_internal_(const mcd_prior* p, const mcd::PriorDev** prior, int* device);

@@ -69,6 +69,14 @@ struct mcd_prior {
     }
 };
 
+int mcd_prior_internal_(const mcd_prior* p, const mcd::PriorDev** prior, int* device)
+{
+    if (!p) return MCD_ERR_INVALID_ARG;
+    *prior = &p->dev;
+    *device = p->device;
+    return MCD_OK;
+}
+
 extern "C" {
 
 int mcd_prior_create(mcd_prior_t** out, int n_nodes, const int32_t* parent, double ht, int clock_model, int n_cal,

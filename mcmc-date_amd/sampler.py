@@ -1,0 +1,318 @@
+"""Batched Metropolis-Hastings-Green driver on the device (first slice).
+
+Host-side mirror of what the reference assembles in app/Definitions.hs and hands to `mcmc`'s `mhg`
+(app/Main.hs:460-479): the initial state (`initWith`, :96-123), the proposal cycle (`proposals`, :256-278 and the
+helper lists :145-253), the burn-in schedule with auto tuning (`burnIn`, :420-424) and the iterations (:440-441).
+`mcmc` evaluates one state per call; here B independent chains run in lock step on one GPU through `mcd_mh_*`
+(include/mcmcdate_mvn.h): every chain executes the same proposal of the (shuffled) cycle at the same time with its
+own random numbers, tuning parameter and accept/reject decision.  There is no CPU path.
+
+Built so far: every proposal of the reference cycle except the contrary time/rate proposals of
+lib/Mcmc/Tree/Proposal/Contrary.hs, the braced-node proposals of .../Brace.hs and NUTS; `proposals()` returns the
+names of the ones it leaves out so that nothing is skipped silently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+from .likelihood import TreeLikelihood
+from .prior import PriorFunction
+from .state import State, StateBatch
+from .tree import Topology
+
+SCALE_SCALAR, SLIDE_NODE, SCALE_SUBTREE_TIME, PULLEY, SCALE_BRANCH_RATE, SCALE_SUBTREE_RATE, SCALE_NORM_TREE, \
+    SCALE_VAR_TREE, SCALE_VAR_TREE_AUTO, SCALE_CONTRARILY = range(10)
+BIRTH, DEATH, TIME_HEIGHT, RATE_MEAN, RATE_VARIANCE = range(5)
+
+
+@dataclass
+class Proposal:
+    """One row of the proposal table (`Proposal I` in `mcmc`)."""
+    name: str
+    kind: int
+    node: int = 0
+    p0: float = 1.0          # standard deviation or gamma shape
+    p1: float = 1.0
+    n1: int = 0
+    n2: int = 0
+    jac_root: bool = False   # liftProposalWith jacobianRootBranch (the "[R]" proposals)
+    dim: int = 1             # PDimension
+    weight: int = 1          # PWeight
+
+
+# ---- initWith -- app/Definitions.hs:96-123 ------------------------------------------------------------------------
+def init_with(topo: Topology, lengths: Sequence[float]) -> State:
+    """Initial state from the mean tree: zero branches -> average branch, stem 0, terminal branches elongated until
+    the tree is ultrametric, height normalised to 1, all rates 1 (stem 0), every scalar 1."""
+    par = topo.parent
+    n = topo.n_nodes
+    ln = np.array(lengths, dtype=np.float64)
+    avg = ln[1:].sum() / (n - 1)
+    ln[1:][ln[1:] == 0] = avg
+    ln[0] = 0.0
+    dist = np.zeros(n)
+    for v in range(1, n):
+        dist[v] = dist[par[v]] + ln[v]
+    height = dist[topo.leaves].max()
+    heights = (height - dist) / height          # makeUltrametric, normalizeHeight, toHeightTreeUltrametric [elynx-tree]
+    heights[topo.leaves] = 0.0
+    heights[0] = 1.0
+    rates = np.ones(n)
+    rates[0] = 0.0
+    return State(1.0, 1.0, 1.0, heights, 1.0, 1.0, rates)
+
+
+# ---- proposals -- app/Definitions.hs:127-278 ----------------------------------------------------------------------
+def weight_n_branches(n: int) -> int:
+    """weightNBranches, :127-130."""
+    return int(math.floor(math.log(n) / math.log(1.3)))
+
+
+def _tables(topo: Topology):
+    n = topo.n_nodes
+    par = topo.parent
+    size = np.ones(n, np.int64)
+    inner = (~topo.leaves).astype(np.int64)      # nInnerNodes, Internal.hs:83-85
+    levels = np.ones(n, np.int64)                # elynx `depth`: a leaf has depth 1
+    plen = np.zeros(n, np.int64)                 # length of the path from the root
+    for v in range(1, n):
+        plen[v] = plen[par[v]] + 1
+    for v in range(n - 1, 0, -1):
+        size[par[v]] += size[v]
+        inner[par[v]] += inner[v]
+        levels[par[v]] = max(levels[par[v]], levels[v] + 1)
+    return size, inner, levels, plen
+
+
+def proposals(topo: Topology, braces: Sequence = (), calibrations_available: bool = False) -> Tuple[List[Proposal], List[str]]:
+    """The proposal cycle of `proposals bs calibrationsAvailable x Nothing` (:256-278) in the reference's order.
+    Returns (table, names of reference proposals that are not built yet)."""
+    n = topo.n_nodes
+    size, inner, levels, plen = _tables(topo)
+    leaf = topo.leaves
+    w = weight_n_branches(n)
+    l, r = topo.root_children()
+    ps: List[Proposal] = []
+    missing: List[str] = []
+    # :258-263
+    ps.append(Proposal("Time birth rate", SCALE_SCALAR, BIRTH, 10.0, weight=w))
+    ps.append(Proposal("Time death rate", SCALE_SCALAR, DEATH, 10.0, weight=w))
+    ps.append(Proposal("Rate mean", SCALE_SCALAR, RATE_MEAN, 10.0, weight=w))
+    ps.append(Proposal("Rate variance", SCALE_SCALAR, RATE_VARIANCE, 10.0, weight=w))
+    missing.append("Rates and time tree (scaleRatesAndTreeContrarily, Contrary.hs:420-446)")
+
+    children_of_root = lambda v: plen[v] == 1      # :133-134
+    other_nodes = lambda v: plen[v] > 1            # :137-138
+    sub_w = lambda v: min(3 + int(levels[v]) - 2, 8)
+
+    # proposalsTimeTree, :145-166
+    def time_ps(hn, tag, jac):
+        out = [Proposal(f"{tag} Time tree node {v}", SLIDE_NODE, v, 0.01, jac_root=jac, dim=1, weight=5)
+               for v in range(n) if not leaf[v] and hn(v)]
+        out += [Proposal(f"{tag} Time tree node {v}", SCALE_SUBTREE_TIME, v, 0.01, n1=int(inner[v]), jac_root=jac,
+                         dim=int(inner[v]), weight=sub_w(v)) for v in range(n) if not leaf[v] and hn(v)]
+        return out
+
+    if not leaf[l] and not leaf[r]:
+        ps.append(Proposal("[R] Time tree", PULLEY, 0, 0.01, n1=int(inner[l]), n2=int(inner[r]), jac_root=True,
+                           dim=int(inner[l] + inner[r]), weight=6))
+    ps += time_ps(children_of_root, "[R]", True)
+    ps += time_ps(other_nodes, "[O]", False)
+    for i, _ in enumerate(braces):
+        missing.append(f"[B] Time tree brace {i} (slideBracedNodesUltrametric, Brace.hs:98-156)")
+
+    # proposalsRateTree, :180-201
+    ps.append(Proposal("[R] Rate mean, Rate tree", SCALE_NORM_TREE, RATE_MEAN, 100.0, jac_root=True, dim=n, weight=w))
+    ps.append(Proposal("[R] Rate variance, Rate tree", SCALE_VAR_TREE, 0, 100.0, jac_root=True, dim=n, weight=w))
+    ps.append(Proposal("[R] Rate variance, Rate tree (autocorrelated)", SCALE_VAR_TREE_AUTO, 0, 100.0, jac_root=True, dim=n, weight=w))
+
+    def rate_ps(hn, tag, jac):
+        out = [Proposal(f"{tag} Rate tree branch {v}", SCALE_BRANCH_RATE, v, 100.0, jac_root=jac, dim=1, weight=3)
+               for v in range(n) if hn(v)]
+        out += [Proposal(f"{tag} Rate tree node {v}", SCALE_SUBTREE_RATE, v, 100.0, n1=int(size[v]), jac_root=jac,
+                         dim=int(size[v]), weight=sub_w(v)) for v in range(n) if not leaf[v] and hn(v)]
+        return out
+
+    ps += rate_ps(children_of_root, "[R]", True)
+    ps += rate_ps(other_nodes, "[O]", False)
+
+    # proposalsTimeRateTreeContra, :204-221
+    missing.append("[C] Trees (slideNodesContrarily / scaleSubTreesContrarily, Contrary.hs:35-77, 269-326)")
+    for i, _ in enumerate(braces):
+        missing.append(f"[C] [B] Trees brace {i} (slideBracedNodesContrarily, Brace.hs:37-61)")
+
+    # proposalsChangingTimeHeight, :241-253
+    if calibrations_available:
+        ps.append(Proposal("Time height", SCALE_SCALAR, TIME_HEIGHT, 3000.0, weight=w))
+        ps.append(Proposal("Time height, rate mean", SCALE_CONTRARILY, 0, 10.0, 0.1, dim=2, weight=w))
+        ps.append(Proposal("[R] Time height, Rate tree", SCALE_NORM_TREE, TIME_HEIGHT, 100.0, jac_root=True, dim=n, weight=w))
+        missing.append("[R] Trees (slideRootContrarily, Contrary.hs:191-223)")
+    return ps, missing
+
+
+def table_arrays(ps: Sequence[Proposal]) -> dict:
+    """Struct-of-arrays form of the table (what mcd_mh_create takes)."""
+    i32 = lambda f: np.ascontiguousarray([int(f(p)) for p in ps], dtype=np.int32)
+    f64 = lambda f: np.ascontiguousarray([float(f(p)) for p in ps], dtype=np.float64)
+    return dict(kind=i32(lambda p: p.kind), node=i32(lambda p: p.node), n1=i32(lambda p: p.n1), n2=i32(lambda p: p.n2),
+                jac_root=i32(lambda p: p.jac_root), dim=i32(lambda p: p.dim), p0=f64(lambda p: p.p0), p1=f64(lambda p: p.p1))
+
+
+def cycle_schedule(ps: Sequence[Proposal], n_iter: int, rng: np.random.Generator) -> np.ndarray:
+    """`mcmc`'s default cycle order [external]: every iteration executes each proposal `weight` times, in a freshly
+    shuffled order.  [n_iter, sum of weights] int32."""
+    base = np.repeat(np.arange(len(ps), dtype=np.int32), [p.weight for p in ps])
+    out = np.empty((n_iter, len(base)), np.int32)
+    for i in range(n_iter):
+        out[i] = rng.permutation(base)
+    return out
+
+
+# burnIn -- app/Definitions.hs:420-424: tuning periods (all proposals built here are `PFast`)
+BURN_IN_FAST = [10, 10] + list(range(10, 131, 10))
+BURN_IN_SLOW = list(range(100, 401, 20))
+ITERATIONS = 8000   # :440-441
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class Sampler:
+    """B chains on one GPU.  `tree_lik` and `prior` must live on the same device and outlive the sampler."""
+
+    def __init__(self, tree_lik: TreeLikelihood, prior: PriorFunction, table: Sequence[Proposal], batch: int, seed: int,
+                 first_chain: int = 0):
+        self.table = list(table)
+        self.topo: Topology = tree_lik.topo
+        self.batch = int(batch)
+        self._keep = (tree_lik, prior)
+        self._h = C.c_void_p()
+        a = table_arrays(self.table)
+        ip = lambda x: x.ctypes.data_as(_ip)
+        dp = lambda x: x.ctypes.data_as(_dp)
+        L = _capi.lib()
+        _capi.check(L.mcd_mh_create(C.byref(self._h), tree_lik._t, prior._p, len(self.table), ip(a["kind"]), ip(a["node"]),
+                                    ip(a["n1"]), ip(a["n2"]), ip(a["jac_root"]), ip(a["dim"]), dp(a["p0"]), dp(a["p1"]),
+                                    self.batch, C.c_uint64(seed)))
+        if first_chain:
+            _capi.check(L.mcd_mh_set_chain_offset(self._h, int(first_chain)))
+        self._sched_rng = np.random.default_rng([int(seed), 0x5EED])
+        self.iterations_done = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _capi.lib().mcd_mh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state --------------------------------------------------------------------------------------------------
+    def set_state(self, s: StateBatch):
+        nn = self.topo.n_nodes
+        f = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+        if s.time_birth_rate is None or s.time_death_rate is None or s.rate_variance is None:
+            raise ValueError("set_state: the state batch lacks time_birth_rate / time_death_rate / rate_variance")
+        arr = [f(s.time_birth_rate), f(s.time_death_rate), f(s.time_height), f(s.heights), f(s.rate_mean), f(s.rate_variance), f(s.rates)]
+        if arr[3].shape != (self.batch, nn) or arr[6].shape != (self.batch, nn) or any(a.shape != (self.batch,) for a in (arr[0], arr[1], arr[2], arr[4], arr[5])):
+            raise ValueError("set_state: inconsistent state shapes")
+        _capi.check(_capi.lib().mcd_mh_set_state(self._h, *[a.ctypes.data_as(_dp) for a in arr], nn))
+
+    def set_initial_state(self, x: State):
+        """Every chain starts from the same state (the reference starts its single chain from `initWith`)."""
+        self.set_state(StateBatch.from_states([x] * self.batch))
+
+    def state(self) -> StateBatch:
+        nn, B = self.topo.n_nodes, self.batch
+        birth, death, tH, rMu, rVar = (np.empty(B) for _ in range(5))
+        H, R = np.empty((B, nn)), np.empty((B, nn))
+        _capi.check(_capi.lib().mcd_mh_get_state(self._h, *[a.ctypes.data_as(_dp) for a in (birth, death, tH, H, rMu, rVar, R)], nn))
+        return StateBatch(H, R, tH, rMu, birth, death, rVar)
+
+    def posterior(self) -> np.ndarray:
+        """[B, 3]: ln prior, ln likelihood, ln jacobianRootBranch of the current states."""
+        post = np.empty((self.batch, 3))
+        _capi.check(_capi.lib().mcd_mh_get_posterior(self._h, post.ctypes.data_as(_dp)))
+        return post
+
+    # -- stepping -----------------------------------------------------------------------------------------------
+    def run_schedule(self, schedule: np.ndarray, accumulate: bool = False, trace: bool = False):
+        sched = np.ascontiguousarray(schedule, dtype=np.int32)
+        if sched.ndim != 2:
+            raise ValueError("run_schedule: schedule must be [n_iter, steps_per_iter]")
+        n_iter, S = sched.shape
+        ta = np.empty((n_iter * S, self.batch)) if trace else None
+        tk = np.empty((n_iter * S, self.batch), np.int8) if trace else None
+        _capi.check(_capi.lib().mcd_mh_run(self._h, sched.ctypes.data_as(_ip), n_iter, S, int(bool(accumulate)),
+                                           ta.ctypes.data_as(_dp) if trace else None,
+                                           tk.ctypes.data_as(C.POINTER(C.c_int8)) if trace else None))
+        self.iterations_done += n_iter
+        return (ta, tk) if trace else None
+
+    def run(self, n_iter: int, accumulate: bool = False, chunk: int = 256):
+        """n_iter iterations of the shuffled cycle."""
+        done = 0
+        while done < n_iter:
+            k = min(chunk, n_iter - done)
+            self.run_schedule(cycle_schedule(self.table, k, self._sched_rng), accumulate=accumulate)
+            done += k
+
+    def autotune(self):
+        _capi.check(_capi.lib().mcd_mh_tune(self._h))
+
+    def burn_in(self, fast: Sequence[int] = BURN_IN_FAST, slow: Sequence[int] = BURN_IN_SLOW):
+        """BurnInWithCustomAutoTuning fast slow: run each period, then tune (mcmc [external])."""
+        for period in list(fast) + list(slow):
+            self.run(period)
+            self.autotune()
+
+    # -- diagnostics --------------------------------------------------------------------------------------------
+    def tuning(self):
+        """(tuning parameters [B, P], accepted [B, P], tried [B, P]) since the last autotune / reset."""
+        B, P = self.batch, len(self.table)
+        t = np.empty((B, P))
+        a = np.empty((B, P), np.int32)
+        n = np.empty((B, P), np.int32)
+        _capi.check(_capi.lib().mcd_mh_get_tuning(self._h, t.ctypes.data_as(_dp), a.ctypes.data_as(_ip), n.ctypes.data_as(_ip)))
+        return t, a, n
+
+    def set_tuning(self, t: np.ndarray):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        if t.shape != (self.batch, len(self.table)):
+            raise ValueError("set_tuning: expected [batch, n_prop]")
+        _capi.check(_capi.lib().mcd_mh_set_tuning(self._h, t.ctypes.data_as(_dp)))
+
+    def reset_counters(self):
+        _capi.check(_capi.lib().mcd_mh_reset_counters(self._h))
+
+    def age_sums(self):
+        """(sum, sum of squares [B, n_nodes], n): running sums of the absolute node ages tH * h_v."""
+        B, nn = self.batch, self.topo.n_nodes
+        s, q = np.empty((B, nn)), np.empty((B, nn))
+        n = C.c_int64(0)
+        _capi.check(_capi.lib().mcd_mh_get_age_sums(self._h, s.ctypes.data_as(_dp), q.ctypes.data_as(_dp), C.byref(n)))
+        return s, q, int(n.value)
+
+    def reset_age_sums(self):
+        _capi.check(_capi.lib().mcd_mh_reset_age_sums(self._h))
+
+    def node_age_summary(self):
+        """Posterior mean and variance of every node age pooled over chains and accumulated iterations, plus the
+        standard error of the mean estimated from the spread of the per-chain means."""
+        s, q, n = self.age_sums()
+        if n == 0:
+            raise ValueError("node_age_summary: nothing accumulated")
+        per_chain = s / n
+        mean = per_chain.mean(axis=0)
+        var = q.sum(axis=0) / (n * self.batch) - mean * mean
+        sem = per_chain.std(axis=0, ddof=1) / math.sqrt(self.batch) if self.batch > 1 else np.full_like(mean, np.nan)
+        return mean, var, sem

@@ -25,6 +25,16 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
 
+class _OrmModel(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("parent", _ip), ("mu", _dp), ("sigma_inv", _dp), ("logdet", C.c_double),
+                ("ht", C.c_double), ("clock_model", C.c_int32), ("ncal", C.c_int32), ("cal_node", _ip), ("cal_has_lo", _ip),
+                ("cal_lo", _dp), ("cal_lo_p", _dp), ("cal_has_hi", _ip), ("cal_hi", _dp), ("cal_hi_p", _dp),
+                ("ncon", C.c_int32), ("con_young", _ip), ("con_old", _ip), ("con_p", _dp),
+                ("nbr", C.c_int32), ("br_ptr", _ip), ("br_nodes", _ip), ("br_sd", _dp),
+                ("n_prop", C.c_int32), ("kind", _ip), ("node", _ip), ("n1", _ip), ("n2", _ip), ("jac_root", _ip), ("dim", _ip),
+                ("p0", _dp), ("p1", _dp)]
+
+
 def build(native: bool = False, force: bool = False) -> str:
     target = "liboracle_native.so" if native else "liboracle.so"
     subprocess.run(["make", "-s"] + (["-B"] if force else []) + ["-C", _HERE, target], check=True)
@@ -39,7 +49,8 @@ def lib(native: bool = False):
     path = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
     src = os.path.join(_HERE, "mvn_oracle.c")
     src2 = os.path.join(_HERE, "prior_oracle.c")
-    newest = max(os.path.getmtime(p) for p in (src, src2) if os.path.exists(p))
+    src3 = os.path.join(_HERE, "mh_oracle.c")
+    newest = max(os.path.getmtime(p) for p in (src, src2, src3) if os.path.exists(p))
     if not os.path.exists(path) or newest > os.path.getmtime(path):
         build(native)
     L = C.CDLL(path)
@@ -101,6 +112,21 @@ def lib(native: bool = False):
     L.orp_prior.restype = C.c_double
     L.orp_prior.argtypes = ([C.c_double, C.c_int, C.c_int, _ip, C.c_double, C.c_double, C.c_double, _dp, C.c_double, C.c_double, _dp]
                             + [C.c_int, _ip, _ip, _dp, _dp, _ip, _dp, _dp] + [C.c_int, _ip, _ip, _dp] + [C.c_int, _ip, _ip, _dp] + [_dp])
+    # mh_oracle.c
+    _u32p = C.POINTER(C.c_uint32)
+    L.orm_philox4x32.restype = None; L.orm_philox4x32.argtypes = [_u32p, _u32p, _u32p]
+    L.orm_uniform_pair.restype = None; L.orm_uniform_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, _dp]
+    L.orm_erfinv.restype = C.c_double; L.orm_erfinv.argtypes = [C.c_double]
+    L.orm_tn_logpdf.restype = C.c_double; L.orm_tn_logpdf.argtypes = [C.c_double] * 5
+    L.orm_tn_quantile.restype = C.c_double; L.orm_tn_quantile.argtypes = [C.c_double] * 5
+    L.orm_gamma_draw.restype = C.c_double; L.orm_gamma_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, C.c_double]
+    _mp = C.POINTER(_OrmModel)
+    L.orm_run.restype = C.c_int
+    L.orm_run.argtypes = ([_mp, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64, _ip, C.c_int64, C.c_int32, C.c_uint64,
+                           C.c_uint64, C.c_int64, _dp, _ip, _ip, _dp, _dp, _dp, _dp, C.POINTER(C.c_int8)])
+    L.orm_tune.restype = None; L.orm_tune.argtypes = [_mp, C.c_int64, _dp, _ip, _ip]
+    L.orm_propose_once.restype = C.c_int
+    L.orm_propose_once.argtypes = [_mp, C.c_int, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     _LIBS[key] = L
     return L
 
@@ -290,3 +316,112 @@ def prior(spec: PriorSpec, birth, death, tH, heights, rMu, rVar, rates):
                         len(spec.con_young), ip(spec.con_young), ip(spec.con_old), dp(spec.con_p),
                         len(spec.br_sd), ip(spec.br_ptr), ip(spec.br_nodes), dp(spec.br_sd), dp(comp))
     return float(v), comp
+
+
+# ---- mh_oracle.c: CPU twin of the lock-step Metropolis-Hastings-Green driver ---------------------------------------
+def philox4x32(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib().orm_philox4x32(c, k, o)
+    return [int(x) for x in o]
+
+
+def uniform_pair(seed, chain, step, d):
+    u = np.empty(2)
+    lib().orm_uniform_pair(seed, chain, step, d, u.ctypes.data_as(_dp))
+    return u
+
+
+def erfinv(y) -> float:
+    return float(lib().orm_erfinv(float(y)))
+
+
+def tn_logpdf(m, s, a, b, x) -> float:
+    return float(lib().orm_tn_logpdf(m, s, a, b, x))
+
+
+def tn_quantile(m, s, a, b, p) -> float:
+    return float(lib().orm_tn_quantile(m, s, a, b, p))
+
+
+def gamma_draw(seed, chain, step, shape, scale) -> float:
+    return float(lib().orm_gamma_draw(seed, chain, step, shape, scale))
+
+
+class MhModel:
+    """Topology + likelihood operands + PriorSpec + proposal table (dict of equally long arrays: kind, node, n1, n2,
+    jac_root, dim, p0, p1) for orm_run."""
+
+    def __init__(self, parent, mu, sigma_inv, logdet, spec: PriorSpec, table: dict):
+        self.keep = k = {}
+        k["parent"] = np.ascontiguousarray(parent, np.int32)
+        k["mu"] = np.ascontiguousarray(mu, np.float64)
+        k["sigma_inv"] = np.ascontiguousarray(sigma_inv, np.float64)
+        for name in ("kind", "node", "n1", "n2", "jac_root", "dim"):
+            k[name] = np.ascontiguousarray(table[name], np.int32)
+        for name in ("p0", "p1"):
+            k[name] = np.ascontiguousarray(table[name], np.float64)
+        self.spec = spec
+        self.n_nodes = len(k["parent"])
+        self.n_prop = len(k["kind"])
+        ip = lambda a: a.ctypes.data_as(_ip)
+        dp = lambda a: a.ctypes.data_as(_dp)
+        self.c = _OrmModel(self.n_nodes, ip(k["parent"]), dp(k["mu"]), dp(k["sigma_inv"]), float(logdet), spec.ht, spec.model,
+                           len(spec.cal_node), ip(spec.cal_node), ip(spec.cal_has_lo), dp(spec.cal_lo), dp(spec.cal_lo_p),
+                           ip(spec.cal_has_hi), dp(spec.cal_hi), dp(spec.cal_hi_p),
+                           len(spec.con_young), ip(spec.con_young), ip(spec.con_old), dp(spec.con_p),
+                           len(spec.br_sd), ip(spec.br_ptr), ip(spec.br_nodes), dp(spec.br_sd),
+                           self.n_prop, ip(k["kind"]), ip(k["node"]), ip(k["n1"]), ip(k["n2"]), ip(k["jac_root"]), ip(k["dim"]),
+                           dp(k["p0"]), dp(k["p1"]))
+
+
+class MhChains:
+    """State of `batch` chains of the CPU twin; same call sequence as the device driver (run / tune / sums)."""
+
+    def __init__(self, model: MhModel, birth, death, tH, H, rMu, rVar, R, seed, chain0=0):
+        self.m = model
+        f = lambda a: np.array(a, np.float64, order="C")
+        self.birth, self.death, self.tH, self.rMu, self.rVar = f(birth), f(death), f(tH), f(rMu), f(rVar)
+        self.H, self.R = f(H), f(R)
+        self.B = len(self.tH)
+        self.seed, self.step, self.chain0 = int(seed), 0, int(chain0)
+        P, n = model.n_prop, model.n_nodes
+        self.tune = np.ones((self.B, P))
+        self.acc = np.zeros((self.B, P), np.int32)
+        self.tried = np.zeros((self.B, P), np.int32)
+        self.post = np.zeros((self.B, 3))
+        self.age_sum = np.zeros((self.B, n))
+        self.age_sq = np.zeros((self.B, n))
+        self.n_samples = 0
+
+    def run(self, schedule, accumulate=False, trace=False):
+        sched = np.ascontiguousarray(schedule, np.int32)
+        n_iter, S = sched.shape
+        ta = np.empty((n_iter * S, self.B)) if trace else None
+        tk = np.empty((n_iter * S, self.B), np.int8) if trace else None
+        dp = lambda a: a.ctypes.data_as(_dp) if a is not None else None
+        ip = lambda a: a.ctypes.data_as(_ip)
+        rc = lib().orm_run(C.byref(self.m.c), self.B, dp(self.birth), dp(self.death), dp(self.tH), dp(self.H), dp(self.rMu),
+                           dp(self.rVar), dp(self.R), self.H.shape[1], ip(sched), n_iter, S, self.seed, self.step, self.chain0,
+                           dp(self.tune), ip(self.acc), ip(self.tried), dp(self.post),
+                           dp(self.age_sum) if accumulate else None, dp(self.age_sq) if accumulate else None, dp(ta),
+                           tk.ctypes.data_as(C.POINTER(C.c_int8)) if trace else None)
+        if rc:
+            raise OracleError(f"orm_run: {rc}")
+        self.step += n_iter * S
+        if accumulate:
+            self.n_samples += n_iter
+        return (ta, tk) if trace else None
+
+    def autotune(self):
+        ip = lambda a: a.ctypes.data_as(_ip)
+        lib().orm_tune(C.byref(self.m.c), self.B, self.tune.ctypes.data_as(_dp), ip(self.acc), ip(self.tried))
+
+
+def propose_once(model: MhModel, p, t, seed, chain, step, sc, H, R):
+    """Apply proposal row p once: (scalars', H', R', ln q-ratio, ln Jacobian)."""
+    sc = np.ascontiguousarray(sc, np.float64); H = np.ascontiguousarray(H, np.float64); R = np.ascontiguousarray(R, np.float64)
+    sc1 = np.empty(5); H1 = np.empty_like(H); R1 = np.empty_like(R); q = np.empty(1); j = np.empty(1)
+    dp = lambda a: a.ctypes.data_as(_dp)
+    lib().orm_propose_once(C.byref(model.c), int(p), float(t), int(seed), int(chain), int(step), dp(sc), dp(H), dp(R), dp(sc1),
+                           dp(H1), dp(R1), dp(q), dp(j))
+    return sc1, H1, R1, float(q[0]), float(j[0])

@@ -1,0 +1,164 @@
+"""GPU parity of the lock-step Metropolis-Hastings-Green driver (first slice) against its CPU
+twin oracle/mh_oracle.c.  Both sides draw the same counter-based random numbers, so chains can be compared step by
+step: ln acceptance ratio of every step within 1e-8 + 1e-12 |ln posterior| (the device evaluates the likelihood
+through the Cholesky factor and libm differs from ocml in the last ulp), identical accept/reject
+decisions, identical counters, final states within 1e-9 relative.  Posterior level: node-age means of two
+independent runs (device vs twin, different seeds) within 1 % on tests/12-leaves-variable-rate (north_star)."""
+import numpy as np
+import pytest
+
+import mcmc_date_amd as M
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+FIX = ["06-leaves-constant-rate", "10-leaves-autocorrelated-rate", "12-leaves-variable-rate", "24-leaves-braces", "25-leaves-bastien"]
+
+
+def setup(fx, model="UncorrelatedGamma", B=16, seed=7, first_chain=0):
+    topo = M.Topology(fx["parent"])
+    cal = [M.Calibration(f"c{i}", int(r[0]), r[2] if r[1] else None, r[3], r[5] if r[4] else None, r[6]) for i, r in enumerate(fx["cal"])]
+    con = [M.Constraint(f"k{i}", int(r[0]), int(r[1]), r[2]) for i, r in enumerate(fx["con"])]
+    br = [M.Brace(f"b{i}", [int(n) for n in fx["brace_nodes"][fx["brace_ptr"][i]:fx["brace_ptr"][i + 1]]], float(s))
+          for i, s in enumerate(fx["brace_sd"])]
+    ht = float(fx["prior_ht"])
+    ps, missing = M.proposals(topo, br, calibrations_available=len(cal) > 0)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    pf = M.PriorFunction(ht, model, cal, con, br, topo)
+    smp = M.Sampler(lik, pf, ps, B, seed, first_chain=first_chain)
+    spec = O.PriorSpec(fx["parent"], ht, model, [(c.node, c.lower, c.lower_p, c.upper, c.upper_p) for c in cal],
+                       [(k.young, k.old, k.p) for k in con], [(b.nodes, b.sd) for b in br])
+    twin_model = O.MhModel(fx["parent"], fx["mu"], fx["sigma_inv"], float(fx["logdet"]), spec, M.table_arrays(ps))
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    if cal:
+        x0.time_height = ht
+    s0 = M.StateBatch.from_states([x0] * B)
+    smp.set_state(s0)
+    twin = O.MhChains(twin_model, s0.time_birth_rate, s0.time_death_rate, s0.time_height, s0.heights, s0.rate_mean,
+                      s0.rate_variance, s0.rates, seed=seed, chain0=first_chain)
+    return topo, ps, smp, twin
+
+
+def compare_states(smp, twin, rtol=1e-9, atol_post=1e-8):
+    s = smp.state()
+    for a, b in ((s.time_birth_rate, twin.birth), (s.time_death_rate, twin.death), (s.time_height, twin.tH), (s.heights, twin.H),
+                 (s.rate_mean, twin.rMu), (s.rate_variance, twin.rVar), (s.rates, twin.R)):
+        assert np.allclose(a, b, rtol=rtol, atol=0), np.max(np.abs(a - b) / np.maximum(1e-300, np.abs(b)))
+    post = smp.posterior()
+    assert np.allclose(post, twin.post, rtol=1e-13, atol=atol_post)
+
+
+@pytest.mark.parametrize("name", FIX)
+def test_lockstep_parity_with_cpu_twin(gpu, golden, name):
+    topo, ps, smp, twin = setup(golden[name], B=16, seed=11)
+    rng = np.random.default_rng(5)
+    # every chain its own tuning parameters, spread over two orders of magnitude
+    tune = np.exp(rng.uniform(np.log(0.1), np.log(10.0), (16, len(ps))))
+    smp.set_tuning(tune)
+    twin.tune[:] = tune
+    sched = M.cycle_schedule(ps, 4, rng)
+    # far from the mode (the initial state) ln likelihoods reach 1e10: the tolerance scales with that magnitude
+    tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
+    ta, tk = smp.run_schedule(sched, accumulate=True, trace=True)
+    ra, rk = twin.run(sched, accumulate=True, trace=True)
+    fin = np.isfinite(ra)
+    assert np.array_equal(np.isfinite(ta), fin)
+    assert np.max(np.abs(ta[fin] - ra[fin])) <= tol, (np.max(np.abs(ta[fin] - ra[fin])), tol)
+    assert np.array_equal(tk, rk)
+    assert 0.05 < tk.mean() < 0.95                      # both outcomes exercised
+    t, acc, tried = smp.tuning()
+    assert np.array_equal(acc, twin.acc) and np.array_equal(tried, twin.tried) and np.array_equal(t, tune)
+    compare_states(smp, twin)
+    s, q, n = smp.age_sums()
+    assert n == 4 and np.allclose(s, twin.age_sum, rtol=1e-9) and np.allclose(q, twin.age_sq, rtol=1e-9)
+    # auto tuning
+    smp.autotune()
+    twin.autotune()
+    t, acc, tried = smp.tuning()
+    assert np.allclose(t, twin.tune, rtol=1e-14) and not acc.any() and not tried.any()
+    # a second stretch continues the same random streams
+    sched = M.cycle_schedule(ps, 2, rng)
+    ta, tk = smp.run_schedule(sched, trace=True)
+    ra, rk = twin.run(sched, trace=True)
+    assert np.array_equal(tk, rk)
+    compare_states(smp, twin)
+
+
+@pytest.mark.parametrize("model", ["UncorrelatedLogNormal", "UncorrelatedWhiteNoise", "AutocorrelatedLogNormal"])
+def test_lockstep_parity_other_clock_models(gpu, golden, model):
+    topo, ps, smp, twin = setup(golden["12-leaves-variable-rate"], model=model, B=8, seed=3)
+    sched = M.cycle_schedule(ps, 3, np.random.default_rng(1))
+    tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
+    ta, tk = smp.run_schedule(sched, trace=True)
+    ra, rk = twin.run(sched, trace=True)
+    fin = np.isfinite(ra)
+    assert np.array_equal(np.isfinite(ta), fin) and np.max(np.abs(ta[fin] - ra[fin])) <= tol
+    assert np.array_equal(tk, rk)
+    compare_states(smp, twin)
+
+
+def test_chain_streams_do_not_depend_on_the_shard(gpu, golden):
+    """Chains 8..15 of a 16-chain run equal an 8-chain shard created with first_chain = 8 (what a second GPU runs)."""
+    fx = golden["12-leaves-variable-rate"]
+    topo, ps, full, _ = setup(fx, B=16, seed=21)
+    _, _, shard, _ = setup(fx, B=8, seed=21, first_chain=8)
+    sched = M.cycle_schedule(ps, 3, np.random.default_rng(2))
+    _, k_full = full.run_schedule(sched, trace=True)
+    _, k_shard = shard.run_schedule(sched, trace=True)
+    assert np.array_equal(k_full[:, 8:], k_shard)
+    a, b = full.state(), shard.state()
+    assert np.array_equal(a.heights[8:], b.heights) and np.array_equal(a.rates[8:], b.rates) and np.array_equal(a.time_height[8:], b.time_height)
+
+
+def test_rejects_invalid_states_and_tables(gpu, golden):
+    fx = golden["12-leaves-variable-rate"]
+    topo, ps, smp, twin = setup(fx, B=4, seed=1)
+    # a chain that starts outside the support never moves: every proposal is rejected (NaN / -inf ratios)
+    s = smp.state()
+    s.time_height[2] = -1.0
+    smp.set_state(s)
+    _, tk = smp.run_schedule(M.cycle_schedule(ps, 1, np.random.default_rng(0)), trace=True)
+    after = smp.state()
+    assert np.isneginf(smp.posterior()[2, 0])
+    assert tk[:, 0].any() and not tk[:, 2].any()
+    assert after.time_height[2] == -1.0 and np.array_equal(after.heights[2], s.heights[2]) and np.array_equal(after.rates[2], s.rates[2])
+    # structural faults
+    lik, pf = smp._keep
+    leaf = int(np.nonzero(topo.leaves)[0][0])
+    with pytest.raises(M.McdError, match="leaf"):
+        M.Sampler(lik, pf, [M.Proposal("bad", M.sampler.SLIDE_NODE, leaf, 0.01)], 4, 0)
+    with pytest.raises(M.McdError):
+        M.Sampler(lik, pf, [M.Proposal("bad", 99, 1, 0.01)], 4, 0)
+    with pytest.raises(M.McdError):
+        M.Sampler(lik, pf, [M.Proposal("bad", M.sampler.SCALE_SCALAR, 7, 10.0)], 4, 0)
+    with pytest.raises(M.McdError):
+        smp.run_schedule(np.array([[len(ps)]], np.int32))
+    fresh = M.Sampler(lik, pf, ps, 4, 0)
+    with pytest.raises(M.McdError, match="set_state"):
+        fresh.run(1)
+
+
+def test_posterior_node_ages_within_one_percent(gpu, golden):
+    """north_star: posterior node-age means within 1 % of the CPU path on tests/12-leaves-variable-rate.  64 chains
+    (BASELINE.json configs[1]), the reference's burn-in schedule and 8000 iterations (app/Definitions.hs:420-441);
+    device run and CPU twin use DIFFERENT seeds, i.e. the comparison is between two independent samples."""
+    fx = golden["12-leaves-variable-rate"]
+    B = 64
+    topo, ps, smp, _ = setup(fx, B=B, seed=1001)
+    _, _, _, twin = setup(fx, B=B, seed=2002)
+    smp.burn_in()
+    smp.run(M.sampler.ITERATIONS, accumulate=True)
+    rng = np.random.default_rng(9)
+    for period in M.sampler.BURN_IN_FAST + M.sampler.BURN_IN_SLOW:
+        twin.run(M.cycle_schedule(ps, period, rng))
+        twin.autotune()
+    twin.run(M.cycle_schedule(ps, M.sampler.ITERATIONS, rng), accumulate=True)
+    mean_gpu, var_gpu, sem_gpu = smp.node_age_summary()
+    mean_cpu = twin.age_sum.mean(axis=0) / twin.n_samples
+    inner = ~topo.leaves
+    rel = np.abs(mean_gpu[inner] - mean_cpu[inner]) / mean_cpu[inner]
+    assert rel.max() <= 0.01, rel
+    # acceptance rates sit near the auto tuner's targets after burn-in
+    t, acc, tried = smp.tuning()
+    rate = acc.sum(axis=0) / np.maximum(1, tried.sum(axis=0))
+    dims = np.array([p.dim for p in ps])
+    assert np.all(np.abs(rate[dims == 1] - 0.44) < 0.1)
