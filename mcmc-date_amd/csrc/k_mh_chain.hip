@@ -1,0 +1,174 @@
+// k_mh_chain.hip -- a whole Metropolis-Hastings-Green schedule in ONE launch for trees of at most 64 nodes (gfx950).
+//
+// One wave owns one chain for the complete schedule (n_iter iterations x steps_per_iter proposals): the chain's state
+// (node heights, branch rates, the five scalars, ln prior / ln likelihood / ln jacobianRootBranch), its tuning
+// parameters and its acceptance counters live in LDS and registers and are written back once at the end.  The
+// row-scaled Cholesky factor of Sigma (N <= 62, at most 31 KB) is staged ONCE per workgroup in LDS and shared by the
+// workgroup's waves.  Per step, inside the wave and without any workgroup barrier:
+//     propose (mh_device.hpp)  ->  ln prior (prior_device.hpp)  ->  distances + forward solve + dot  ->  accept.
+// lanes = nodes for the state and the prior, lanes = rows of the factor for the solve: z_j is broadcast with
+// v_readlane and column j of the factor is one conflict-free ds_read_b64 (address j * 64 + lane).
+//
+// The arithmetic is the one of the per-phase kernels (k_mh.hip, k_prior.hip, k_tree_logpdf.hip at R = 1): same
+// proposal code, same prior code, the same fma order in the column sweep and the same reduction tree, so a chain
+// advanced by this kernel is bit-identical to the same chain advanced by one launch per phase
+// (tests/test_gpu_mh.py::test_chain_kernel_equals_per_phase_kernels).
+//
+// Reference: the loop this replaces is `mhg`'s iteration of `mcmc` [external] driven from app/Main.hs:460-479 with
+// the cycle of app/Definitions.hs:256-278; likelihood app/Probability.hs:166-173, 195-207; jacobianRootBranch :393-410.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mh_device.hpp"
+#include "prior_device.hpp"
+
+namespace mcd {
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDev T, PriorDev P, const double* __restrict__ Fp,
+                                                       const int32_t* __restrict__ sched, int64_t n_steps, int32_t S,
+                                                       int accumulate, uint64_t step0, uint64_t seed,
+                                                       double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
+{
+    extern __shared__ double lds[];
+    const int n = V.n, nn = M.n_nodes, NP = M.n_prop;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* Fs = lds;                                   // [n][64]: Fs[j * 64 + i] = L_ij / L_ii (i > j), 0 otherwise
+    for (int i = threadIdx.x; i < n * 64; i += 64 * WPB) Fs[i] = Fp[i];
+    __syncthreads();                                    // the only workgroup barrier; waves are independent afterwards
+    const int64_t b = (int64_t)blockIdx.x * WPB + wave;
+    if (b >= M.batch) return;
+    const size_t per_wave = 4 * 64 + (size_t)NP + (size_t)NP;          // doubles: Hc Rc Hp Rp | tune | (acc, tried) as int32 pairs
+    double* Hc = lds + (size_t)n * 64 + (size_t)wave * per_wave;
+    double* Rc = Hc + 64;
+    double* Hp = Rc + 64;
+    double* Rp = Hp + 64;
+    double* tune = Rp + 64;
+    int32_t* acc = reinterpret_cast<int32_t*>(tune + NP);
+    int32_t* tried = acc + NP;
+    const int64_t B = M.batch;
+    Hc[lane] = (lane < nn) ? M.H[b * M.ld + lane] : 0.0;
+    Rc[lane] = (lane < nn) ? M.R[b * M.ld + lane] : 0.0;
+    for (int i = lane; i < NP; i += 64) {
+        tune[i] = M.tune[b * NP + i];
+        acc[i] = M.acc[b * NP + i];
+        tried[i] = M.tried[b * NP + i];
+    }
+    double sc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sc[i] = M.sc[i * B + b];
+    double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
+    // row `lane` of the solve: mean, 1 / L_ii, the node whose branch feeds this distance slot and that node's parent
+    const double mu_l = V.mu[lane], iv_l = V.invdiag[lane];
+    const int slot = T.slot_node[lane];
+    const int slot_par = (slot >= 0) ? T.parent[slot] : 0;
+    const int rr = T.root_right;
+    double age_s = 0.0, age_q = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    int p = sched[0];
+    for (int64_t gs = 0; gs < n_steps; ++gs) {
+        const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : 0;
+        const uint64_t step = step0 + (uint64_t)gs;
+        const Rng g = mh_rng(seed, M.chain0 + b, step);
+        double sc1[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
+        const double lnqj = mh_propose_wave(M, p, tune[p], g, lane, sc1, Hc, Rc, Hp, Rp);
+        __builtin_amdgcn_wave_barrier();
+        const double lp1 = prior_eval_wave(P, lane, sc1[0], sc1[1], sc1[2], sc1[3], sc1[4], Hp, Rp, nullptr);
+        // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207)
+        double dist = 0.0;
+        if (slot >= 0) {
+            dist = (Hp[slot_par] - Hp[slot]) * Rp[slot];
+            if (lane == 0) dist = dist + (Hp[0] - Hp[rr]) * Rp[rr];
+            dist = dist * (sc1[2] * sc1[3]);
+        }
+        const double lj1 = log(1.0 / mh_readlane64(dist, 0));              // jacobianRootBranch, :393-410
+        double d = (dist - mu_l) * iv_l;
+        for (int j = 0; j < n; ++j) {                                      // column sweep of L z = x - mu, row-scaled
+            const double zj = mh_readlane64(d, j);
+            d = fma(-Fs[j * 64 + lane], zj, d);
+        }
+        const double q = pr_wave_sum(fma(d, d, 0.0));
+        const double ll1 = V.c + (-0.5) * (V.logdet + q);                  // :169
+        double la = (lp1 + ll1) - (lp + ll) + lnqj;
+        if (M.jac_root[p]) la += lj1 - lj;
+        double ua, ub;
+        philox_block(g, 0xFFFFFFFFu, ua, ub);
+        const bool ok = (la >= 0) || (ua < exp(la));
+        if (ok) {
+            Hc[lane] = Hp[lane];
+            Rc[lane] = Rp[lane];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
+            lp = lp1;
+            ll = ll1;
+            lj = lj1;
+        }
+        if (lane == 0) {
+            tried[p] += 1;
+            if (ok) acc[p] += 1;
+            if (trace_alpha) trace_alpha[gs * B + b] = la;
+            if (trace_accept) trace_accept[gs * B + b] = ok ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (accumulate && (gs + 1) % S == 0) {
+            const double a = sc[2] * Hc[lane];
+            age_s += a;
+            age_q += a * a;
+        }
+        p = p_next;
+    }
+    if (lane < nn) {
+        M.H[b * M.ld + lane] = Hc[lane];
+        M.R[b * M.ld + lane] = Rc[lane];
+        if (accumulate) {
+            M.age_sum[b * nn + lane] += age_s;
+            M.age_sq[b * nn + lane] += age_q;
+        }
+    }
+    for (int i = lane; i < NP; i += 64) {
+        M.acc[b * NP + i] = acc[i];
+        M.tried[b * NP + i] = tried[i];
+    }
+    if (lane < 5) {
+        double mine = sc[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i)
+            if (lane == i) mine = sc[i];
+        M.sc[lane * B + b] = mine;
+    }
+    if (lane == 0) {
+        M.post[b] = lp;
+        M.post[B + b] = ll;
+        M.post[2 * B + b] = lj;
+    }
+}
+
+size_t mh_chain_lds_bytes(int n, int n_prop, int wpb)
+{
+    return sizeof(double) * ((size_t)n * 64 + (size_t)wpb * (4 * 64 + 2 * (size_t)n_prop));
+}
+
+hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const double* Fp,
+                           const int32_t* sched, int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed,
+                           double* trace_alpha, int8_t* trace_accept, hipStream_t st)
+{
+    if (n_steps <= 0) return hipSuccess;
+    if (M.batch >= 1024) {
+        constexpr int WPB = 4;
+        const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB);
+        hipLaunchKernelGGL(k_mh_chain<WPB>, dim3((unsigned)((M.batch + WPB - 1) / WPB)), dim3(64 * WPB), sh, st, M, V, T, P, Fp, sched,
+                           n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept);
+    } else {
+        constexpr int WPB = 1;
+        const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB);
+        hipLaunchKernelGGL(k_mh_chain<WPB>, dim3((unsigned)M.batch), dim3(64), sh, st, M, V, T, P, Fp, sched, n_steps, S, accumulate,
+                           step0, seed, trace_alpha, trace_accept);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mcd

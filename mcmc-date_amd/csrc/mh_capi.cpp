@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -43,6 +44,8 @@ struct mcd_mh {
     uint64_t seed = 0, step = 0;
     int64_t n_samples = 0;
     bool have_state = false;
+    bool chain_kernel = false;   // n_nodes <= 64: whole schedule in one launch
+    const double* d_Fp = nullptr;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
     int32_t* d_sched = nullptr;
@@ -112,7 +115,8 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     std::unique_ptr<mcd_mh> m(new mcd_mh());
     int dev_t = 0, dev_p = 0;
     const int32_t* parent = nullptr;
-    if (mcd_tree_internal_(tree, &m->mvn, &m->tree, &dev_t, &parent) || mcd_prior_internal_(prior, &m->prior, &dev_p))
+    const double* host_L = nullptr;
+    if (mcd_tree_internal_(tree, &m->mvn, &m->tree, &dev_t, &parent, &host_L) || mcd_prior_internal_(prior, &m->prior, &dev_p))
         return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: invalid handle");
     if (dev_t != dev_p) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree (device %d) and prior (device %d) live on different GPUs", dev_t, dev_p);
     const int n = m->tree->n_nodes;
@@ -179,6 +183,19 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
         (rc = dev_alloc(m.get(), &D.tried, BP, true)) || (rc = dev_alloc(m.get(), &D.age_sum, BN, true)) ||
         (rc = dev_alloc(m.get(), &D.age_sq, BN, true)))
         return rc;
+    // trees of at most 64 nodes: the whole schedule runs in one launch with the factor staged in LDS (k_mh_chain.hip).
+    // MCD_MH_PER_PHASE=1 (diagnostic) keeps the one-launch-per-phase path that larger trees use.
+    const char* per_phase = getenv("MCD_MH_PER_PHASE");
+    const int nd = m->mvn->n;
+    if (n <= 64 && !(per_phase && per_phase[0] == '1') && mcd::mh_chain_lds_bytes(nd, n_prop, 4) <= 64 * 1024) {
+        std::vector<double> Fp((size_t)nd * 64, 0.0);
+        for (int i = 0; i < nd; ++i) {
+            const double inv = 1.0 / host_L[(size_t)i * nd + i];
+            for (int j = 0; j < i; ++j) Fp[(size_t)j * 64 + i] = host_L[(size_t)i * nd + j] * inv;
+        }
+        if ((rc = dev_upload(m.get(), &m->d_Fp, Fp.data(), Fp.size()))) return rc;
+        m->chain_kernel = true;
+    }
     {
         std::vector<double> ones(BP, 1.0);
         MHIP_TRY(hipMemcpy(D.tune, ones.data(), sizeof(double) * BP, hipMemcpyHostToDevice));
@@ -277,7 +294,13 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         MHIP_TRY(hipMalloc((void**)&m->d_trace_accept, steps * B));
         m->trace_cap = steps * B;
     }
-    for (int64_t it = 0; it < n_iter; ++it) {
+    if (m->chain_kernel) {
+        MHIP_TRY(mcd::launch_mh_chain(D, *m->mvn, *m->tree, *m->prior, m->d_Fp, m->d_sched, (int64_t)steps, S, accumulate, m->step, m->seed,
+                                      trace ? m->d_trace_alpha : nullptr, trace ? m->d_trace_accept : nullptr, m->stream));
+        m->step += steps;
+        if (accumulate) m->n_samples += n_iter;
+    }
+    for (int64_t it = 0; it < (m->chain_kernel ? 0 : n_iter); ++it) {
         for (int s = 0; s < S; ++s) {
             const int64_t gs = it * S + s;
             MHIP_TRY(mcd::launch_mh_propose(D, m->d_sched, gs, m->step, m->seed, m->stream));

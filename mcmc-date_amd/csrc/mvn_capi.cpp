@@ -150,13 +150,15 @@ extern "C" int mcd_set_last_error_(int code, const char* msg)
     return code;
 }
 
-int mcd_tree_internal_(const mcd_tree* t, const mcd::MvnDev** mvn, const mcd::TreeDev** tree, int* device, const int32_t** host_parent)
+int mcd_tree_internal_(const mcd_tree* t, const mcd::MvnDev** mvn, const mcd::TreeDev** tree, int* device, const int32_t** host_parent,
+                       const double** host_L)
 {
     if (!t || !t->mvn) return MCD_ERR_INVALID_ARG;
     *mvn = &t->mvn->dev;
     *tree = &t->dev;
     *device = t->mvn->device;
     *host_parent = t->parent.data();
+    *host_L = t->mvn->L.data();
     return MCD_OK;
 }
 

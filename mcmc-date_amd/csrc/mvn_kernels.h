@@ -89,11 +89,17 @@ hipError_t launch_mh_accept(const MhDev& M, const int32_t* sched, int64_t sched_
                             double* trace_alpha, int8_t* trace_accept, hipStream_t st);
 hipError_t launch_mh_accumulate(const MhDev& M, hipStream_t st);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
+// whole schedule in one launch (k_mh_chain.hip); needs n_nodes <= 64 and mh_chain_lds_bytes(...) <= 64 KB
+size_t mh_chain_lds_bytes(int n, int n_prop, int wpb);
+hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const double* Fp,
+                           const int32_t* sched, int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed,
+                           double* trace_alpha, int8_t* trace_accept, hipStream_t st);
 
 }  // namespace mcd
 
 // handle internals shared between the translation units of the C ABI (mvn_capi.cpp, prior_capi.cpp, mh_capi.cpp)
 struct mcd_tree;
 struct mcd_prior;
-int mcd_tree_internal_(const mcd_tree* t, const mcd::MvnDev** mvn, const mcd::TreeDev** tree, int* device, const int32_t** host_parent);
+int mcd_tree_internal_(const mcd_tree* t, const mcd::MvnDev** mvn, const mcd::TreeDev** tree, int* device, const int32_t** host_parent,
+                       const double** host_L);
 int mcd_prior_internal_(const mcd_prior* p, const mcd::PriorDev** prior, int* device);

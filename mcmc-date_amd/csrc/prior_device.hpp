@@ -1,0 +1,191 @@
+// prior_device.hpp -- wave-level evaluation of McmcDate's log prior (shared by k_prior.hip and k_mh_chain.hip).
+//
+// priorFunction ht md cb cs bs x  (app/Probability.hs:127-150); see k_prior.hip for the mapping and the citations of
+// every factor.  `h` and `r` may point to global memory or LDS (generic pointers): node heights and branch rates of
+// ONE chain.  All 64 lanes of the calling wave must be active; every lane returns the same value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mvn_kernels.h"
+
+namespace mcd {
+
+
+__device__ __forceinline__ double pr_readlane64(double v, int l)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double pr_dpp64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pr_wave_sum(double v)
+{
+    v += pr_dpp64<0xB1>(v);
+    v += pr_dpp64<0x4E>(v);
+    v += pr_dpp64<0x124>(v);
+    v += pr_dpp64<0x128>(v);
+    return (pr_readlane64(v, 0) + pr_readlane64(v, 16)) + (pr_readlane64(v, 32) + pr_readlane64(v, 48));
+}
+
+constexpr double kLnSqrt2Pi = 0.9189385332046727417803297364056176;
+constexpr double kNegInf = -__builtin_huge_val();
+
+// [third party: mcmc, Mcmc.Prior] exponential / gamma densities, log domain
+__device__ __forceinline__ double ln_exponential(double l, double x) { return (x < 0) ? kNegInf : log(l) + (-l * x); }
+__device__ __forceinline__ double ln_gamma_pdf(double k, double t, double x)
+{
+    return (x <= 0) ? kNegInf : log(x) * (k - 1.0) - (x / t) - lgamma(k) - log(t) * k;
+}
+// d x / d 0 for d = normal 0 s  (Calibration.hs:391, Constraint.hs:414, Brace.hs:226-230)
+__device__ __forceinline__ double ln_normal_ratio(double s, double x)
+{
+    const double q = x / s;
+    return -0.5 * q * q;
+}
+// logNormal' m v x -- Prior/Branch/RelaxedClock.hs:141-150
+__device__ __forceinline__ double ln_lognormal_prime(double m, double v, double x)
+{
+    if (x <= 0) return kNegInf;
+    const double t = -(kLnSqrt2Pi + log(x * sqrt(v)));
+    const double a = 1.0 / (2 * v);
+    const double b = log(x / m) + 0.5 * v;
+    return t + (-(a * b * b));
+}
+// computeDE / computeDENearCritical -- Prior/BirthDeath.hs:53-79, 90-114
+__device__ __forceinline__ void compute_de(bool near, double la, double mu, double rho, double dt, double e0, double& pD,
+                                           double& pE)
+{
+    const double d = la - mu;
+    const double c = (1 - rho) + rho * e0;
+    if (near) {
+        const double y = (mu - c * la) * dt;
+        const double denom = 1 + y;
+        pD = (1 - d * dt) / denom / denom;
+        pE = (c + y) / denom;
+    } else {
+        const double x = exp(-d * dt);
+        const double y = (mu - c * la) * x;
+        const double c1 = c - 1;
+        const double denom = la * c1 + y;
+        pD = d * d * x / denom / denom;
+        pE = (mu * c1 + y) / denom;
+    }
+}
+
+// ln prior of one chain; comp3 (may be null, lane-uniform pointer): node priors, birth-death block, clock block
+__device__ __forceinline__ double prior_eval_wave(const PriorDev& P, int lane, double la, double mu, double th, double rm,
+                                                  double va, const double* h, const double* r, double* c_out)
+{
+    const bool near = 1e-6 > fabs(la - mu);                    // epsNearCritical, BirthDeath.hs:117-118
+
+    // ---- per-node terms: birth-death D factors and relaxed-clock branch densities ------------------
+    double bd = 0.0, clock = 0.0;
+    for (int v = 1 + lane; v < P.n_nodes; v += 64) {
+        const int pv = P.parent[v];
+        const double br = h[pv] - h[v];                        // heightTreeToLengthTree
+        // E at the bottom of v's branch
+        double e_bottom = 0.0;
+        const int nc = P.n_children[v];
+        if (nc > 0 && !near) {
+            const double xx = exp(-(la - mu) * h[v]);
+            e_bottom = mu * (1.0 - xx) / (la - mu * xx);
+        } else if (nc > 0) {   // near-critical: compose branch by branch like the reference, tip first
+            int u = P.first_child[v];
+            int depth = 1;
+            while (P.n_children[u] > 0) { u = P.first_child[u]; ++depth; }
+            double e = 0.0;                                    // below a tip: E = 0 with the tip's sampling rate
+            for (int i = 0; i < depth; ++i) {                  // u climbs from the tip to first_child[v]
+                const double bu = h[P.parent[u]] - h[u];
+                if (bu <= 0) {
+                    e = 1.0;                                   // `| br <= 0 = (0.0, 1.0)`
+                } else {
+                    double dd, ee;
+                    compute_de(near, la, mu, 1.0, bu, e, dd, ee);   // rho = 1 everywhere in priorFunctionBirthDeath
+                    e = ee;
+                }
+                u = P.parent[u];
+            }
+            e_bottom = e;
+        }
+        if (br <= 0) {
+            bd += kNegInf;
+        } else {
+            double dT, eT;
+            compute_de(near, la, mu, 1.0, br, e_bottom, dT, eT);
+            bd += log(dT * ((nc == 2) ? la : 1.0));            // internal node: dT * la; tip / unary: dT * rho, rho = 1
+        }
+        // relaxed molecular clock, branchesWith WithoutStem (Prior/Branch.hs:23-25)
+        const double rate = r[v];
+        double term;
+        switch (P.clock_model) {
+            case 0: term = ln_gamma_pdf(1.0 / va, va, rate); break;                       // uncorrelatedGamma 1.0 va
+            case 1: term = ln_lognormal_prime(1.0, va, rate); break;                      // uncorrelatedLogNormal
+            case 2: { const double v2 = va / br; term = ln_gamma_pdf(1.0 / v2, v2, rate); } break;   // white noise
+            default: term = ln_lognormal_prime(1.0, va * br, rate); break;                // autocorrelatedLogNormal
+        }
+        clock += term;
+    }
+    // ---- soft node priors ------------------------------------------------------------------------
+    double node = 0.0;
+    const double x = 1.0 / th;                                 // transformInterval (recip h), Calibration.hs:426-430
+    for (int i = lane; i < P.n_cal; i += 64) {
+        const double hv = h[P.cal_node[i]];
+        double t = 0.0;
+        if (hv < 0) {
+            t = kNegInf;
+        } else {
+            if (P.cal_has_lo[i]) {
+                const double a = (th == 1) ? P.cal_lo[i] : x * P.cal_lo[i];
+                if (hv < a) t += ln_normal_ratio(0.7978845608028654 * P.cal_lo_p[i], a - hv);
+            }
+            if (P.cal_has_hi[i]) {
+                const double bb = (th == 1) ? P.cal_hi[i] : x * P.cal_hi[i];
+                if (hv > bb) t += ln_normal_ratio(0.7978845608028654 * P.cal_hi_p[i], hv - bb);
+            }
+        }
+        node += t;
+    }
+    for (int i = lane; i < P.n_con; i += 64) {
+        const double hy = h[P.con_young[i]], ho = h[P.con_old[i]];
+        if (!(hy < ho)) node += ln_normal_ratio(0.7978845608028654 * P.con_p[i], hy - ho);
+    }
+    for (int i = lane; i < P.n_brace; i += 64) {
+        const int lo = P.brace_ptr[i], hi = P.brace_ptr[i + 1];
+        const double h0 = h[P.brace_nodes[lo]];
+        bool all_equal = true;
+        double sum = 0.0;
+        for (int j = lo; j < hi; ++j) {
+            const double hj = h[P.brace_nodes[j]];
+            all_equal = all_equal && (hj == h0);
+            sum += hj;
+        }
+        if (!all_equal) {
+            const double mean = sum / (double)(hi - lo);
+            for (int j = lo; j < hi; ++j) node += ln_normal_ratio(P.brace_sd[i], h[P.brace_nodes[j]] - mean);
+        }
+    }
+    double c0 = pr_wave_sum(node), c1 = pr_wave_sum(bd), c2 = pr_wave_sum(clock);
+    if (th <= 0) c0 = kNegInf;                                 // Combined.hs:78
+    if (va <= 0) c2 = __builtin_nan("");                       // the reference calls `error` (variance <= 0)
+    if (la < 0 || mu < 0) c1 = __builtin_nan("");              // birthDeath: `error` on negative rates
+    c1 += ln_exponential(1.0, la) + ln_exponential(1.0, mu);   // app/Probability.hs:72-73
+    c2 += ln_exponential(P.ht, rm) + ln_gamma_pdf(1.5, 1.0 / 6.0, va);   // :105-111
+    if (c_out) {
+        c_out[0] = c0;
+        c_out[1] = c1;
+        c_out[2] = c2;
+    }
+    return c0 + c1 + c2;
+}
+
+}  // namespace mcd

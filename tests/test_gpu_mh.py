@@ -96,6 +96,57 @@ def test_lockstep_parity_other_clock_models(gpu, golden, model):
     compare_states(smp, twin)
 
 
+def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
+    """Trees of at most 64 nodes run the whole schedule in one launch (k_mh_chain.hip); larger trees use one launch
+    per phase (k_mh.hip + k_prior.hip + k_tree_logpdf.hip).  Same arithmetic in the same order: bit-identical chains."""
+    fx = golden["25-leaves-bastien"]
+    topo, ps, fused, _ = setup(fx, B=12, seed=5)
+    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
+    _, _, phased, _ = setup(fx, B=12, seed=5)
+    monkeypatch.delenv("MCD_MH_PER_PHASE")
+    sched = M.cycle_schedule(ps, 3, np.random.default_rng(8))
+    a1, k1 = fused.run_schedule(sched, accumulate=True, trace=True)
+    a2, k2 = phased.run_schedule(sched, accumulate=True, trace=True)
+    assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2)
+    s1, s2 = fused.state(), phased.state()
+    for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
+        assert np.array_equal(getattr(s1, f), getattr(s2, f))
+    assert np.array_equal(fused.posterior(), phased.posterior())
+    assert all(np.array_equal(x, y) for x, y in zip(fused.tuning(), phased.tuning()))
+    assert all(np.array_equal(x, y) for x, y in zip(fused.age_sums()[:2], phased.age_sums()[:2]))
+
+
+def test_large_tree_uses_the_per_phase_path(gpu):
+    """A synthetic 70-leaf tree (139 nodes, N = 137, three row blocks): lanes stride over the nodes and the likelihood
+    runs through the streaming kernel; parity with the CPU twin as for the small trees."""
+    from mcmc_date_amd import synthetic as S
+
+    topo = S.random_topology(70, seed=3)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=3)
+    sigma_inv = np.linalg.inv(sigma)
+    logdet = float(np.linalg.slogdet(sigma)[1])
+    B = 6
+    s0 = S.random_states(topo, B, seed=4)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    lik = M.MvnLikelihood(M.Full(mu, sigma_inv, logdet)).bind_tree(topo)
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
+    smp = M.Sampler(lik, pf, ps, B, seed=13)
+    smp.set_state(s0)
+    spec = O.PriorSpec(topo.parent, 1.0, "UncorrelatedGamma", [], [], [])
+    twin = O.MhChains(O.MhModel(topo.parent, mu, sigma_inv, logdet, spec, M.table_arrays(ps)), s0.time_birth_rate, s0.time_death_rate,
+                      s0.time_height, s0.heights, s0.rate_mean, s0.rate_variance, s0.rates, seed=13)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :400]
+    tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
+    ta, tk = smp.run_schedule(sched, trace=True)
+    ra, rk = twin.run(sched, trace=True)
+    fin = np.isfinite(ra)
+    assert np.array_equal(np.isfinite(ta), fin) and np.max(np.abs(ta[fin] - ra[fin])) <= tol
+    assert np.array_equal(tk, rk) and 0.02 < tk.mean() < 0.98
+    compare_states(smp, twin, atol_post=tol)
+
+
 def test_chain_streams_do_not_depend_on_the_shard(gpu, golden):
     """Chains 8..15 of a 16-chain run equal an 8-chain shard created with first_chain = 8 (what a second GPU runs)."""
     fx = golden["12-leaves-variable-rate"]
