@@ -172,8 +172,7 @@ int mcd_prior_logprior_batch(const mcd_prior_t* p, const double* birth, const do
  * time, each with its own random numbers, tuning parameter and accept/reject decision.  The state never leaves
  * the device between calls.  A proposal is a row of the table below; the caller builds the table and the
  * per-iteration order (the reference: app/Definitions.hs:127-278 `proposals`, weights replicated and shuffled by
- * `mcmc`).  Kinds built so far (the contrary and braced proposals of lib/Mcmc/Tree/Proposal/{Contrary,Brace}.hs
- * and NUTS are not: DESIGN.md section 9):
+ * `mcmc`).  Every proposal of the reference cycle is a kind below; NUTS (app/Hamiltonian.hs, row f3) is not built.
  * ---------------------------------------------------------------------------------------------- */
 #define MCD_PROP_SCALE_SCALAR 0        /* scaleUnbiased k [mcmc]: node = 0 birth, 1 death, 2 tH, 3 rMu, 4 rVar; p0 = k          */
 #define MCD_PROP_SLIDE_NODE 1          /* slideNodeAtUltrametric (Ultrametric.hs:50-59): node; p0 = sd                          */
@@ -185,6 +184,13 @@ int mcd_prior_logprior_batch(const mcd_prior_t* p, const double* birth, const do
 #define MCD_PROP_SCALE_VAR_TREE 7      /* scaleVarianceAndTree (:286-316): p0 = shape                                            */
 #define MCD_PROP_SCALE_VAR_TREE_AUTO 8 /* scaleVarianceAndTreeAutocorrelated (:354-386): p0 = shape                              */
 #define MCD_PROP_SCALE_CONTRARILY 9    /* scaleContrarily k th [mcmc] on (tH, rMu): p0 = k, p1 = th                              */
+#define MCD_PROP_SLIDE_NODE_CONTRA 10  /* slideNodesAtContrarily (Contrary.hs:35-77): node; p0 = sd                              */
+#define MCD_PROP_SCALE_SUBTREE_CONTRA 11 /* scaleSubTreesAtContrarily (:269-326): node; p0 = sd; n1 = inner nodes, n2 = nodes    */
+#define MCD_PROP_SLIDE_ROOT_CONTRA 12  /* slideRootContrarily (:191-223) on (tH, time tree, rate tree): p0 = sd; n1 = inner nodes */
+#define MCD_PROP_SCALE_RATES_TREE_CONTRA 13 /* scaleRatesAndTreeContrarily (:420-446) on (birth rate, rate mean, time tree):
+                                          p0 = sd; n1 = inner nodes - 1                                                         */
+#define MCD_PROP_SLIDE_BRACE 14        /* slideBracedNodesUltrametric (Brace.hs:98-156): node = brace index of the prior; p0 = sd */
+#define MCD_PROP_SLIDE_BRACE_CONTRA 15 /* slideBracedNodesContrarily (Brace.hs:37-61): node = brace index; p0 = sd                */
 
 typedef struct mcd_mh mcd_mh_t;
 

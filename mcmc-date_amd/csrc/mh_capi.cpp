@@ -123,6 +123,18 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     if (m->prior->n_nodes != n) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree has %d nodes, prior %d", n, m->prior->n_nodes);
     std::vector<int32_t> size(n, 1);
     for (int v = n - 1; v > 0; --v) size[parent[v]] += size[v];
+    // the braces live in the prior's tables (device memory): a host copy for the checks below
+    const int nbr = m->prior->n_brace;
+    std::vector<int32_t> host_brace_ptr(nbr + 1, 0), host_brace_nodes;
+    if (nbr > 0) {
+        int dev_prior = 0;
+        const mcd::PriorDev* pd = nullptr;
+        (void)mcd_prior_internal_(prior, &pd, &dev_prior);
+        MHIP_TRY(hipSetDevice(dev_prior));
+        MHIP_TRY(hipMemcpy(host_brace_ptr.data(), pd->brace_ptr, sizeof(int32_t) * (nbr + 1), hipMemcpyDeviceToHost));
+        host_brace_nodes.resize(host_brace_ptr[nbr]);
+        MHIP_TRY(hipMemcpy(host_brace_nodes.data(), pd->brace_nodes, sizeof(int32_t) * host_brace_nodes.size(), hipMemcpyDeviceToHost));
+    }
     // proposal table checks: the reference raises `error` for a path to a leaf / an invalid path when the proposal is built
     const int root_right = 1 + size[1];
     for (int i = 0; i < n_prop; ++i) {
@@ -149,6 +161,22 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
             case MCD_PROP_SCALE_SUBTREE_RATE:
                 if (v < 1 || v >= n) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: node %d out of range", i, v);
                 break;
+            case MCD_PROP_SLIDE_NODE_CONTRA:
+            case MCD_PROP_SCALE_SUBTREE_CONTRA:
+                if (v < 1 || v >= n) return mfail(MCD_ERR_INVALID_ARG, "slideNodesAtContrarily: Path is invalid (proposal %d, node %d).", i, v);
+                if (size[v] == 1) return mfail(MCD_ERR_INVALID_ARG, "slideNodesAtContrarily: Path leads to a leaf (proposal %d, node %d).", i, v);
+                break;
+            case MCD_PROP_SLIDE_BRACE:
+            case MCD_PROP_SLIDE_BRACE_CONTRA:
+                if (v < 0 || v >= m->prior->n_brace) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: proposal %d: the prior has no brace %d", i, v);
+                for (int j = host_brace_ptr[v]; j < host_brace_ptr[v + 1]; ++j) {
+                    const int x = host_brace_nodes[j];
+                    if (x == 0) return mfail(MCD_ERR_INVALID_ARG, "slideBracedNodesUltrametric: Braced root node (proposal %d).", i);
+                    if (size[x] == 1) return mfail(MCD_ERR_INVALID_ARG, "slideBracedNodesUltrametric: Path of a node leads to a leaf (proposal %d).", i);
+                }
+                break;
+            case MCD_PROP_SLIDE_ROOT_CONTRA:
+            case MCD_PROP_SCALE_RATES_TREE_CONTRA:
             case MCD_PROP_SCALE_VAR_TREE:
             case MCD_PROP_SCALE_VAR_TREE_AUTO: break;
             case MCD_PROP_SCALE_CONTRARILY:
@@ -168,6 +196,9 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     D.ld = (n + 7) / 8 * 8;
     D.chain0 = 0;
     D.parent = m->tree->parent;
+    D.brace_ptr = m->prior->brace_ptr;
+    D.brace_nodes = m->prior->brace_nodes;
+    D.n_brace = nbr;
     int rc = MCD_OK;
     const size_t B = (size_t)batch, BL = B * (size_t)D.ld, BP = B * (size_t)n_prop, BN = B * (size_t)n;
     if ((rc = dev_upload(m.get(), &D.size, size.data(), (size_t)n)) || (rc = dev_upload(m.get(), &D.kind, kind, (size_t)n_prop)) ||

@@ -124,7 +124,11 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
     double hmul = 1.0, hmul2 = 1.0, rmul = 1.0, radd = 0.0;
     int pt1 = -1, pt2 = -1;
     double pv1 = 0.0, pv2 = 0.0;
-    bool rate_positive_guard = false;
+    bool rate_positive_guard = false, h_divide = false;
+    int rp1 = -1, rp2 = -1, rp3 = -1;          // single branches whose rate is multiplied (children, then the stem)
+    double rm1 = 1.0, rm2 = 1.0, rm3 = 1.0;
+    int brace_lo = 0, brace_hi = 0;
+    double brace_delta = 0.0;
     switch (kind) {
         case MCD_PROP_SCALE_SCALAR: {
             const double k = p0 / t, th = t / p0, u = gamma_sample(g, k, th);
@@ -234,11 +238,108 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             lnj = -2.0 * log(u);
             break;
         }
+        case MCD_PROP_SLIDE_NODE_CONTRA: {   // Contrary.hs:35-77
+            double hc = -__builtin_huge_val();
+            const int end = v + M.size[v];
+            for (int c = v + 1; c < end; c += M.size[c]) hc = fmax(hc, H[c]);
+            const double hN = H[v], hP = H[M.parent[v]];
+            double ua, ub, h1;
+            philox_block(g, 0, ua, ub);
+            tn_sample(hN, p0, t, hc, hP, ua, h1, lnq);
+            pt1 = v;
+            pv1 = h1;
+            const double xiStem = (hP - hN) / (hP - h1);
+            double sumlog = 0.0;
+            int k = 0;
+            for (int c = v + 1; c < end; c += M.size[c], ++k) {
+                const double xi = (hN - H[c]) / (h1 - H[c]);
+                sumlog += log(xi);
+                if (k == 0) { rp1 = c; rm1 = xi; } else { rp2 = c; rm2 = xi; }
+            }
+            rp3 = v;
+            rm3 = xiStem;
+            lnj = sumlog + log(xiStem);
+            break;
+        }
+        case MCD_PROP_SCALE_SUBTREE_CONTRA: {   // Contrary.hs:269-326
+            const double hN = H[v], hP = H[M.parent[v]];
+            double ua, ub, h1;
+            philox_block(g, 0, ua, ub);
+            tn_sample(hN, p0, t, 0.0, hP, ua, h1, lnq);
+            const double xiT = h1 / hN, xiR = 1.0 / xiT, xiStem = (hP - hN) / (hP - h1);
+            hlo = v + 1; hhi = v + M.size[v]; hmul = xiT; pt1 = v; pv1 = h1;
+            rlo = v + 1; rhi = v + M.size[v]; rmul = xiR;
+            rp3 = v;
+            rm3 = xiStem;
+            lnj = (double)(M.n1[p] - M.n2[p]) * log(xiT) + log(xiStem);
+            break;
+        }
+        case MCD_PROP_SLIDE_ROOT_CONTRA: {   // Contrary.hs:191-223
+            if (fabs(H[0] - 1.0) > 1e-14) {
+                lnq = __builtin_nan("");
+                break;
+            }
+            const int l = 1, r = 1 + M.size[1];
+            const double ht = sc[2], hL = H[l], hR = H[r];
+            double ua, ub, ht1;
+            philox_block(g, 0, ua, ub);
+            tn_sample(ht, p0, t, ht * fmax(hL, hR), __builtin_huge_val(), ua, ht1, lnq);
+            const double u = ht1 / ht;
+            const double xil = (1.0 - hL) / (u - hL), xir = (1.0 - hR) / (u - hR);
+            hlo = 1; hhi = n; hmul = u; h_divide = true;
+            rp1 = l; rm1 = xil; rp2 = r; rm2 = xir;
+            sc[2] = ht1;
+            lnj = (double)(-M.n1[p]) * log(u) + log(xil) + log(xir);
+            break;
+        }
+        case MCD_PROP_SCALE_RATES_TREE_CONTRA: {   // Contrary.hs:420-446 on (timeBirthRate, rateMean, timeTree)
+            const int l = 1, r = 1 + M.size[1];
+            const double m = fmax(H[l], H[r]);
+            double ua, ub, m1;
+            philox_block(g, 0, ua, ub);
+            tn_sample(m, p0, t, 0.0, H[0], ua, m1, lnq);
+            const double xi = m1 / m;
+            hlo = 1; hhi = n; hmul = xi;
+            sc[0] = sc[0] / xi;
+            sc[3] = sc[3] / xi;
+            lnj = (double)(M.n1[p] - 1 - 2) * log(xi);
+            break;
+        }
+        case MCD_PROP_SLIDE_BRACE:
+        case MCD_PROP_SLIDE_BRACE_CONTRA: {   // Brace.hs:98-156, 37-61; the per-node updates are part of the copy loop below
+            const int lo = M.brace_ptr[v], hi = M.brace_ptr[v + 1];
+            double a = -__builtin_huge_val(), bb = __builtin_huge_val();
+            for (int i = lo; i < hi; ++i) {
+                const int x = M.brace_nodes[i];
+                double hc = -__builtin_huge_val();
+                const int end = x + M.size[x];
+                for (int c = x + 1; c < end; c += M.size[c]) hc = fmax(hc, H[c]);
+                a = fmax(a, hc - H[x]);
+                bb = fmin(bb, H[M.parent[x]] - H[x]);
+            }
+            double ua, ub;
+            philox_block(g, 0, ua, ub);
+            tn_sample(0.0, p0, t, a, bb, ua, brace_delta, lnq);
+            brace_lo = lo;
+            brace_hi = hi;
+            if (kind == MCD_PROP_SLIDE_BRACE_CONTRA) {
+                double sumlog = 0.0;
+                for (int i = lo; i < hi; ++i) {
+                    const int x = M.brace_nodes[i];
+                    const double hN = H[x], hP = H[M.parent[x]];
+                    sumlog += log((hP - hN) / (hP - hN - brace_delta));
+                    const int end = x + M.size[x];
+                    for (int c = x + 1; c < end; c += M.size[c]) sumlog += log((hN - H[c]) / (hN + brace_delta - H[c]));
+                }
+                lnj = sumlog;
+            }
+            break;
+        }
         default: lnq = __builtin_nan("");
     }
     for (int w = lane; w < n; w += 64) {
         double h = H[w], r = R[w];
-        if (w >= hlo && w < hhi) h *= hmul;
+        if (w >= hlo && w < hhi) h = h_divide ? h / hmul : h * hmul;
         if (w >= hlo2 && w < hhi2) h *= hmul2;
         if (w == pt1) h = pv1;
         if (w == pt2) h = pv2;
@@ -249,6 +350,21 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             } else {
                 r *= rmul;
             }
+        }
+        if (w == rp1) r *= rm1;
+        if (w == rp2) r *= rm2;
+        if (w == rp3) r *= rm3;
+        for (int i = brace_lo; i < brace_hi; ++i) {      // braced nodes: w is one of them and / or a daughter of one
+            const int x = M.brace_nodes[i];
+            const double hN = H[x];
+            if (w == x) {
+                h = hN + brace_delta;
+                if (kind == MCD_PROP_SLIDE_BRACE_CONTRA) {
+                    const double hP = H[M.parent[x]];
+                    r *= (hP - hN) / (hP - hN - brace_delta);
+                }
+            }
+            if (kind == MCD_PROP_SLIDE_BRACE_CONTRA && M.parent[w] == x) r *= (hN - H[w]) / (hN + brace_delta - H[w]);
         }
         H1[w] = h;
         R1[w] = r;

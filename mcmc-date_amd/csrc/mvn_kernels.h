@@ -58,6 +58,8 @@ struct MhDev {
     const int32_t* size;     // [n_nodes] nodes in the sub tree of v (pre-order: the range [v, v + size[v]))
     const int32_t *kind, *node, *n1, *n2, *jac_root, *dim;   // [n_prop] proposal table (MCD_PROP_*)
     const double *p0, *p1;
+    const int32_t *brace_ptr, *brace_nodes;                  // CSR of the braces (shared with the prior tables)
+    int n_brace;
     double *sc, *H, *R;        // current state: scalars [5][batch] (birth, death, tH, rMu, rVar), heights/rates [batch][ld]
     double *sc1, *H1, *R1;     // proposed state
     double *post, *post1;      // [3][batch] ln prior, ln likelihood, ln jacobianRootBranch (current, proposed)

@@ -7,9 +7,9 @@ helper lists :145-253), the burn-in schedule with auto tuning (`burnIn`, :420-42
 (include/mcmcdate_mvn.h): every chain executes the same proposal of the (shuffled) cycle at the same time with its
 own random numbers, tuning parameter and accept/reject decision.  There is no CPU path.
 
-Built so far: every proposal of the reference cycle except the contrary time/rate proposals of
-lib/Mcmc/Tree/Proposal/Contrary.hs, the braced-node proposals of .../Brace.hs and NUTS; `proposals()` returns the
-names of the ones it leaves out so that nothing is skipped silently.
+Built: every proposal of the reference's Metropolis-Hastings cycle (`proposals bs calibrationsAvailable x Nothing`).
+NUTS (`Just htarget`, app/Hamiltonian.hs) is not; `proposals()` returns the names of what it
+leaves out (an empty list for the default cycle) so that nothing is skipped silently.
 """
 from __future__ import annotations
 
@@ -27,7 +27,8 @@ from .state import State, StateBatch
 from .tree import Topology
 
 SCALE_SCALAR, SLIDE_NODE, SCALE_SUBTREE_TIME, PULLEY, SCALE_BRANCH_RATE, SCALE_SUBTREE_RATE, SCALE_NORM_TREE, \
-    SCALE_VAR_TREE, SCALE_VAR_TREE_AUTO, SCALE_CONTRARILY = range(10)
+    SCALE_VAR_TREE, SCALE_VAR_TREE_AUTO, SCALE_CONTRARILY, SLIDE_NODE_CONTRA, SCALE_SUBTREE_CONTRA, SLIDE_ROOT_CONTRA, \
+    SCALE_RATES_TREE_CONTRA, SLIDE_BRACE, SLIDE_BRACE_CONTRA = range(16)
 BIRTH, DEATH, TIME_HEIGHT, RATE_MEAN, RATE_VARIANCE = range(5)
 
 
@@ -105,7 +106,10 @@ def proposals(topo: Topology, braces: Sequence = (), calibrations_available: boo
     ps.append(Proposal("Time death rate", SCALE_SCALAR, DEATH, 10.0, weight=w))
     ps.append(Proposal("Rate mean", SCALE_SCALAR, RATE_MEAN, 10.0, weight=w))
     ps.append(Proposal("Rate variance", SCALE_SCALAR, RATE_VARIANCE, 10.0, weight=w))
-    missing.append("Rates and time tree (scaleRatesAndTreeContrarily, Contrary.hs:420-446)")
+    n_inner = int(inner[0])
+    if n_inner - 1 < 1:
+        raise ValueError("scaleRatesAndTreeContrarilyPFunction: no internal nodes to scale")     # Contrary.hs:427
+    ps.append(Proposal("Rates and time tree", SCALE_RATES_TREE_CONTRA, 0, 0.1, n1=n_inner - 1, jac_root=True, dim=n_inner - 1 + 2, weight=w))
 
     children_of_root = lambda v: plen[v] == 1      # :133-134
     other_nodes = lambda v: plen[v] > 1            # :137-138
@@ -124,8 +128,8 @@ def proposals(topo: Topology, braces: Sequence = (), calibrations_available: boo
                            dim=int(inner[l] + inner[r]), weight=6))
     ps += time_ps(children_of_root, "[R]", True)
     ps += time_ps(other_nodes, "[O]", False)
-    for i, _ in enumerate(braces):
-        missing.append(f"[B] Time tree brace {i} (slideBracedNodesUltrametric, Brace.hs:98-156)")
+    for i, b in enumerate(braces):
+        ps.append(Proposal(f"[B] Time tree {b.name}", SLIDE_BRACE, i, 0.01, dim=len(b.nodes), weight=5))
 
     # proposalsRateTree, :180-201
     ps.append(Proposal("[R] Rate mean, Rate tree", SCALE_NORM_TREE, RATE_MEAN, 100.0, jac_root=True, dim=n, weight=w))
@@ -143,16 +147,25 @@ def proposals(topo: Topology, braces: Sequence = (), calibrations_available: boo
     ps += rate_ps(other_nodes, "[O]", False)
 
     # proposalsTimeRateTreeContra, :204-221
-    missing.append("[C] Trees (slideNodesContrarily / scaleSubTreesContrarily, Contrary.hs:35-77, 269-326)")
-    for i, _ in enumerate(braces):
-        missing.append(f"[C] [B] Trees brace {i} (slideBracedNodesContrarily, Brace.hs:37-61)")
+    def contra_ps(hn, tag, jac):
+        out = [Proposal(f"{tag} Trees node {v}", SLIDE_NODE_CONTRA, v, 0.1, jac_root=jac, dim=1 + 1 + len(topo.children(v)), weight=sub_w(v))
+               for v in range(n) if not leaf[v] and hn(v)]
+        out += [Proposal(f"{tag} Trees node {v}", SCALE_SUBTREE_CONTRA, v, 0.1, n1=int(inner[v]), n2=int(size[v]), jac_root=jac,
+                         dim=int(inner[v] + size[v]), weight=sub_w(v)) for v in range(n) if not leaf[v] and hn(v)]
+        return out
+
+    ps += contra_ps(children_of_root, "[C] [R]", True)
+    ps += contra_ps(other_nodes, "[C] [O]", False)
+    for i, b in enumerate(braces):
+        n_daughters = sum(len(topo.children(x)) for x in b.nodes)
+        ps.append(Proposal(f"[C] [B] Trees {b.name}", SLIDE_BRACE_CONTRA, i, 0.1, dim=2 * len(b.nodes) + n_daughters, weight=5))
 
     # proposalsChangingTimeHeight, :241-253
     if calibrations_available:
         ps.append(Proposal("Time height", SCALE_SCALAR, TIME_HEIGHT, 3000.0, weight=w))
         ps.append(Proposal("Time height, rate mean", SCALE_CONTRARILY, 0, 10.0, 0.1, dim=2, weight=w))
         ps.append(Proposal("[R] Time height, Rate tree", SCALE_NORM_TREE, TIME_HEIGHT, 100.0, jac_root=True, dim=n, weight=w))
-        missing.append("[R] Trees (slideRootContrarily, Contrary.hs:191-223)")
+        ps.append(Proposal("[R] Trees", SLIDE_ROOT_CONTRA, 0, 10.0, n1=n_inner, jac_root=True, dim=1 + n_inner + 2, weight=w))
     return ps, missing
 
 

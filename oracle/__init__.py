@@ -53,6 +53,8 @@ def lib(native: bool = False):
     newest = max(os.path.getmtime(p) for p in (src, src2, src3) if os.path.exists(p))
     if not os.path.exists(path) or newest > os.path.getmtime(path):
         build(native)
+    # mh_oracle.c runs chains under OpenMP; a GPU box shows every host core but grants a share of about 16
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     L = C.CDLL(path)
     L.orc_logpdf_full.restype = C.c_double
     L.orc_logpdf_full.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp]

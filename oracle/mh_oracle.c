@@ -6,7 +6,9 @@
  * What it restates, one chain at a time and strictly sequentially:
  *   - the proposals of lib/Mcmc/Tree/Proposal/Ultrametric.hs (slide node :50-59, scale sub tree :126-149,
  *     pulley :221-286) and Unconstrained.hs (scaleTree :95-106, scaleNormAndTreeContrarily :221-256,
- *     scaleVarianceAndTree :286-316, scaleVarianceAndTreeAutocorrelated :354-386);
+ *     scaleVarianceAndTree :286-316, scaleVarianceAndTreeAutocorrelated :354-386), Contrary.hs (slide nodes
+ *     contrarily, slide root contrarily, scale sub tree contrarily, scale rates and tree contrarily) and Brace.hs
+ *     (slide braced nodes, ultrametric and contrarily);
  *   - truncatedNormalSample (lib/Mcmc/Tree/Proposal/Internal.hs:107-138) over
  *     lib/Statistics/Distribution/TruncatedNormal.hs:55-130 (density, quantile);
  *   - the generic gamma-multiplier proposals `scaleUnbiased k` and `scaleContrarily k th` and the MHG acceptance
@@ -54,7 +56,13 @@ enum {
     ORM_SCALE_NORM_TREE = 6,     /* node = which scalar (2 tH or 3 rMu); p0 = shape                                 */
     ORM_SCALE_VAR_TREE = 7,      /* p0 = shape                                                                      */
     ORM_SCALE_VAR_TREE_AUTO = 8, /* p0 = shape                                                                      */
-    ORM_SCALE_CONTRARILY = 9     /* (tH, rMu); p0 = shape k, p1 = scale th                                          */
+    ORM_SCALE_CONTRARILY = 9,    /* (tH, rMu); p0 = shape k, p1 = scale th                                          */
+    ORM_SLIDE_NODE_CONTRA = 10,  /* node; p0 = sd                                   Contrary.hs:35-77               */
+    ORM_SCALE_SUBTREE_CONTRA = 11, /* node; p0 = sd; n1 = inner nodes, n2 = nodes of the sub tree   :269-326           */
+    ORM_SLIDE_ROOT_CONTRA = 12,  /* p0 = sd; n1 = inner nodes of the tree           :191-223                        */
+    ORM_SCALE_RATES_TREE_CONTRA = 13, /* p0 = sd; n1 = inner nodes - 1 (birth rate, rate mean, time tree)  :420-446    */
+    ORM_SLIDE_BRACE = 14,        /* node = brace index; p0 = sd                     Brace.hs:98-156 (ultrametric)   */
+    ORM_SLIDE_BRACE_CONTRA = 15  /* node = brace index; p0 = sd                     Brace.hs:37-61 ... contrarily   */
 };
 
 typedef struct {
@@ -344,6 +352,104 @@ static void propose(const orm_model *M, const int32_t *size, int p, double t, co
             y->sc[3] = cur->sc[3] / u;
             *lnq = gamma_ratio(k, th, u);
             *lnj = -2.0 * log(u);
+            break;
+        }
+        case ORM_SLIDE_NODE_CONTRA: {   /* Contrary.hs:35-77 (the root is never handled: `hn` excludes the empty path) */
+            double hc = -INFINITY, ub[2], h1;
+            for (int w = v + 1; w < v + size[v]; ++w)
+                if (M->parent[w] == v && cur->H[w] > hc) hc = cur->H[w];
+            const double hN = cur->H[v], hP = cur->H[M->parent[v]];
+            rng_block(g, 0, ub);
+            tn_sample(hN, p0, t, hc, hP, ub[0], &h1, lnq);
+            y->H[v] = h1;
+            const double xiStem = (hP - hN) / (hP - h1);
+            double sumlog = 0.0;
+            for (int w = v + 1; w < v + size[v]; ++w)
+                if (M->parent[w] == v) {
+                    const double xi = (hN - cur->H[w]) / (h1 - cur->H[w]);
+                    y->R[w] = cur->R[w] * xi;
+                    sumlog += log(xi);
+                }
+            y->R[v] = cur->R[v] * xiStem;
+            *lnj = sumlog + log(xiStem);
+            break;
+        }
+        case ORM_SCALE_SUBTREE_CONTRA: {   /* Contrary.hs:269-326 */
+            double ub[2], h1;
+            const double hN = cur->H[v], hP = cur->H[M->parent[v]];
+            rng_block(g, 0, ub);
+            tn_sample(hN, p0, t, 0.0, hP, ub[0], &h1, lnq);
+            const double xiT = h1 / hN, xiR = 1.0 / xiT, xiStem = (hP - hN) / (hP - h1);
+            y->H[v] = h1;
+            for (int w = v + 1; w < v + size[v]; ++w) {
+                y->H[w] = cur->H[w] * xiT;
+                y->R[w] = cur->R[w] * xiR;
+            }
+            y->R[v] = cur->R[v] * xiStem;
+            *lnj = (double)(M->n1[p] - M->n2[p]) * log(xiT) + log(xiStem);
+            break;
+        }
+        case ORM_SLIDE_ROOT_CONTRA: {   /* Contrary.hs:191-223 */
+            if (fabs(cur->H[0] - 1.0) > 1e-14) { *lnq = NAN; break; }        /* `error` upstream */
+            const int l = 1, r = 1 + size[1];
+            const double ht = cur->sc[2], hmax = fmax(cur->H[l], cur->H[r]);
+            double ub[2], ht1;
+            rng_block(g, 0, ub);
+            tn_sample(ht, p0, t, ht * hmax, INFINITY, ub[0], &ht1, lnq);
+            const double u = ht1 / ht;
+            const double xil = (1.0 - cur->H[l]) / (u - cur->H[l]), xir = (1.0 - cur->H[r]) / (u - cur->H[r]);
+            for (int w = 1; w < n; ++w) y->H[w] = cur->H[w] / u;
+            y->R[l] = cur->R[l] * xil;
+            y->R[r] = cur->R[r] * xir;
+            y->sc[2] = ht1;
+            *lnj = (double)(-M->n1[p]) * log(u) + log(xil) + log(xir);
+            break;
+        }
+        case ORM_SCALE_RATES_TREE_CONTRA: {   /* Contrary.hs:420-446 on (timeBirthRate, rateMean, timeTree), app/Definitions.hs:238-239 */
+            const int l = 1, r = 1 + size[1];
+            const double m = fmax(cur->H[l], cur->H[r]);
+            double ub[2], m1;
+            rng_block(g, 0, ub);
+            tn_sample(m, p0, t, 0.0, cur->H[0], ub[0], &m1, lnq);
+            const double xi = m1 / m;
+            for (int w = 1; w < n; ++w) y->H[w] = cur->H[w] * xi;
+            y->sc[0] = cur->sc[0] / xi;
+            y->sc[3] = cur->sc[3] / xi;
+            *lnj = (double)(M->n1[p] - 1 - 2) * log(xi);
+            break;
+        }
+        case ORM_SLIDE_BRACE:
+        case ORM_SLIDE_BRACE_CONTRA: {   /* Brace.hs:98-156 and :37-61 */
+            const int lo = M->br_ptr[v], hi = M->br_ptr[v + 1];
+            double a = -INFINITY, b = INFINITY, ub[2], delta;
+            for (int i = lo; i < hi; ++i) {
+                const int x = M->br_nodes[i];
+                double hc = -INFINITY;
+                for (int w = x + 1; w < x + size[x]; ++w)
+                    if (M->parent[w] == x && cur->H[w] > hc) hc = cur->H[w];
+                a = fmax(a, hc - cur->H[x]);
+                b = fmin(b, cur->H[M->parent[x]] - cur->H[x]);
+            }
+            rng_block(g, 0, ub);
+            tn_sample(0.0, p0, t, a, b, ub[0], &delta, lnq);
+            double sumlog = 0.0;
+            for (int i = lo; i < hi; ++i) {
+                const int x = M->br_nodes[i];
+                y->H[x] = cur->H[x] + delta;
+                if (M->kind[p] == ORM_SLIDE_BRACE_CONTRA) {
+                    const double hN = cur->H[x], hP = cur->H[M->parent[x]];
+                    const double xiS = (hP - hN) / (hP - hN - delta);
+                    y->R[x] = y->R[x] * xiS;
+                    sumlog += log(xiS);
+                    for (int w = x + 1; w < x + size[x]; ++w)
+                        if (M->parent[w] == x) {
+                            const double xi = (hN - cur->H[w]) / (hN + delta - cur->H[w]);
+                            y->R[w] = y->R[w] * xi;
+                            sumlog += log(xi);
+                        }
+                }
+            }
+            *lnj = sumlog;
             break;
         }
         default: *lnq = NAN;

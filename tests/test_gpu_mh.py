@@ -1,7 +1,7 @@
 """GPU parity of the lock-step Metropolis-Hastings-Green driver (first slice) against its CPU
 twin oracle/mh_oracle.c.  Both sides draw the same counter-based random numbers, so chains can be compared step by
-step: ln acceptance ratio of every step within 1e-8 + 1e-12 |ln posterior| (the device evaluates the likelihood
-through the Cholesky factor and libm differs from ocml in the last ulp), identical accept/reject
+step: ln acceptance ratio of every step within 1e-8 + 1e-12 |ln posterior| + 1e-10 |ratio| (the device evaluates the
+likelihood through the Cholesky factor and libm differs from ocml in the last ulp), identical accept/reject
 decisions, identical counters, final states within 1e-9 relative.  Posterior level: node-age means of two
 independent runs (device vs twin, different seeds) within 1 % on tests/12-leaves-variable-rate (north_star)."""
 import numpy as np
@@ -38,6 +38,12 @@ def setup(fx, model="UncorrelatedGamma", B=16, seed=7, first_chain=0):
     return topo, ps, smp, twin
 
 
+def alpha_close(a, b, tol):
+    """ln acceptance ratios agree: absolute `tol` plus 1e-10 relative (a contrary slide that lands next to a bound
+    multiplies a rate by 1 / (tiny height difference): ratios of -1e5 and more, conditioned accordingly)."""
+    return bool(np.all(np.abs(a - b) <= tol + 1e-10 * np.abs(b)))
+
+
 def compare_states(smp, twin, rtol=1e-9, atol_post=1e-8):
     s = smp.state()
     for a, b in ((s.time_birth_rate, twin.birth), (s.time_death_rate, twin.death), (s.time_height, twin.tH), (s.heights, twin.H),
@@ -62,7 +68,7 @@ def test_lockstep_parity_with_cpu_twin(gpu, golden, name):
     ra, rk = twin.run(sched, accumulate=True, trace=True)
     fin = np.isfinite(ra)
     assert np.array_equal(np.isfinite(ta), fin)
-    assert np.max(np.abs(ta[fin] - ra[fin])) <= tol, (np.max(np.abs(ta[fin] - ra[fin])), tol)
+    assert alpha_close(ta[fin], ra[fin], tol)
     assert np.array_equal(tk, rk)
     assert 0.05 < tk.mean() < 0.95                      # both outcomes exercised
     t, acc, tried = smp.tuning()
@@ -91,7 +97,7 @@ def test_lockstep_parity_other_clock_models(gpu, golden, model):
     ta, tk = smp.run_schedule(sched, trace=True)
     ra, rk = twin.run(sched, trace=True)
     fin = np.isfinite(ra)
-    assert np.array_equal(np.isfinite(ta), fin) and np.max(np.abs(ta[fin] - ra[fin])) <= tol
+    assert np.array_equal(np.isfinite(ta), fin) and alpha_close(ta[fin], ra[fin], tol)
     assert np.array_equal(tk, rk)
     compare_states(smp, twin)
 
@@ -142,7 +148,7 @@ def test_large_tree_uses_the_per_phase_path(gpu):
     ta, tk = smp.run_schedule(sched, trace=True)
     ra, rk = twin.run(sched, trace=True)
     fin = np.isfinite(ra)
-    assert np.array_equal(np.isfinite(ta), fin) and np.max(np.abs(ta[fin] - ra[fin])) <= tol
+    assert np.array_equal(np.isfinite(ta), fin) and alpha_close(ta[fin], ra[fin], tol)
     assert np.array_equal(tk, rk) and 0.02 < tk.mean() < 0.98
     compare_states(smp, twin, atol_post=tol)
 

@@ -21,8 +21,10 @@ def model_for(fx, clock="UncorrelatedGamma", calibrated=None):
     topo = M.Topology(fx["parent"])
     cal = [(int(r[0]), r[2] if r[1] else None, r[3], r[5] if r[4] else None, r[6]) for r in fx["cal"]]
     con = [(int(r[0]), int(r[1]), r[2]) for r in fx["con"]]
-    spec = O.PriorSpec(fx["parent"], float(fx["prior_ht"]), clock, cal, con, [])
-    ps, missing = M.proposals(topo, [], calibrations_available=(len(cal) > 0) if calibrated is None else calibrated)
+    br = [M.Brace(f"b{i}", [int(x) for x in fx["brace_nodes"][fx["brace_ptr"][i]:fx["brace_ptr"][i + 1]]], float(s))
+          for i, s in enumerate(fx["brace_sd"])]
+    spec = O.PriorSpec(fx["parent"], float(fx["prior_ht"]), clock, cal, con, [(b.nodes, b.sd) for b in br])
+    ps, missing = M.proposals(topo, br, calibrations_available=(len(cal) > 0) if calibrated is None else calibrated)
     return topo, ps, missing, O.MhModel(fx["parent"], fx["mu"], fx["sigma_inv"], float(fx["logdet"]), spec, M.table_arrays(ps))
 
 
@@ -69,10 +71,16 @@ def test_proposal_table_mirrors_the_reference_cycle(golden):
     inner = [v for v in range(1, n) if not topo.leaves[v]]
     l, r = topo.root_children()
     names = [p.name for p in ps]
-    assert names[:4] == ["Time birth rate", "Time death rate", "Rate mean", "Rate variance"] and all(p.weight == w for p in ps[:4])
+    assert names[:5] == ["Time birth rate", "Time death rate", "Rate mean", "Rate variance", "Rates and time tree"] and all(p.weight == w for p in ps[:5])
+    assert (ps[4].kind, ps[4].p0, ps[4].n1, ps[4].dim, ps[4].jac_root) == (SM.SCALE_RATES_TREE_CONTRA, 0.1, 10, 12, True)
     slides = [p for p in ps if p.kind == SM.SLIDE_NODE]
     assert sorted(p.node for p in slides) == inner and all(p.weight == 5 and p.dim == 1 and p.p0 == 0.01 for p in slides)
-    assert all(p.jac_root == (p.node in (l, r)) for p in ps if p.kind in (SM.SLIDE_NODE, SM.SCALE_SUBTREE_TIME, SM.SCALE_BRANCH_RATE, SM.SCALE_SUBTREE_RATE))
+    assert all(p.jac_root == (p.node in (l, r)) for p in ps if p.kind in (SM.SLIDE_NODE, SM.SCALE_SUBTREE_TIME, SM.SCALE_BRANCH_RATE, SM.SCALE_SUBTREE_RATE,
+                                                                          SM.SLIDE_NODE_CONTRA, SM.SCALE_SUBTREE_CONTRA))
+    csl = [p for p in ps if p.kind == SM.SLIDE_NODE_CONTRA]
+    assert sorted(p.node for p in csl) == inner and all(p.dim == 4 and p.p0 == 0.1 and 3 <= p.weight <= 8 for p in csl)
+    csc = [p for p in ps if p.kind == SM.SCALE_SUBTREE_CONTRA]
+    assert sorted(p.node for p in csc) == inner and all(p.n2 == topo.subtree_size(p.node) and p.dim == p.n1 + p.n2 for p in csc)
     sub = [p for p in ps if p.kind == SM.SCALE_SUBTREE_TIME]
     assert sorted(p.node for p in sub) == inner and all(3 <= p.weight <= 8 and p.n1 == p.dim >= 1 for p in sub)
     branches = [p for p in ps if p.kind == SM.SCALE_BRANCH_RATE]
@@ -81,12 +89,19 @@ def test_proposal_table_mirrors_the_reference_cycle(golden):
     assert all(p.n1 == topo.subtree_size(p.node) for p in rsub) and sorted(p.node for p in rsub) == inner
     pulley = [p for p in ps if p.kind == SM.PULLEY]
     assert len(pulley) == (0 if topo.leaves[l] or topo.leaves[r] else 1) and all(p.weight == 6 and p.jac_root for p in pulley)
-    assert [p.name for p in ps[-3:]] == ["Time height", "Time height, rate mean", "[R] Time height, Rate tree"]
-    assert ps[-3].p0 == 3000.0 and (ps[-2].p0, ps[-2].p1, ps[-2].dim) == (10.0, 0.1, 2) and not ps[-2].jac_root and ps[-1].jac_root
-    assert len(missing) == 3 and any("slideRootContrarily" in m for m in missing)
+    assert [p.name for p in ps[-4:]] == ["Time height", "Time height, rate mean", "[R] Time height, Rate tree", "[R] Trees"]
+    assert ps[-4].p0 == 3000.0 and (ps[-3].p0, ps[-3].p1, ps[-3].dim) == (10.0, 0.1, 2) and not ps[-3].jac_root and ps[-2].jac_root
+    assert (ps[-1].kind, ps[-1].p0, ps[-1].n1, ps[-1].dim, ps[-1].jac_root, ps[-1].weight) == (SM.SLIDE_ROOT_CONTRA, 10.0, 11, 14, True, w)
+    assert missing == []                                 # the whole Metropolis-Hastings cycle of the reference is built
     # without calibrations the time height is not moved (app/Definitions.hs:270-271)
     _, ps0, missing0, _ = model_for(fx, calibrated=False)
-    assert len(ps0) == len(ps) - 3 and not any(p.kind == SM.SCALE_CONTRARILY for p in ps0) and len(missing0) == 2
+    assert len(ps0) == len(ps) - 4 and not any(p.kind in (SM.SCALE_CONTRARILY, SM.SLIDE_ROOT_CONTRA) for p in ps0) and missing0 == []
+    # braces add one ultrametric and one contrary proposal each (:165, :221)
+    fb = golden["24-leaves-braces"]
+    _, psb, _, _ = model_for(fb)
+    bps = [p for p in psb if p.kind in (SM.SLIDE_BRACE, SM.SLIDE_BRACE_CONTRA)]
+    assert [(p.kind, p.node, p.p0, p.weight, p.jac_root) for p in bps] == [(SM.SLIDE_BRACE, 0, 0.01, 5, False), (SM.SLIDE_BRACE_CONTRA, 0, 0.1, 5, False)]
+    assert bps[0].dim == 2 and bps[1].dim == 2 + 2 + 4
     sched = M.cycle_schedule(ps, 3, np.random.default_rng(0))
     assert sched.shape == (3, sum(p.weight for p in ps))
     for row in sched:
@@ -159,6 +174,51 @@ def test_every_proposal_kind_closed_forms_and_reversibility(golden):
             g = st.gamma(k, scale=th)
             assert abs(lnq - (g.logpdf(1 / u) - g.logpdf(u))) < 1e-9 * max(1.0, abs(lnq))
             assert np.array_equal(H1, H)
+        elif p.kind in (SM.SLIDE_NODE_CONTRA, SM.SCALE_SUBTREE_CONTRA, SM.SLIDE_ROOT_CONTRA, SM.SCALE_RATES_TREE_CONTRA, SM.SLIDE_BRACE,
+                        SM.SLIDE_BRACE_CONTRA):
+            s1 = t * p.p0
+            z = lambda m, a, b: st.norm.cdf((b - m) / s1) - st.norm.cdf((a - m) / s1)
+            par = topo.parent
+            tl = lambda HH: HH[np.maximum(par, 0)] - HH                       # branch lengths
+            if p.kind == SM.SLIDE_NODE_CONTRA:
+                ch = topo.children(v)
+                assert max(H[c] for c in ch) <= H1[v] <= H[par[v]] and np.array_equal(np.delete(H1, v), np.delete(H, v))
+                touched = ch + [v]
+                # contrary: every touched branch keeps its time * rate product
+                assert np.allclose((tl(H1) * R1)[touched], (tl(H) * R)[touched], rtol=1e-13)
+                assert np.array_equal(np.delete(R1, touched), np.delete(R, touched))
+                assert abs(lnj - np.sum(np.log(R1[touched] / R[touched]))) < 1e-11
+                assert abs(lnq - (np.log(z(H[v], max(H[c] for c in ch), H[par[v]])) - np.log(z(H1[v], max(H[c] for c in ch), H[par[v]])))) < 1e-9
+            elif p.kind == SM.SCALE_SUBTREE_CONTRA:
+                xi = H1[v] / H[v]
+                assert np.allclose(H1[sub[1:]], H[sub[1:]] * xi, rtol=1e-15) and np.array_equal(np.delete(H1, sub), np.delete(H, sub))
+                assert np.allclose((tl(H1) * R1)[sub], (tl(H) * R)[sub], rtol=1e-13) and np.array_equal(np.delete(R1, sub), np.delete(R, sub))
+                assert abs(lnj - ((p.n1 - p.n2) * np.log(xi) + np.log(R1[v] / R[v]))) < 1e-11
+            elif p.kind == SM.SLIDE_ROOT_CONTRA:
+                u = sc1[2] / sc[2]
+                l, r = topo.root_children()
+                assert sc1[2] >= sc[2] * max(H[l], H[r]) and H1[0] == 1.0 and np.allclose(H1[1:], H[1:] / u, rtol=1e-15)
+                # absolute node ages below the root and the root branches' time * rate products are unchanged
+                assert np.allclose(sc1[2] * H1[1:], sc[2] * H[1:], rtol=1e-14)
+                assert np.allclose((sc1[2] * tl(H1) * R1)[[l, r]], (sc[2] * tl(H) * R)[[l, r]], rtol=1e-13)
+                assert abs(lnj - (-p.n1 * np.log(u) + np.log(R1[l] / R[l]) + np.log(R1[r] / R[r]))) < 1e-11
+                assert np.array_equal(np.delete(R1, [l, r]), np.delete(R, [l, r])) and np.array_equal(np.delete(sc1, 2), np.delete(sc, 2))
+            elif p.kind == SM.SCALE_RATES_TREE_CONTRA:
+                l, r = topo.root_children()
+                xi = max(H1[l], H1[r]) / max(H[l], H[r])
+                assert H1[0] == H[0] and np.allclose(H1[1:], H[1:] * xi, rtol=1e-15) and np.array_equal(R1, R)
+                assert abs(sc1[0] * xi - sc[0]) < 1e-15 and abs(sc1[3] * xi - sc[3]) < 1e-15 and abs(lnj - (p.n1 - 3) * np.log(xi)) < 1e-11
+            else:
+                nodes = [36, 6]
+                delta = H1[nodes[0]] - H[nodes[0]]
+                assert delta != 0 and np.allclose(H1[nodes] - H[nodes], delta, rtol=1e-12) and np.array_equal(np.delete(H1, nodes), np.delete(H, nodes))
+                if p.kind == SM.SLIDE_BRACE:
+                    assert np.array_equal(R1, R) and lnj == 0.0
+                else:
+                    touched = nodes + [c for x in nodes for c in topo.children(x)]
+                    assert np.allclose((tl(H1) * R1)[touched], (tl(H) * R)[touched], rtol=1e-13)
+                    assert abs(lnj - np.sum(np.log(R1[touched] / R[touched]))) < 1e-11
+            assert M.State(1, 1, 1, H1, 1, 1, np.maximum(R1, 1e-9)).is_valid(topo)
         else:
             s1 = t * p.p0
             z = lambda m, a, b: st.norm.cdf((b - m) / s1) - st.norm.cdf((a - m) / s1)
@@ -178,7 +238,7 @@ def test_every_proposal_kind_closed_forms_and_reversibility(golden):
                 assert abs(lnj - ((p.n1 - 1) * np.log(H1[l] / H[l]) + (p.n2 - 1) * np.log(H1[r] / H[r]))) < 1e-11
             assert np.array_equal(R1, R) and np.array_equal(sc1, sc)
             assert M.State(1, 1, 1, H1, 1, 1, np.maximum(R1, 1e-9)).is_valid(topo)     # still a valid ultrametric tree
-    assert seen == set(range(10))
+    assert seen == set(range(16))
 
 
 def test_chain_is_reproducible_and_chain_offset_selects_the_stream(golden):
