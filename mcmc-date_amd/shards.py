@@ -60,3 +60,31 @@ def gather_loglik(ll_local, shard: ChainShard):
     out = torch.empty(shard.world * m, dtype=ll_local.dtype, device=ll_local.device)
     dist.all_gather_into_tensor(out, pad)
     return torch.cat([out[r * m: r * m + c] for r, c in enumerate(counts)])
+
+
+def gather_chain_rows(rows_local, shard: ChainShard):
+    """All-gather of a per-chain table ([shard.size, k]: e.g. the sampler's per-chain node-age means or ln posterior
+    triples) in global chain order; ragged shards allowed.  One collective, like gather_loglik."""
+    import torch
+    import torch.distributed as dist
+
+    if rows_local.dim() != 2 or rows_local.shape[0] != shard.size:
+        raise ValueError("gather_chain_rows: expected a [shard.size, k] tensor")
+    if shard.world == 1:
+        return rows_local.clone()
+    k = rows_local.shape[1]
+    counts = shard.counts()
+    m = max(counts)
+    pad = torch.zeros(m, k, dtype=rows_local.dtype, device=rows_local.device)
+    pad[: shard.size] = rows_local
+    out = torch.empty(shard.world * m, k, dtype=rows_local.dtype, device=rows_local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m: r * m + c] for r, c in enumerate(counts)])
+
+
+def shard_sampler(tree_lik, prior, table, n_chains: int, seed: int, shard: ChainShard):
+    """This rank's block of a global set of `n_chains` Metropolis-Hastings chains: a `Sampler` whose chain b draws the
+    random stream of global chain shard.lo + b, so the global result does not depend on the number of GPUs."""
+    from .sampler import Sampler
+
+    return Sampler(tree_lik, prior, table, shard.size, seed, first_chain=shard.lo)

@@ -71,3 +71,55 @@ def test_shard_arithmetic():
         assert shards[0].lo == 0 and shards[-1].hi == n
         assert all(a.hi == b.lo for a, b in zip(shards, shards[1:]))
         assert sum(s.size for s in shards) == n and max(s.size for s in shards) - min(s.size for s in shards) <= 1
+
+
+def _mh_worker(rank, world, port, n_chains, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mcmc_date_amd as M
+    import oracle as O
+    from mcmc_date_amd.shards import ChainShard, gather_chain_rows
+
+    fx = dict(np.load(os.path.join(ROOT, "tests", "golden", "06-leaves-constant-rate.npz")))
+    topo = M.Topology(fx["parent"])
+    ps, _ = M.proposals(topo, [], calibrations_available=False)
+    spec = O.PriorSpec(fx["parent"], float(fx["prior_ht"]), "UncorrelatedGamma", [], [], [])
+    model = O.MhModel(fx["parent"], fx["mu"], fx["sigma_inv"], float(fx["logdet"]), spec, M.table_arrays(ps))
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    sched = M.cycle_schedule(ps, 6, np.random.default_rng(123))          # the schedule depends on the seed only: same on every rank
+
+    def chains(lo, hi):
+        s = M.StateBatch.from_states([x0] * (hi - lo))
+        return O.MhChains(model, s.time_birth_rate, s.time_death_rate, s.time_height, s.heights, s.rate_mean, s.rate_variance, s.rates,
+                          seed=9, chain0=lo)
+
+    sh = ChainShard(rank, world, n_chains)
+    mine = chains(sh.lo, sh.hi)
+    mine.run(sched, accumulate=True)
+    ages = gather_chain_rows(torch.as_tensor(mine.age_sum / mine.n_samples), sh)
+    post = gather_chain_rows(torch.as_tensor(mine.post), sh)
+    full = chains(0, n_chains)
+    full.run(sched, accumulate=True)
+    ok = np.array_equal(ages.numpy(), full.age_sum / full.n_samples) and np.array_equal(post.numpy(), full.post)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_chains", [8, 5])
+def test_sharded_mh_chains_equal_the_unsharded_run(n_chains):
+    """N > 1 path of the sampler: every rank advances its block of chains with the global chain index as the random
+    stream id (what shards.shard_sampler passes as first_chain on a GPU); the gathered per-chain results equal a
+    single-process run bit for bit.  The chains here are the CPU twin (the HIP path needs a GPU)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_mh_worker, args=(r, world, port, n_chains, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps) and all(ok for _, ok in res)
