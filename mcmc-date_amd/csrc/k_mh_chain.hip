@@ -51,6 +51,8 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
     const int64_t B = M.batch;
     Hc[lane] = (lane < nn) ? M.H[b * M.ld + lane] : 0.0;
     Rc[lane] = (lane < nn) ? M.R[b * M.ld + lane] : 0.0;
+    Hp[lane] = 0.0;                                     // lanes beyond the tree stay equal in both copies
+    Rp[lane] = 0.0;
     for (int i = lane; i < NP; i += 64) {
         tune[i] = M.tune[b * NP + i];
         acc[i] = M.acc[b * NP + i];
@@ -59,40 +61,71 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
     double sc[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) sc[i] = M.sc[i * B + b];
-    double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
+    double ll = M.post[B + b], lj = M.post[2 * B + b];
+    // the three blocks of the ln prior of the current state; a step re-evaluates only the blocks whose inputs moved
+    __builtin_amdgcn_wave_barrier();
+    double c0 = prior_nodes_wave(P, lane, sc[2], Hc);
+    double c1 = prior_bd_wave(P, lane, sc[0], sc[1], Hc);
+    double c2 = prior_clock_wave(P, lane, sc[3], sc[4], Hc, Rc);
+    double lp = c0 + c1 + c2;
     // row `lane` of the solve: mean, 1 / L_ii, the node whose branch feeds this distance slot and that node's parent
     const double mu_l = V.mu[lane], iv_l = V.invdiag[lane];
     const int slot = T.slot_node[lane];
     const int slot_par = (slot >= 0) ? T.parent[slot] : 0;
     const int rr = T.root_right;
     double age_s = 0.0, age_q = 0.0;
+#ifdef MCD_MH_STAMP
+    uint64_t tk[6] = {0, 0, 0, 0, 0, 0};
+#define MH_TICK(i)                                        \
+    {                                                     \
+        const uint64_t now_ = __builtin_readcyclecounter(); \
+        tk[i] += now_ - t_last;                           \
+        t_last = now_;                                    \
+    }
+    uint64_t t_last = __builtin_readcyclecounter();
+#else
+#define MH_TICK(i)
+#endif
     __builtin_amdgcn_wave_barrier();
     int p = sched[0];
     for (int64_t gs = 0; gs < n_steps; ++gs) {
         const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : 0;
         const uint64_t step = step0 + (uint64_t)gs;
-        const Rng g = mh_rng(seed, M.chain0 + b, step);
+        const Rng g = mh_rng(seed, M.chain0 + b, step, lane);
         double sc1[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
+        MH_TICK(0)
         const double lnqj = mh_propose_wave(M, p, tune[p], g, lane, sc1, Hc, Rc, Hp, Rp);
         __builtin_amdgcn_wave_barrier();
-        const double lp1 = prior_eval_wave(P, lane, sc1[0], sc1[1], sc1[2], sc1[3], sc1[4], Hp, Rp, nullptr);
+        MH_TICK(1)
+        const bool dH = __builtin_amdgcn_ballot_w64(Hp[lane] != Hc[lane]) != 0;     // NaN != NaN: re-evaluated
+        const bool dR = __builtin_amdgcn_ballot_w64(Rp[lane] != Rc[lane]) != 0;
+        const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(P, lane, sc1[2], Hp) : c0;
+        const double c1p = (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) ? prior_bd_wave(P, lane, sc1[0], sc1[1], Hp) : c1;
+        const double c2p = (dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2))
+                               ? prior_clock_wave(P, lane, sc1[3], sc1[4], Hp, Rp) : c2;
+        const double lp1 = c0p + c1p + c2p;
+        MH_TICK(2)
         // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207)
-        double dist = 0.0;
-        if (slot >= 0) {
-            dist = (Hp[slot_par] - Hp[slot]) * Rp[slot];
-            if (lane == 0) dist = dist + (Hp[0] - Hp[rr]) * Rp[rr];
-            dist = dist * (sc1[2] * sc1[3]);
+        double ll1 = ll, lj1 = lj;
+        if (dH || dR || sc1[2] != sc[2] || sc1[3] != sc[3]) {              // birth, death and rVar do not enter the likelihood
+            double dist = 0.0;
+            if (slot >= 0) {
+                dist = (Hp[slot_par] - Hp[slot]) * Rp[slot];
+                if (lane == 0) dist = dist + (Hp[0] - Hp[rr]) * Rp[rr];
+                dist = dist * (sc1[2] * sc1[3]);
+            }
+            lj1 = log(1.0 / mh_readlane64(dist, 0));                       // jacobianRootBranch, :393-410
+            double d = (dist - mu_l) * iv_l;
+            for (int j = 0; j < n; ++j) {                                  // column sweep of L z = x - mu, row-scaled
+                const double zj = mh_readlane64(d, j);
+                d = fma(-Fs[j * 64 + lane], zj, d);
+            }
+            const double q = pr_wave_sum(fma(d, d, 0.0));
+            ll1 = V.c + (-0.5) * (V.logdet + q);                           // :169
         }
-        const double lj1 = log(1.0 / mh_readlane64(dist, 0));              // jacobianRootBranch, :393-410
-        double d = (dist - mu_l) * iv_l;
-        for (int j = 0; j < n; ++j) {                                      // column sweep of L z = x - mu, row-scaled
-            const double zj = mh_readlane64(d, j);
-            d = fma(-Fs[j * 64 + lane], zj, d);
-        }
-        const double q = pr_wave_sum(fma(d, d, 0.0));
-        const double ll1 = V.c + (-0.5) * (V.logdet + q);                  // :169
+        MH_TICK(3)
         double la = (lp1 + ll1) - (lp + ll) + lnqj;
         if (M.jac_root[p]) la += lj1 - lj;
         double ua, ub;
@@ -103,6 +136,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
             Rc[lane] = Rp[lane];
 #pragma unroll
             for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
+            c0 = c0p;
+            c1 = c1p;
+            c2 = c2p;
             lp = lp1;
             ll = ll1;
             lj = lj1;
@@ -120,7 +156,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
             age_q += a * a;
         }
         p = p_next;
+        MH_TICK(4)
     }
+#ifdef MCD_MH_STAMP
+    if (trace_alpha && lane == 0)
+        for (int i = 0; i < 5; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // cycles: loop head, propose, prior, likelihood, accept
+#endif
     if (lane < nn) {
         M.H[b * M.ld + lane] = Hc[lane];
         M.R[b * M.ld + lane] = Rc[lane];

@@ -10,11 +10,15 @@
 
 namespace mcd {
 
+// Random stream of one (chain, step).  The Philox blocks a step may need are evaluated ONCE, lane-parallel: lane l holds
+// the two doubles of block d = l (l < 62), lane 62 those of d = 0xFFFFFFFE (gamma boost), lane 63 those of
+// d = 0xFFFFFFFF (acceptance).  philox_block() then is a v_readlane; any other block index falls back to computing it.
 struct Rng {
     uint32_t k0, k1, chain, s0, s1;
+    double pa, pb;
 };
 
-__device__ __forceinline__ void philox_block(const Rng& g, uint32_t d, double& ua, double& ub)
+__device__ __forceinline__ void philox_compute(const Rng& g, uint32_t d, double& ua, double& ub)
 {
     uint32_t c0 = d, c1 = g.chain, c2 = g.s0, c3 = g.s1, k0 = g.k0, k1 = g.k1;
 #pragma unroll
@@ -30,6 +34,26 @@ __device__ __forceinline__ void philox_block(const Rng& g, uint32_t d, double& u
     }
     ua = ((double)((((uint64_t)c0 << 32) | c1) >> 11) + 0.5) * 0x1p-53;
     ub = ((double)((((uint64_t)c2 << 32) | c3) >> 11) + 0.5) * 0x1p-53;
+}
+
+__device__ __forceinline__ double rng_readlane64(double v, int l)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void philox_block(const Rng& g, uint32_t d_in, double& ua, double& ub)
+{
+    const uint32_t d = __builtin_amdgcn_readfirstlane(d_in);   // wave-uniform by construction
+    if (d < 62u || d >= 0xFFFFFFFEu) {
+        const int l = (d < 62u) ? (int)d : (int)(d - 0xFFFFFFFEu) + 62;
+        ua = rng_readlane64(g.pa, l);
+        ub = rng_readlane64(g.pb, l);
+    } else {
+        philox_compute(g, d, ua, ub);
+    }
 }
 
 __device__ __forceinline__ double phi2(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); }
@@ -105,9 +129,12 @@ __device__ __forceinline__ double mh_wave_sum(double v)
 }
 
 
-__device__ __forceinline__ Rng mh_rng(uint64_t seed, int64_t chain, uint64_t step)
+__device__ __forceinline__ Rng mh_rng(uint64_t seed, int64_t chain, uint64_t step, int lane)
 {
-    return Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)chain, (uint32_t)step, (uint32_t)(step >> 32)};
+    Rng g{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)chain, (uint32_t)step, (uint32_t)(step >> 32), 0.0, 0.0};
+    const uint32_t d = (lane < 62) ? (uint32_t)lane : 0xFFFFFFFEu + (uint32_t)(lane - 62);
+    philox_compute(g, d, g.pa, g.pb);
+    return g;
 }
 
 // Apply proposal row p with tuning parameter t to the state (sc, H, R) of one chain; all 64 lanes active.

@@ -82,59 +82,13 @@ __device__ __forceinline__ void compute_de(bool near, double la, double mu, doub
     }
 }
 
-// ln prior of one chain; comp3 (may be null, lane-uniform pointer): node priors, birth-death block, clock block
-__device__ __forceinline__ double prior_eval_wave(const PriorDev& P, int lane, double la, double mu, double th, double rm,
-                                                  double va, const double* h, const double* r, double* c_out)
+// The log prior is the sum of three blocks (what app/Monitor.hs monitors); each is a function of part of the state:
+//   nodes  (th, heights)                      calibrations, constraints, braces           Combined.hs:70-92
+//   bd     (la, mu, heights)                  birth-death prior + exponential 1 la, mu    app/Probability.hs:66-85
+//   clock  (rm, va, rates; heights for the white-noise and autocorrelated models)         app/Probability.hs:96-124
+// A caller that knows which part of the state changed re-evaluates only the affected blocks (k_mh_chain.hip).
+__device__ __forceinline__ double prior_nodes_wave(const PriorDev& P, int lane, double th, const double* h)
 {
-    const bool near = 1e-6 > fabs(la - mu);                    // epsNearCritical, BirthDeath.hs:117-118
-
-    // ---- per-node terms: birth-death D factors and relaxed-clock branch densities ------------------
-    double bd = 0.0, clock = 0.0;
-    for (int v = 1 + lane; v < P.n_nodes; v += 64) {
-        const int pv = P.parent[v];
-        const double br = h[pv] - h[v];                        // heightTreeToLengthTree
-        // E at the bottom of v's branch
-        double e_bottom = 0.0;
-        const int nc = P.n_children[v];
-        if (nc > 0 && !near) {
-            const double xx = exp(-(la - mu) * h[v]);
-            e_bottom = mu * (1.0 - xx) / (la - mu * xx);
-        } else if (nc > 0) {   // near-critical: compose branch by branch like the reference, tip first
-            int u = P.first_child[v];
-            int depth = 1;
-            while (P.n_children[u] > 0) { u = P.first_child[u]; ++depth; }
-            double e = 0.0;                                    // below a tip: E = 0 with the tip's sampling rate
-            for (int i = 0; i < depth; ++i) {                  // u climbs from the tip to first_child[v]
-                const double bu = h[P.parent[u]] - h[u];
-                if (bu <= 0) {
-                    e = 1.0;                                   // `| br <= 0 = (0.0, 1.0)`
-                } else {
-                    double dd, ee;
-                    compute_de(near, la, mu, 1.0, bu, e, dd, ee);   // rho = 1 everywhere in priorFunctionBirthDeath
-                    e = ee;
-                }
-                u = P.parent[u];
-            }
-            e_bottom = e;
-        }
-        if (br <= 0) {
-            bd += kNegInf;
-        } else {
-            double dT, eT;
-            compute_de(near, la, mu, 1.0, br, e_bottom, dT, eT);
-            bd += log(dT * ((nc == 2) ? la : 1.0));            // internal node: dT * la; tip / unary: dT * rho, rho = 1
-        }
-        // relaxed molecular clock, branchesWith WithoutStem (Prior/Branch.hs:23-25)
-        const double rate = r[v];
-        double term;
-        switch (P.clock_model) {
-            case 0: term = ln_gamma_pdf(1.0 / va, va, rate); break;                       // uncorrelatedGamma 1.0 va
-            case 1: term = ln_lognormal_prime(1.0, va, rate); break;                      // uncorrelatedLogNormal
-            case 2: { const double v2 = va / br; term = ln_gamma_pdf(1.0 / v2, v2, rate); } break;   // white noise
-            default: term = ln_lognormal_prime(1.0, va * br, rate); break;                // autocorrelatedLogNormal
-        }
-        clock += term;
-    }
     // ---- soft node priors ------------------------------------------------------------------------
     double node = 0.0;
     const double x = 1.0 / th;                                 // transformInterval (recip h), Calibration.hs:426-430
@@ -174,12 +128,86 @@ __device__ __forceinline__ double prior_eval_wave(const PriorDev& P, int lane, d
             for (int j = lo; j < hi; ++j) node += ln_normal_ratio(P.brace_sd[i], h[P.brace_nodes[j]] - mean);
         }
     }
-    double c0 = pr_wave_sum(node), c1 = pr_wave_sum(bd), c2 = pr_wave_sum(clock);
+    double c0 = pr_wave_sum(node);
     if (th <= 0) c0 = kNegInf;                                 // Combined.hs:78
-    if (va <= 0) c2 = __builtin_nan("");                       // the reference calls `error` (variance <= 0)
+    return c0;
+}
+
+__device__ __forceinline__ double prior_bd_wave(const PriorDev& P, int lane, double la, double mu, const double* h)
+{
+    const bool near = 1e-6 > fabs(la - mu);                    // epsNearCritical, BirthDeath.hs:117-118
+    double bd = 0.0;
+    for (int v = 1 + lane; v < P.n_nodes; v += 64) {
+        const int pv = P.parent[v];
+        const double br = h[pv] - h[v];                        // heightTreeToLengthTree
+        // E at the bottom of v's branch
+        double e_bottom = 0.0;
+        const int nc = P.n_children[v];
+        if (nc > 0 && !near) {
+            const double xx = exp(-(la - mu) * h[v]);
+            e_bottom = mu * (1.0 - xx) / (la - mu * xx);
+        } else if (nc > 0) {   // near-critical: compose branch by branch like the reference, tip first
+            int u = P.first_child[v];
+            int depth = 1;
+            while (P.n_children[u] > 0) { u = P.first_child[u]; ++depth; }
+            double e = 0.0;                                    // below a tip: E = 0 with the tip's sampling rate
+            for (int i = 0; i < depth; ++i) {                  // u climbs from the tip to first_child[v]
+                const double bu = h[P.parent[u]] - h[u];
+                if (bu <= 0) {
+                    e = 1.0;                                   // `| br <= 0 = (0.0, 1.0)`
+                } else {
+                    double dd, ee;
+                    compute_de(near, la, mu, 1.0, bu, e, dd, ee);   // rho = 1 everywhere in priorFunctionBirthDeath
+                    e = ee;
+                }
+                u = P.parent[u];
+            }
+            e_bottom = e;
+        }
+        if (br <= 0) {
+            bd += kNegInf;
+        } else {
+            double dT, eT;
+            compute_de(near, la, mu, 1.0, br, e_bottom, dT, eT);
+            bd += log(dT * ((nc == 2) ? la : 1.0));            // internal node: dT * la; tip / unary: dT * rho, rho = 1
+        }
+    }
+    double c1 = pr_wave_sum(bd);
     if (la < 0 || mu < 0) c1 = __builtin_nan("");              // birthDeath: `error` on negative rates
     c1 += ln_exponential(1.0, la) + ln_exponential(1.0, mu);   // app/Probability.hs:72-73
+    return c1;
+}
+
+__device__ __forceinline__ double prior_clock_wave(const PriorDev& P, int lane, double rm, double va, const double* h,
+                                                   const double* r)
+{
+    double clock = 0.0;
+    for (int v = 1 + lane; v < P.n_nodes; v += 64) {
+        const double br = h[P.parent[v]] - h[v];               // heightTreeToLengthTree
+        // relaxed molecular clock, branchesWith WithoutStem (Prior/Branch.hs:23-25)
+        const double rate = r[v];
+        double term;
+        switch (P.clock_model) {
+            case 0: term = ln_gamma_pdf(1.0 / va, va, rate); break;                       // uncorrelatedGamma 1.0 va
+            case 1: term = ln_lognormal_prime(1.0, va, rate); break;                      // uncorrelatedLogNormal
+            case 2: { const double v2 = va / br; term = ln_gamma_pdf(1.0 / v2, v2, rate); } break;   // white noise
+            default: term = ln_lognormal_prime(1.0, va * br, rate); break;                // autocorrelatedLogNormal
+        }
+        clock += term;
+    }
+    double c2 = pr_wave_sum(clock);
+    if (va <= 0) c2 = __builtin_nan("");                       // the reference calls `error` (variance <= 0)
     c2 += ln_exponential(P.ht, rm) + ln_gamma_pdf(1.5, 1.0 / 6.0, va);   // :105-111
+    return c2;
+}
+
+// ln prior of one chain; c_out (may be null): node priors, birth-death block, clock block
+__device__ __forceinline__ double prior_eval_wave(const PriorDev& P, int lane, double la, double mu, double th, double rm,
+                                                  double va, const double* h, const double* r, double* c_out)
+{
+    const double c0 = prior_nodes_wave(P, lane, th, h);
+    const double c1 = prior_bd_wave(P, lane, la, mu, h);
+    const double c2 = prior_clock_wave(P, lane, rm, va, h, r);
     if (c_out) {
         c_out[0] = c0;
         c_out[1] = c1;
