@@ -4,7 +4,7 @@ One hot path, hand-written for gfx950, behind the reference's likelihood plugin 
     likelihood_function(lhd, topology)  ~  likelihoodFunction :: LikelihoodData -> LikelihoodFunction I
 (app/Probability.hs:277-281).  See DESIGN.md and include/mcmcdate_mvn.h.
 """
-from . import _capi
+from . import _capi, monitor
 from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating
 from .likelihood import (Full, LikelihoodData, MvnLikelihood, NoData, Sparse, TreeLikelihood, Univariate,
                          jacobian_root_branch, likelihood_function, read_data_file, write_data_file)

@@ -219,3 +219,39 @@ def test_posterior_node_ages_within_one_percent(gpu, golden):
     rate = acc.sum(axis=0) / np.maximum(1, tried.sum(axis=0))
     dims = np.array([p.dim for p in ps])
     assert np.all(np.abs(rate[dims == 1] - 0.44) < 0.1)
+
+
+def test_monitor_files_and_age_summary(gpu, golden, tmp_path):
+    """Row f4, reporting: the four monitor files of app/Definitions.hs:288-417 (period 2) for one chain and the node-age
+    summary of the reference's analysis script, fed by the device sampler."""
+    from mcmc_date_amd import monitor as MO
+
+    fx = golden["24-leaves-braces"]
+    topo, ps, smp, _ = setup(fx, B=8, seed=4)
+    lik, pf = smp._keep
+    cal = [M.Calibration(f"c{i}", int(r[0]), r[2] if r[1] else None, r[3], r[5] if r[4] else None, r[6]) for i, r in enumerate(fx["cal"])]
+    con = [M.Constraint(f"k{i}", int(r[0]), int(r[1]), r[2]) for i, r in enumerate(fx["con"])]
+    br = [M.Brace(f"b{i}", [int(n) for n in fx["brace_nodes"][fx["brace_ptr"][i]:fx["brace_ptr"][i + 1]]], float(s)) for i, s in enumerate(fx["brace_sd"])]
+    smp.run(20)
+    tr = MO.collect(smp, 41, accumulate=True)                 # 20 samples (period 2); the odd last iteration is run, not sampled
+    assert list(tr.iteration) == list(range(22, 62, 2)) and smp.iterations_done == 61 and tr.heights.shape == (20, 8, topo.n_nodes)
+    s_sum, _, n_acc = smp.age_sums()
+    assert n_acc == 41
+    files = MO.write_monitor_files(str(tmp_path / "run"), tr, 3, topo, cal, con, br, prior=pf)
+    assert [f.rsplit(".", 2)[1] for f in files] == ["params", "timetree", "ratetree", "prior"]
+    rows = [l.rstrip("\n").split("\t") for l in open(files[0])]
+    assert rows[0][:6] == ["Iteration", "TimeBirthRate", "TimeDeathRate", "TimeHeight", "RateMean", "RateVariance"]
+    assert len(rows) == 21 and len(rows[0]) == 6 + len(cal) + len(con) + len(br) and rows[1][0] == "22"
+    assert float(rows[5][3]) == tr.time_height[4, 3]
+    k = 7
+    trees = [l.rstrip("\n").split("\t") for l in open(files[1])]
+    from mcmc_date_amd.tree import parse_newick
+    topo2, ln2 = parse_newick(trees[1 + k][1])[:2]
+    assert np.array_equal(topo2.parent, topo.parent)
+    assert np.allclose(ln2[1:], (M.height_tree_to_length_tree(topo, tr.heights[k, 3]) * tr.time_height[k, 3])[1:], rtol=1e-15)
+    prior_rows = [l.split("\t") for l in open(files[3])]
+    lp, comp = pf.logprior(tr.states(k).slice(3, 4), want_components=True)
+    assert np.allclose([float(x) for x in prior_rows[1 + k][1:]], comp[0], rtol=0, atol=0)
+    summ = MO.summarize_node_ages(tr.ages()[:, 3, :], burn_in=0.25, names=[str(v) for v in range(topo.n_nodes)])
+    assert np.all(summ.ci_lower <= summ.mean) and np.all(summ.mean <= summ.ci_upper) and np.all(summ.mean[topo.leaves] == 0)
+    assert summ.render().count("\n") == topo.n_nodes + 1

@@ -152,3 +152,27 @@ def test_hamiltonian_position_vector(golden):
     assert len(g) == 73 and g[0] == fx["gR"][4][-1] and g[-1] == 0.0 and g[-3] == float(fx["gtH"][4])
     with pytest.raises(ValueError):
         M.to_vector(mask[:-1], x)
+
+
+def test_node_age_summary_follows_the_reference_script():
+    """scripts/trees-monitor-summary-ultrametric:149-175: drop round(l * burn-in) samples, ML variance, 95 % interval =
+    sorted[floor(0.025 l)] .. sorted[floor(0.025 l) + floor(0.95 l) - 1]."""
+    from mcmc_date_amd import monitor as MO
+
+    rng = np.random.default_rng(4)
+    ages = rng.gamma(5.0, 2.0, size=(1000, 3))
+    s = MO.summarize_node_ages(ages, burn_in=0.25, names=["r", "x", "a"])
+    kept = ages[250:]
+    l = len(kept)
+    for v in range(3):
+        srt = sorted(kept[:, v])
+        assert abs(s.mean[v] - kept[:, v].mean()) < 1e-12 and abs(s.variance[v] - np.mean((kept[:, v] - kept[:, v].mean()) ** 2)) < 1e-12
+        assert s.minimum[v] == srt[0] and s.maximum[v] == srt[-1]
+        assert s.ci_lower[v] == srt[int(l * 0.025)] and s.ci_upper[v] == srt[int(l * 0.025) + int(l * 0.95) - 1]
+    lines = s.render().splitlines()
+    assert lines[0] == "Index\tName\tMean\tVariance\tMin\tMax\t95CILower\t95CIUpper" and lines[2].startswith("1\tx\t") and len(lines) == 4
+    # five samples, no burn-in: floor(0.125) = 0, floor(4.75) = 4 -> the interval covers sorted[0..3]
+    tiny = MO.summarize_node_ages(np.array([[5.0], [1.0], [3.0], [2.0], [4.0]]), burn_in=0.0)
+    assert (tiny.ci_lower[0], tiny.ci_upper[0], tiny.minimum[0], tiny.maximum[0]) == (1.0, 4.0, 1.0, 5.0)
+    with pytest.raises(ValueError):
+        MO.summarize_node_ages(np.zeros((1, 2)), burn_in=0.9)
