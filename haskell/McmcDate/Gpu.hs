@@ -17,6 +17,17 @@ module McmcDate.Gpu
     withGpuLikelihood,
     likelihoodFunctionGpu,
     jacobianRootBranchGpu,
+    -- * Batched prior and lock-step Metropolis-Hastings driver (raw bindings)
+    McdPrior,
+    McdMh,
+    c_prior_create,
+    c_prior_logprior_batch,
+    c_mh_create,
+    c_mh_set_state,
+    c_mh_run,
+    c_mh_tune,
+    c_mh_get_state,
+    c_mh_get_age_sums,
   )
 where
 
@@ -112,3 +123,49 @@ likelihoodFunctionGpu ht = Exp . fst . evalState ht
 -- | Drop-in for 'jacobianRootBranch' (app/Probability.hs:408-410).
 jacobianRootBranchGpu :: ForeignPtr McdTree -> JacobianFunction I
 jacobianRootBranchGpu ht = Exp . snd . evalState ht
+
+
+-- ---------------------------------------------------------------------------------------------------------------
+-- Raw bindings of the remaining entry points (include/mcmcdate_mvn.h).  A batched driver in Haskell builds the
+-- proposal table from 'Definitions.proposals' (kind / node / parameters per proposal, see MCD_PROP_* in the
+-- header), hands blocks of iterations to 'c_mh_run' and reads states or node-age sums back for its monitors.
+-- ---------------------------------------------------------------------------------------------------------------
+data McdPrior
+
+data McdMh
+
+-- priorFunction ht md cb cs bs (app/Probability.hs:127-150); node indices are pre-order ids.
+foreign import ccall unsafe "mcd_prior_create"
+  c_prior_create ::
+    Ptr (Ptr McdPrior) -> CInt -> Ptr Int32 -> CDouble -> CInt ->
+    CInt -> Ptr Int32 -> Ptr Int32 -> Ptr CDouble -> Ptr CDouble -> Ptr Int32 -> Ptr CDouble -> Ptr CDouble ->
+    CInt -> Ptr Int32 -> Ptr Int32 -> Ptr CDouble ->
+    CInt -> Ptr Int32 -> Ptr Int32 -> Ptr CDouble -> CInt -> IO CInt
+
+foreign import ccall unsafe "mcd_prior_logprior_batch"
+  c_prior_logprior_batch ::
+    Ptr McdPrior -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble ->
+    Int64 -> Int64 -> CInt -> Ptr () -> Ptr CDouble -> Ptr CDouble -> IO CInt
+
+-- mhg over the cycle `proposals bs calibrationsAvailable x Nothing` for B chains in lock step (app/Main.hs:460-479).
+foreign import ccall unsafe "mcd_mh_create"
+  c_mh_create ::
+    Ptr (Ptr McdMh) -> Ptr McdTree -> Ptr McdPrior -> CInt -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 ->
+    Ptr CDouble -> Ptr CDouble -> Int64 -> Word64 -> IO CInt
+
+foreign import ccall unsafe "mcd_mh_set_state"
+  c_mh_set_state ::
+    Ptr McdMh -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Int64 -> IO CInt
+
+foreign import ccall safe "mcd_mh_run"
+  c_mh_run :: Ptr McdMh -> Ptr Int32 -> Int64 -> Int32 -> CInt -> Ptr CDouble -> Ptr Int8 -> IO CInt
+
+foreign import ccall unsafe "mcd_mh_tune"
+  c_mh_tune :: Ptr McdMh -> IO CInt
+
+foreign import ccall unsafe "mcd_mh_get_state"
+  c_mh_get_state ::
+    Ptr McdMh -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Int64 -> IO CInt
+
+foreign import ccall unsafe "mcd_mh_get_age_sums"
+  c_mh_get_age_sums :: Ptr McdMh -> Ptr CDouble -> Ptr CDouble -> Ptr Int64 -> IO CInt
