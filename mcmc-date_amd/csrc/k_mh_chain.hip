@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
     __builtin_amdgcn_wave_barrier();
     double c0 = prior_nodes_wave(P, lane, sc[2], Hc);
     double c1 = prior_bd_wave(P, lane, sc[0], sc[1], Hc);
-    double c2 = prior_clock_wave(P, lane, sc[3], sc[4], Hc, Rc);
+    ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};                    // variance-only pieces of the clock block, current state
+    double c2 = prior_clock_wave(P, lane, sc[3], sc[4], Hc, Rc, &cc);
     double lp = c0 + c1 + c2;
     // row `lane` of the solve: mean, 1 / L_ii, the node whose branch feeds this distance slot and that node's parent
     const double mu_l = V.mu[lane], iv_l = V.invdiag[lane];
@@ -101,10 +102,11 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
         MH_TICK(1)
         const bool dH = __builtin_amdgcn_ballot_w64(Hp[lane] != Hc[lane]) != 0;     // NaN != NaN: re-evaluated
         const bool dR = __builtin_amdgcn_ballot_w64(Rp[lane] != Rc[lane]) != 0;
+        ClockCache ccp = cc;                                               // refreshed only if the proposal moved rVar
         const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(P, lane, sc1[2], Hp) : c0;
         const double c1p = (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) ? prior_bd_wave(P, lane, sc1[0], sc1[1], Hp) : c1;
         const double c2p = (dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2))
-                               ? prior_clock_wave(P, lane, sc1[3], sc1[4], Hp, Rp) : c2;
+                               ? prior_clock_wave(P, lane, sc1[3], sc1[4], Hp, Rp, &ccp) : c2;
         const double lp1 = c0p + c1p + c2p;
         MH_TICK(2)
         // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207)
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
             c0 = c0p;
             c1 = c1p;
             c2 = c2p;
+            cc = ccp;
             lp = lp1;
             ll = ll1;
             lj = lj1;

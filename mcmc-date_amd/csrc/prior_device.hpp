@@ -178,9 +178,32 @@ __device__ __forceinline__ double prior_bd_wave(const PriorDev& P, int lane, dou
     return c1;
 }
 
+// Wave-uniform pieces of the clock block that depend on the rate variance only: lgamma and two logarithms.  A caller
+// that evaluates many states with the same variance (most proposals do not touch it) passes the cache of the previous
+// evaluation; the values are the same function results either way.
+struct ClockCache {
+    double va, lg_k, log_t, hyper;    // lgamma(1 / va), log(va), ln gamma(3/2, 1/6)(va)
+};
+
 __device__ __forceinline__ double prior_clock_wave(const PriorDev& P, int lane, double rm, double va, const double* h,
-                                                   const double* r)
+                                                   const double* r, ClockCache* cache = nullptr)
 {
+    double lg_k, log_t, hyper;
+    if (cache != nullptr && cache->va == va) {
+        lg_k = cache->lg_k;
+        log_t = cache->log_t;
+        hyper = cache->hyper;
+    } else {
+        lg_k = lgamma(1.0 / va);
+        log_t = log(va);
+        hyper = ln_gamma_pdf(1.5, 1.0 / 6.0, va);                         // app/Probability.hs:108-111
+        if (cache != nullptr) {
+            cache->va = va;
+            cache->lg_k = lg_k;
+            cache->log_t = log_t;
+            cache->hyper = hyper;
+        }
+    }
     double clock = 0.0;
     for (int v = 1 + lane; v < P.n_nodes; v += 64) {
         const double br = h[P.parent[v]] - h[v];               // heightTreeToLengthTree
@@ -188,7 +211,10 @@ __device__ __forceinline__ double prior_clock_wave(const PriorDev& P, int lane, 
         const double rate = r[v];
         double term;
         switch (P.clock_model) {
-            case 0: term = ln_gamma_pdf(1.0 / va, va, rate); break;                       // uncorrelatedGamma 1.0 va
+            case 0: {                                          // uncorrelatedGamma 1.0 va = gamma (1 / va) va
+                const double k = 1.0 / va;
+                term = (rate <= 0) ? kNegInf : log(rate) * (k - 1.0) - (rate / va) - lg_k - log_t * k;
+            } break;
             case 1: term = ln_lognormal_prime(1.0, va, rate); break;                      // uncorrelatedLogNormal
             case 2: { const double v2 = va / br; term = ln_gamma_pdf(1.0 / v2, v2, rate); } break;   // white noise
             default: term = ln_lognormal_prime(1.0, va * br, rate); break;                // autocorrelatedLogNormal
@@ -197,7 +223,7 @@ __device__ __forceinline__ double prior_clock_wave(const PriorDev& P, int lane, 
     }
     double c2 = pr_wave_sum(clock);
     if (va <= 0) c2 = __builtin_nan("");                       // the reference calls `error` (variance <= 0)
-    c2 += ln_exponential(P.ht, rm) + ln_gamma_pdf(1.5, 1.0 / 6.0, va);   // :105-111
+    c2 += ln_exponential(P.ht, rm) + hyper;                    // :105-111
     return c2;
 }
 
