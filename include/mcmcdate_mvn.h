@@ -166,6 +166,18 @@ int mcd_prior_logprior_batch(const mcd_prior_t* p, const double* birth, const do
                              int64_t ld_state, int64_t batch, int on_device, void* stream, double* lp,
                              double* components);
 
+/*
+ * Log prior and its gradient with respect to the seven fields of the state (first part): the prior
+ * factor of the Hamiltonian target `htargetWith` (app/Hamiltonian.hs:72-92), which the reference differentiates by AD.
+ * g_heights / g_rates: [batch][ld_state] (every node; masking per app/Hamiltonian.hs:33-47 is the caller's business;
+ * g_rates[.][0] = 0).  Outside the support (ln prior = -inf or NaN) and in the near-critical regime of the birth-death
+ * prior (|birth - death| < 1e-6, BirthDeath.hs:117-118) every gradient entry of that chain is NaN.
+ */
+int mcd_prior_grad_batch(const mcd_prior_t* p, const double* birth, const double* death, const double* tH,
+                         const double* heights, const double* rMu, const double* rVar, const double* rates,
+                         int64_t ld_state, int64_t batch, int on_device, void* stream, double* lp, double* g_birth,
+                         double* g_death, double* g_tH, double* g_heights, double* g_rMu, double* g_rVar, double* g_rates);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched Metropolis-Hastings-Green driver (FIRST SLICE).  `mcmc`'s `mhg` evaluates one state
  * per call (app/Main.hs:474); here `batch` independent chains execute the same proposal of the cycle at the same

@@ -51,6 +51,7 @@ SYMBOLS = {
                                    C.c_int, _ip, _ip, _dp, C.c_int]),
     "mcd_prior_destroy": (None, [_vp]),
     "mcd_prior_logprior_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "mcd_prior_grad_batch": (C.c_int, [_vp] * 8 + [C.c_int64, C.c_int64, C.c_int, _vp] + [_vp] * 8),
     "mcd_mh_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
     "mcd_mh_destroy": (None, [_vp]),
     "mcd_mh_set_chain_offset": (C.c_int, [_vp, C.c_int64]),

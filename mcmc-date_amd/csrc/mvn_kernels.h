@@ -38,6 +38,7 @@ struct PriorDev {
     const int32_t* parent;    // [n_nodes]
     const int32_t* first_child;   // [n_nodes], -1 for tips
     const int32_t* n_children;    // [n_nodes]
+    const int32_t* second_child;  // [n_nodes], -1 when there is none
     int n_cal;
     const int32_t *cal_node, *cal_has_lo, *cal_has_hi;
     const double *cal_lo, *cal_lo_p, *cal_hi, *cal_hi_p;
@@ -86,6 +87,10 @@ hipError_t launch_prior(const PriorDev& P, const double* birth, const double* de
                         const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
                         double* comp, hipStream_t st);
 
+hipError_t launch_prior_grad(const PriorDev& P, const double* birth, const double* death, const double* tH, const double* H,
+                             const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
+                             double* g_birth, double* g_death, double* g_tH, double* g_H, double* g_rMu, double* g_rVar, double* g_R,
+                             hipStream_t st);
 hipError_t launch_mh_propose(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed, hipStream_t st);
 hipError_t launch_mh_accept(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
                             double* trace_alpha, int8_t* trace_accept, hipStream_t st);

@@ -95,7 +95,7 @@ int mcd_prior_create(mcd_prior_t** out, int n_nodes, const int32_t* parent, doub
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return pfail(MCD_ERR_NO_DEVICE, "mcd_prior_create: no HIP device available (this library has no CPU path)");
     if (device_id < 0 || device_id >= ndev) return pfail(MCD_ERR_INVALID_ARG, "mcd_prior_create: device_id %d out of range", device_id);
-    std::vector<int32_t> par(parent, parent + n_nodes), first(n_nodes, -1), nch(n_nodes, 0);
+    std::vector<int32_t> par(parent, parent + n_nodes), first(n_nodes, -1), second(n_nodes, -1), nch(n_nodes, 0);
     {
         std::vector<int> stack{0};
         for (int v = 1; v < n_nodes; ++v) {
@@ -103,7 +103,9 @@ int mcd_prior_create(mcd_prior_t** out, int n_nodes, const int32_t* parent, doub
             while (!stack.empty() && stack.back() != par[v]) stack.pop_back();
             if (stack.empty()) return pfail(MCD_ERR_INVALID_ARG, "mcd_prior_create: node %d is not numbered in pre-order", v);
             stack.push_back(v);
-            if (nch[par[v]]++ == 0) first[par[v]] = v;
+            if (nch[par[v]] == 0) first[par[v]] = v;
+            if (nch[par[v]] == 1) second[par[v]] = v;
+            nch[par[v]]++;
         }
     }
     if (nch[0] != 2) return pfail(MCD_ERR_ROOT_NOT_BIFURCATING, "birthDeath: Tree is not bifurcating.");   // BirthDeath.hs:177
@@ -151,7 +153,7 @@ int mcd_prior_create(mcd_prior_t** out, int n_nodes, const int32_t* parent, doub
     D.n_brace = n_brace;
     int rc = MCD_OK;
     if ((rc = up_i(par.data(), n_nodes, &D.parent)) || (rc = up_i(first.data(), n_nodes, &D.first_child)) ||
-        (rc = up_i(nch.data(), n_nodes, &D.n_children)) || (rc = up_i(cal_node, n_cal, &D.cal_node)) ||
+        (rc = up_i(nch.data(), n_nodes, &D.n_children)) || (rc = up_i(second.data(), n_nodes, &D.second_child)) || (rc = up_i(cal_node, n_cal, &D.cal_node)) ||
         (rc = up_i(cal_has_lo, n_cal, &D.cal_has_lo)) || (rc = up_i(cal_has_hi, n_cal, &D.cal_has_hi)) ||
         (rc = up_d(cal_lo, n_cal, &D.cal_lo)) || (rc = up_d(cal_lo_p, n_cal, &D.cal_lo_p)) ||
         (rc = up_d(cal_hi, n_cal, &D.cal_hi)) || (rc = up_d(cal_hi_p, n_cal, &D.cal_hi_p)) ||
@@ -229,6 +231,61 @@ int mcd_prior_logprior_batch(const mcd_prior_t* cp, const double* birth, const d
                                components ? dcomp : nullptr, st));
     PHIP_TRY(hipMemcpyAsync(lp, dlp, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     if (components) PHIP_TRY(hipMemcpyAsync(components, dcomp, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, st));
+    PHIP_TRY(hipStreamSynchronize(st));
+    return MCD_OK;
+}
+
+int mcd_prior_grad_batch(const mcd_prior_t* cp, const double* birth, const double* death, const double* tH, const double* heights,
+                         const double* rMu, const double* rVar, const double* rates, int64_t ld_state, int64_t batch, int on_device,
+                         void* stream, double* lp, double* g_birth, double* g_death, double* g_tH, double* g_heights, double* g_rMu,
+                         double* g_rVar, double* g_rates)
+{
+    if (!cp) return pfail(MCD_ERR_INVALID_ARG, "mcd_prior_grad_batch: NULL handle");
+    mcd_prior* p = const_cast<mcd_prior*>(cp);
+    if (batch < 0 || ld_state < p->n_nodes) return pfail(MCD_ERR_INVALID_ARG, "mcd_prior_grad_batch: need batch >= 0 and ld_state >= n_nodes");
+    if (batch == 0) return MCD_OK;
+    if (!birth || !death || !tH || !heights || !rMu || !rVar || !rates || !lp || !g_birth || !g_death || !g_tH || !g_heights || !g_rMu ||
+        !g_rVar || !g_rates)
+        return pfail(MCD_ERR_INVALID_ARG, "mcd_prior_grad_batch: NULL data pointer");
+    if ((size_t)p->n_nodes * 16 > 64 * 1024) return pfail(MCD_ERR_UNSUPPORTED, "mcd_prior_grad_batch: more than 4096 nodes");
+    PHIP_TRY(hipSetDevice(p->device));
+    if (on_device) {
+        PHIP_TRY(mcd::launch_prior_grad(p->dev, birth, death, tH, heights, rMu, rVar, rates, ld_state, batch, lp, g_birth, g_death, g_tH,
+                                        g_heights, g_rMu, g_rVar, g_rates, (hipStream_t)stream));
+        return MCD_OK;
+    }
+    // host pointers: one private allocation per call (this entry point is not on a hot path of its own)
+    const size_t B = (size_t)batch, nn = (size_t)p->n_nodes;
+    const size_t need = 4 * B * nn + 11 * B;
+    double* buf = nullptr;
+    hipStream_t st = nullptr;
+    PHIP_TRY(hipMalloc((void**)&buf, need * sizeof(double)));
+    struct Free {
+        double* b;
+        hipStream_t* s;
+        ~Free()
+        {
+            (void)hipFree(b);
+            if (*s) (void)hipStreamDestroy(*s);
+        }
+    } fr{buf, &st};
+    PHIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    double* dH = buf;
+    double* dR = dH + B * nn;
+    double* dgH = dR + B * nn;
+    double* dgR = dgH + B * nn;
+    double* dsc = dgR + B * nn;          // birth, death, tH, rMu, rVar | lp | g_birth, g_death, g_tH, g_rMu, g_rVar
+    PHIP_TRY(hipMemcpy2DAsync(dH, sizeof(double) * nn, heights, sizeof(double) * ld_state, sizeof(double) * nn, B, hipMemcpyHostToDevice, st));
+    PHIP_TRY(hipMemcpy2DAsync(dR, sizeof(double) * nn, rates, sizeof(double) * ld_state, sizeof(double) * nn, B, hipMemcpyHostToDevice, st));
+    const double* src[5] = {birth, death, tH, rMu, rVar};
+    for (int i = 0; i < 5; ++i) PHIP_TRY(hipMemcpyAsync(dsc + i * B, src[i], sizeof(double) * B, hipMemcpyHostToDevice, st));
+    double* o = dsc + 5 * B;
+    PHIP_TRY(mcd::launch_prior_grad(p->dev, dsc, dsc + B, dsc + 2 * B, dH, dsc + 3 * B, dsc + 4 * B, dR, (int64_t)nn, batch, o, o + B, o + 2 * B,
+                                    o + 3 * B, dgH, o + 4 * B, o + 5 * B, dgR, st));
+    double* dst[6] = {lp, g_birth, g_death, g_tH, g_rMu, g_rVar};
+    for (int i = 0; i < 6; ++i) PHIP_TRY(hipMemcpyAsync(dst[i], o + i * B, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    PHIP_TRY(hipMemcpy2DAsync(g_heights, sizeof(double) * ld_state, dgH, sizeof(double) * nn, sizeof(double) * nn, B, hipMemcpyDeviceToHost, st));
+    PHIP_TRY(hipMemcpy2DAsync(g_rates, sizeof(double) * ld_state, dgR, sizeof(double) * nn, sizeof(double) * nn, B, hipMemcpyDeviceToHost, st));
     PHIP_TRY(hipStreamSynchronize(st));
     return MCD_OK;
 }

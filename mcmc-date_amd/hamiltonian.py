@@ -8,7 +8,8 @@ heights, the stem of the rate tree, and timeHeight when no calibrations are avai
 
 `grad_to_vector` arranges the device gradient of the LIKELIHOOD (mcd_tree_grad_batch) in that position
 vector; the likelihood does not depend on timeBirthRate, timeDeathRate, rateVariance, so their entries are 0
-(their gradients come from the prior, which is outside this repository's scope).
+(their gradients come from the prior: `PriorFunction.grad`, mcd_prior_grad_batch).  `target_grad` assembles the gradient
+of the whole Hamiltonian target ln (prior x likelihood x jacobianRootBranch) (`htargetWith`, :72-92) for a batch.
 """
 from __future__ import annotations
 
@@ -56,3 +57,32 @@ def grad_to_vector(mask: np.ndarray, g_heights, g_rates, g_time_height: float, g
     full = np.concatenate([[0.0, 0.0, g_time_height], np.asarray(g_heights, float), [g_rate_mean, 0.0],
                            np.asarray(g_rates, float)])
     return full[mask][::-1].copy()
+
+
+def target_grad(mask: np.ndarray, tree_lik, prior, states):
+    """Value and gradient of the Hamiltonian target of the reference, ln [prior x likelihood x jacobianRootBranch]
+    (`htargetWith`, app/Hamiltonian.hs:72-92), for every chain of `states`, in the position-vector layout of
+    `to_vector`: (value [B], gradient [B, mask.sum()]).  Prior and likelihood (values and gradients) come from the device
+    (mcd_prior_grad_batch, mcd_tree_grad_batch); the Jacobian factor 1 / rootBranch (app/Probability.hs:393-410),
+    rootBranch = tH rMu (t_l r_l + t_r r_r), is five numbers per chain and is differentiated here."""
+    lp, gp = prior.grad(states)
+    ll, gH, gR, gt, gm = tree_lik.grad(states)
+    lj = tree_lik.loglik(states)[1]
+    H, R = np.asarray(states.heights), np.asarray(states.rates)
+    tH, rMu = np.asarray(states.time_height), np.asarray(states.rate_mean)
+    topo = tree_lik.topo
+    l, r = topo.root_children()
+    S = (H[:, 0] - H[:, l]) * R[:, l] + (H[:, 0] - H[:, r]) * R[:, r]
+    jH = np.zeros_like(H)
+    jR = np.zeros_like(R)
+    jH[:, l] = R[:, l] / S                                    # d/d h_l of -ln S
+    jH[:, r] = R[:, r] / S
+    jH[:, 0] = -(R[:, l] + R[:, r]) / S
+    jR[:, l] = -(H[:, 0] - H[:, l]) / S
+    jR[:, r] = -(H[:, 0] - H[:, r]) / S
+    B = H.shape[0]
+    full = np.concatenate([gp["time_birth_rate"][:, None], gp["time_death_rate"][:, None], (gp["time_height"] + gt - 1.0 / tH)[:, None],
+                           gp["heights"] + gH + jH, (gp["rate_mean"] + gm - 1.0 / rMu)[:, None], gp["rate_variance"][:, None],
+                           gp["rates"] + gR + jR], axis=1)
+    assert full.shape == (B, len(mask))
+    return lp + ll + lj, full[:, mask][:, ::-1].copy()

@@ -201,6 +201,25 @@ class PriorFunction:
         return (lp, comp) if want_components else lp
 
 
+    def grad(self, s: StateBatch):
+        """ln prior and its gradient with respect to the seven fields of the state (host arrays):
+        (lp [B], dict(time_birth_rate, time_death_rate, time_height, heights [B, n_nodes], rate_mean, rate_variance,
+        rates [B, n_nodes])).  NaN outside the support and in the birth-death prior's near-critical regime."""
+        if s.time_birth_rate is None or s.time_death_rate is None or s.rate_variance is None:
+            raise ValueError("grad: the state batch lacks time_birth_rate / time_death_rate / rate_variance")
+        nn = self.topo.n_nodes
+        fields = (s.time_birth_rate, s.time_death_rate, s.time_height, s.heights, s.rate_mean, s.rate_variance, s.rates)
+        arr = [np.ascontiguousarray(a, dtype=np.float64) for a in fields]
+        B = arr[3].shape[0]
+        if arr[3].shape != (B, nn) or arr[6].shape != (B, nn) or any(a.shape != (B,) for a in (arr[0], arr[1], arr[2], arr[4], arr[5])):
+            raise ValueError("grad: inconsistent state shapes")
+        lp, gb, gd, gt, gm, gv = (np.empty(B) for _ in range(6))
+        gH, gR = np.empty((B, nn)), np.empty((B, nn))
+        _capi.check(_capi.lib().mcd_prior_grad_batch(self._p, *[_ptr(a) for a in arr], nn, B, 0, None, _ptr(lp), _ptr(gb), _ptr(gd), _ptr(gt),
+                                                     _ptr(gH), _ptr(gm), _ptr(gv), _ptr(gR)))
+        return lp, dict(time_birth_rate=gb, time_death_rate=gd, time_height=gt, heights=gH, rate_mean=gm, rate_variance=gv, rates=gR)
+
+
 def prior_function(ht: float, model: str, calibrations, constraints, braces, topo: Topology,
                    device: int = 0) -> Callable[[State], float]:
     """`priorFunction :: Double -> RelaxedMolecularClockModel -> ... -> PriorFunction I` (app/Probability.hs:127-150)."""

@@ -99,3 +99,115 @@ def test_prior_large_tree(gpu):
         ref = np.array([O.prior(spec, birth[b], death[b], st.time_height[b], st.heights[b], st.rate_mean[b], rvar[b], st.rates[b])[0]
                         for b in range(40)])
         assert close(lp, ref)
+
+
+@pytest.mark.parametrize("name", ["12-leaves-variable-rate", "24-leaves-braces"])
+@pytest.mark.parametrize("model", MODELS)
+def test_prior_gradient_against_differences_of_the_oracle(gpu, golden, name, model):
+    """Row f3, first part: d ln prior / d state from forward-mode duals on the device against central differences of
+    the pinned value oracle (oracle/prior_oracle.c).  The prior is C^1 (soft bounds are piecewise quadratic), so
+    fourth-order central differences with a relative step of 1e-4 are accurate to about 1e-7; tolerance 2e-5 * max(1, |g|)."""
+    fx = golden[name]
+    topo = M.Topology(fx["parent"])
+    cal, con, br = tables(fx)
+    ht = float(fx["prior_ht"])
+    pf = M.PriorFunction(ht, model, cal, con, br, topo)
+    spec = O.PriorSpec(fx["parent"], ht, model, [(c.node, c.lower, c.lower_p, c.upper, c.upper_p) for c in cal],
+                       [(k.young, k.old, k.p) for k in con], [(b.nodes, b.sd) for b in br])
+    s = batch(fx).slice(0, 6)
+    # make sure some soft bounds are active: push the first calibrated node of chain 1 above its upper bound, and
+    # spread the braced nodes of chain 2
+    H = s.heights.copy()
+    tHs = s.time_height.copy()
+    if cal:
+        c = cal[0]
+        if c.upper is not None:
+            tHs[1] = 1.3 * c.upper / H[1, c.node]
+    s = M.StateBatch(H, s.rates, tHs, s.rate_mean, s.time_birth_rate, s.time_death_rate, s.rate_variance)
+    lp, g = pf.grad(s)
+    lp_ref = pf.logprior(s)
+    assert np.array_equal(lp, lp_ref)                         # same value code
+    n = topo.n_nodes
+
+    def f(b, birth, death, tH, Hb, rMu, rVar, Rb):
+        return O.prior(spec, birth, death, tH, Hb, rMu, rVar, Rb)[0]
+
+    for b in range(6):
+        base = [s.time_birth_rate[b], s.time_death_rate[b], s.time_height[b], s.heights[b].copy(), s.rate_mean[b], s.rate_variance[b], s.rates[b].copy()]
+        assert np.isfinite(lp[b])
+        if abs(base[0] - base[1]) < 1e-6:                      # the fixtures' chain 1 sits in the near-critical regime on purpose
+            assert np.all(np.isnan(g["heights"][b])) and np.isnan(g["time_birth_rate"][b])
+            continue
+
+        def at(i, v, x):
+            a = list(base)
+            if v is None:
+                a[i] = x
+            else:
+                a[i] = base[i].copy()
+                a[i][v] = x
+            return f(b, *a)
+
+        def stencil(i, v, x0):                                  # fourth-order central difference, step 1e-4 |x|
+            h = 1e-4 * abs(x0)
+            return (-at(i, v, x0 + 2 * h) + 8 * at(i, v, x0 + h) - 8 * at(i, v, x0 - h) + at(i, v, x0 - 2 * h)) / (12 * h)
+
+        def fd_scalar(i):
+            return stencil(i, None, base[i])
+
+        for i, key in ((0, "time_birth_rate"), (1, "time_death_rate"), (2, "time_height"), (4, "rate_mean"), (5, "rate_variance")):
+            fd = fd_scalar(i)
+            assert abs(g[key][b] - fd) <= 2e-5 * max(1.0, abs(fd)), (key, b, g[key][b], fd)
+        assert g["rate_mean"][b] == -ht and g["rates"][b, 0] == 0.0
+        for v in range(1, n):
+            for i, key in ((3, "heights"), (6, "rates")):
+                x0 = base[i][v]
+                if x0 == 0.0:
+                    continue                                   # leaves: heights are not free parameters (mask)
+                fd = stencil(i, v, x0)
+                assert abs(g[key][b, v] - fd) <= 2e-5 * max(1.0, abs(fd)), (key, b, v, g[key][b, v], fd)
+    # outside the support the gradient is NaN, and in the near-critical regime as well
+    bad = batch(fx).slice(0, 3)
+    R = bad.rates.copy(); R[0, 3] = -1.0
+    birth = bad.time_birth_rate.copy(); death = bad.time_death_rate.copy()
+    birth[1] = death[1] + 1e-9
+    lp2, g2 = pf.grad(M.StateBatch(bad.heights, R, bad.time_height, bad.rate_mean, birth, death, bad.rate_variance))
+    assert lp2[0] == -np.inf and np.all(np.isnan(g2["heights"][0])) and np.isnan(g2["rate_variance"][0])
+    assert np.isfinite(lp2[1]) and np.all(np.isnan(g2["heights"][1])) and np.isnan(g2["time_birth_rate"][1])
+    assert np.isfinite(lp2[2]) and np.all(np.isfinite(g2["heights"][2]))
+
+
+def test_hamiltonian_target_gradient_in_position_layout(gpu, golden):
+    """ln [prior x likelihood x jacobianRootBranch] (htargetWith, app/Hamiltonian.hs:72-92) and its gradient in the
+    masked, reversed position vector of toVector (:49-53): directional derivative against differences of the oracles."""
+    fx = golden["24-leaves-braces"]
+    topo = M.Topology(fx["parent"])
+    cal, con, br = tables(fx)
+    ht = float(fx["prior_ht"])
+    pf = M.PriorFunction(ht, "UncorrelatedGamma", cal, con, br, topo)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    spec = O.PriorSpec(fx["parent"], ht, "UncorrelatedGamma", [(c.node, c.lower, c.lower_p, c.upper, c.upper_p) for c in cal],
+                       [(k.young, k.old, k.p) for k in con], [(b.nodes, b.sd) for b in br])
+    s = batch(fx).slice(2, 6)
+    mask = M.get_mask(True, topo)
+    val, grad = M.target_grad(mask, lik, pf, s)
+    assert grad.shape == (4, 73)                                  # SURVEY.md: 73 positions for the 24-leaf dataset
+
+    def target(x: M.State) -> float:
+        lp = O.prior(spec, x.time_birth_rate, x.time_death_rate, x.time_height, x.time_tree, x.rate_mean, x.rate_variance, x.rate_tree)[0]
+        ll, lj = O.tree_loglik_full_batch(fx["parent"], x.time_tree[None], x.rate_tree[None], np.array([x.time_height]), np.array([x.rate_mean]),
+                                          fx["mu"], fx["sigma_inv"], float(fx["logdet"]))
+        return lp + ll[0] + lj[0]
+
+    rng = np.random.default_rng(0)
+    for b in range(4):
+        x = M.State(s.time_birth_rate[b], s.time_death_rate[b], s.time_height[b], s.heights[b], s.rate_mean[b], s.rate_variance[b], s.rates[b])
+        assert abs(val[b] - target(x)) <= 1e-9 * max(1.0, abs(val[b]))
+        q = M.to_vector(mask, x)
+        for _ in range(3):
+            d = rng.normal(size=q.shape) * np.abs(q)
+            h = 1e-5
+            f = lambda a: target(M.from_vector_with(mask, x, q + a * h * d))
+            fd = (-f(2) + 8 * f(1) - 8 * f(-1) + f(-2)) / (12 * h)
+            an = float(grad[b] @ d)
+            assert abs(an - fd) <= 1e-5 * max(1.0, abs(fd)), (b, an, fd)
