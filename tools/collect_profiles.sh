@@ -15,5 +15,8 @@ CMD="python3 $ROOT/bench.py --steps 1000 --warmup 100 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_write.json 2> $OUT/pmc_write.log
+# Metropolis-Hastings driver (row f2): kernel trace + stats of a short run on the 12-leaf dataset, 64 and 4096 chains
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mh_trace -- python3 $ROOT/tools/bench_mh.py --iters 40 --cpu-iters 10 > $OUT/mh_steps.json 2> $OUT/mh_trace.log
 cd $ROOT
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log
 python3 tools/parse_profiles.py $TAG

@@ -66,4 +66,16 @@ if traffic:
     traffic["note"] = ("rocprofv3 --pmc, separate passes; KiB per dispatch averaged over the bench's dispatches; corrected = "
                        "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)")
     json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+f = find("mh_trace", "_kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(out, f"{tag}_mh_kernel_stats.csv"), "w") as g:
+        w = csv.DictWriter(g, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
+for name in ("mh_steps.json", "bench_default.json"):
+    src = os.path.join(base, name)
+    if os.path.exists(src):
+        lines = [l for l in open(src) if l.startswith("{")]
+        open(os.path.join(out, f"{tag}_{name}"), "w").write("".join(lines))
 print(json.dumps({"trace": summary, "traffic": traffic}, indent=1))
