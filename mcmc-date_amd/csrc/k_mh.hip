@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void k_mh_propose(MhDev M, const int32_t* __re
     double sc[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) sc[i] = M.sc[i * B + b];
-    const double lnqj = mh_propose_wave(M, p, M.tune[b * M.n_prop + p], mh_rng(seed, M.chain0 + b, step, lane), lane, sc, M.H + b * M.ld,
-                                        M.R + b * M.ld, M.H1 + b * M.ld, M.R1 + b * M.ld);
+    const double t = M.tune[b * M.n_prop + p];
+    const StepDraws dr = mh_step_draws(M, p, t, mh_rng(seed, M.chain0 + b, step));
+    const double lnqj = mh_propose_wave(M, p, t, dr, lane, sc, M.H + b * M.ld, M.R + b * M.ld, M.H1 + b * M.ld, M.R1 + b * M.ld);
     if (lane < 5) {
         double mine = sc[0];
 #pragma unroll
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_mh_accept(MhDev M, const int32_t* __res
     double la = (lp1 + ll1) - (lp + ll) + M.lnqj[b];
     if (M.jac_root[p]) la += lj1 - lj;
     double ua, ub;
-    philox_block(mh_rng(seed, M.chain0 + b, step, lane), 0xFFFFFFFFu, ua, ub);
+    philox_block(mh_rng(seed, M.chain0 + b, step), 0xFFFFFFFFu, ua, ub);
     const bool ok = (la >= 0) || (ua < exp(la));
     if (ok) {
         const double* H1 = M.H1 + b * M.ld;

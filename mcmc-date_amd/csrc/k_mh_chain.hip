@@ -89,15 +89,27 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
 #endif
     __builtin_amdgcn_wave_barrier();
     int p = sched[0];
+    StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                 // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
         const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : 0;
-        const uint64_t step = step0 + (uint64_t)gs;
-        const Rng g = mh_rng(seed, M.chain0 + b, step, lane);
+        if ((gs & 63) == 0) {
+            // 64 consecutive steps at once, one step per lane: the random draws that depend only on the proposal row and its
+            // tuning parameter (gamma multipliers with their ratio and logarithm, the uniforms of the truncated normals
+            // and of the acceptance) cost one evaluation per 64 steps instead of one per step
+            const int64_t mine = gs + lane;
+            if (mine < n_steps) {
+                const int pl = sched[mine];
+                pre = mh_step_draws(M, pl, tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
+            }
+        }
+        const int sl = (int)(gs & 63);
+        const StepDraws dr{mh_readlane64(pre.u, sl), mh_readlane64(pre.lnq, sl), mh_readlane64(pre.logu, sl), mh_readlane64(pre.U, sl),
+                           mh_readlane64(pre.Uacc, sl)};
         double sc1[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
         MH_TICK(0)
-        const double lnqj = mh_propose_wave(M, p, tune[p], g, lane, sc1, Hc, Rc, Hp, Rp);
+        const double lnqj = mh_propose_wave(M, p, tune[p], dr, lane, sc1, Hc, Rc, Hp, Rp);
         __builtin_amdgcn_wave_barrier();
         MH_TICK(1)
         const bool dH = __builtin_amdgcn_ballot_w64(Hp[lane] != Hc[lane]) != 0;     // NaN != NaN: re-evaluated
@@ -130,9 +142,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
         MH_TICK(3)
         double la = (lp1 + ll1) - (lp + ll) + lnqj;
         if (M.jac_root[p]) la += lj1 - lj;
-        double ua, ub;
-        philox_block(g, 0xFFFFFFFFu, ua, ub);
-        const bool ok = (la >= 0) || (ua < exp(la));
+        const bool ok = (la >= 0) || (dr.Uacc < exp(la));
         if (ok) {
             Hc[lane] = Hp[lane];
             Rc[lane] = Rp[lane];

@@ -10,15 +10,12 @@
 
 namespace mcd {
 
-// Random stream of one (chain, step).  The Philox blocks a step may need are evaluated ONCE, lane-parallel: lane l holds
-// the two doubles of block d = l (l < 62), lane 62 those of d = 0xFFFFFFFE (gamma boost), lane 63 those of
-// d = 0xFFFFFFFF (acceptance).  philox_block() then is a v_readlane; any other block index falls back to computing it.
+// Random stream of one (chain, step): Philox4x32-10, counter = (draw, chain, step_lo, step_hi), key = seed.
 struct Rng {
     uint32_t k0, k1, chain, s0, s1;
-    double pa, pb;
 };
 
-__device__ __forceinline__ void philox_compute(const Rng& g, uint32_t d, double& ua, double& ub)
+__device__ __forceinline__ void philox_block(const Rng& g, uint32_t d, double& ua, double& ub)
 {
     uint32_t c0 = d, c1 = g.chain, c2 = g.s0, c3 = g.s1, k0 = g.k0, k1 = g.k1;
 #pragma unroll
@@ -36,26 +33,6 @@ __device__ __forceinline__ void philox_compute(const Rng& g, uint32_t d, double&
     ub = ((double)((((uint64_t)c2 << 32) | c3) >> 11) + 0.5) * 0x1p-53;
 }
 
-__device__ __forceinline__ double rng_readlane64(double v, int l)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, l);
-    hi = __builtin_amdgcn_readlane(hi, l);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ void philox_block(const Rng& g, uint32_t d_in, double& ua, double& ub)
-{
-    const uint32_t d = __builtin_amdgcn_readfirstlane(d_in);   // wave-uniform by construction
-    if (d < 62u || d >= 0xFFFFFFFEu) {
-        const int l = (d < 62u) ? (int)d : (int)(d - 0xFFFFFFFEu) + 62;
-        ua = rng_readlane64(g.pa, l);
-        ub = rng_readlane64(g.pb, l);
-    } else {
-        philox_compute(g, d, ua, ub);
-    }
-}
-
 __device__ __forceinline__ double phi2(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); }
 
 // ln density of the normal(m, s) truncated to [a, b] at x; NaN where the reference raises `error`
@@ -67,13 +44,30 @@ __device__ inline double tn_logpdf(double m, double s, double a, double b, doubl
     return log((1.0 / s) * (1.0 / z) * (0.39894228040143267794 * exp(-0.5 * xi * xi)));
 }
 
-// truncatedNormalSample: new value and ln (qYX / qXY)
+__device__ __forceinline__ double tn_readlane64(double v, int l)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+// truncatedNormalSample: new value and ln (qYX / qXY).  All 64 lanes call it with the same arguments; the four normal
+// distribution functions, the two exponentials and the two logarithms it needs come in pairs with different arguments,
+// so even and odd lanes evaluate one member of each pair and the results are exchanged with v_readlane: the same
+// function values as the straight-line form (tn_logpdf(u, s1, a, b, m) - tn_logpdf(m, s1, a, b, u)) at half the calls.
 __device__ inline void tn_sample(double m, double s, double t, double a, double b, double U, double& x, double& lnq)
 {
+    const bool odd = (threadIdx.x & 1) != 0;
     const double s1 = t * s;
     double u = __builtin_nan("");
-    if ((s1 > 0) && (a < b) && !(a > m) && !(b < m)) {
-        const double pa = phi2((a - m) / s1), z = phi2((b - m) / s1) - pa;
+    double pa = 0.0, pb = 0.0;
+    const bool valid = (s1 > 0) && (a < b) && !(a > m) && !(b < m);
+    if (valid) {
+        const double p1 = phi2(((odd ? b : a) - m) / s1);              // even lanes: Phi(alpha), odd lanes: Phi(beta)
+        pa = tn_readlane64(p1, 0);
+        pb = tn_readlane64(p1, 1);
+        const double z = pb - pa;
         u = erfinv(2.0 * (U * z + pa) - 1.0) * 1.41421356237309504880 * s1 + m;
     }
     if (!(a <= u && u <= b)) {
@@ -82,7 +76,13 @@ __device__ inline void tn_sample(double m, double s, double t, double a, double 
         return;
     }
     x = u;
-    lnq = tn_logpdf(u, s1, a, b, m) - tn_logpdf(m, s1, a, b, u);
+    const double p2 = phi2(((odd ? b : a) - u) / s1);                  // the same two for the reverse move (mean u)
+    const double qa = tn_readlane64(p2, 0), qb = tn_readlane64(p2, 1);
+    // even lanes: ln density of the forward move (mean m at u), odd lanes: of the reverse move (mean u at m)
+    const double zz = odd ? (qb - qa) : (pb - pa);
+    const double xi = odd ? (m - u) / s1 : (u - m) / s1;
+    const double ld = log((1.0 / s1) * (1.0 / zz) * (0.39894228040143267794 * exp(-0.5 * xi * xi)));
+    lnq = tn_readlane64(ld, 1) - tn_readlane64(ld, 0);
 }
 
 // Gamma(shape, scale), Marsaglia & Tsang
@@ -129,18 +129,50 @@ __device__ __forceinline__ double mh_wave_sum(double v)
 }
 
 
-__device__ __forceinline__ Rng mh_rng(uint64_t seed, int64_t chain, uint64_t step, int lane)
+__device__ __forceinline__ Rng mh_rng(uint64_t seed, int64_t chain, uint64_t step)
 {
-    Rng g{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)chain, (uint32_t)step, (uint32_t)(step >> 32), 0.0, 0.0};
-    const uint32_t d = (lane < 62) ? (uint32_t)lane : 0xFFFFFFFEu + (uint32_t)(lane - 62);
-    philox_compute(g, d, g.pa, g.pb);
-    return g;
+    return Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)chain, (uint32_t)step, (uint32_t)(step >> 32)};
+}
+
+// The STATE-INDEPENDENT random part of one step: what can be drawn knowing only the proposal row and its tuning
+// parameter.  Gamma-multiplier proposals: the multiplier u, ln (q(1/u) / q(u)) and ln u; truncated-normal proposals:
+// the uniform that goes through the quantile; every step: the acceptance uniform.  The whole-schedule kernel computes
+// these for 64 consecutive steps at once, one step per lane (k_mh_chain.hip); the per-phase kernel per step.
+struct StepDraws {
+    double u, lnq, logu;   // gamma kinds
+    double U;              // truncated-normal kinds: first double of block 0
+    double Uacc;           // acceptance: first double of block 0xFFFFFFFF
+};
+
+__device__ __forceinline__ bool mh_is_gamma_kind(int kind)
+{
+    return kind == MCD_PROP_SCALE_SCALAR || kind == MCD_PROP_SCALE_BRANCH_RATE || kind == MCD_PROP_SCALE_SUBTREE_RATE ||
+           kind == MCD_PROP_SCALE_NORM_TREE || kind == MCD_PROP_SCALE_VAR_TREE || kind == MCD_PROP_SCALE_VAR_TREE_AUTO ||
+           kind == MCD_PROP_SCALE_CONTRARILY;
+}
+
+__device__ inline StepDraws mh_step_draws(const MhDev& M, int p, double t, const Rng& g)
+{
+    StepDraws d{1.0, 0.0, 0.0, 0.5, 0.5};
+    double ub;
+    const int kind = M.kind[p];
+    if (mh_is_gamma_kind(kind)) {
+        const double p0 = M.p0[p];
+        const double k = p0 / t, th = (kind == MCD_PROP_SCALE_CONTRARILY) ? M.p1[p] * t : t / p0;
+        d.u = gamma_sample(g, k, th);
+        d.lnq = gamma_ratio(k, th, d.u);
+        d.logu = log(d.u);
+    } else {
+        philox_block(g, 0, d.U, ub);
+    }
+    philox_block(g, 0xFFFFFFFFu, d.Uacc, ub);
+    return d;
 }
 
 // Apply proposal row p with tuning parameter t to the state (sc, H, R) of one chain; all 64 lanes active.
 // Writes the proposed heights / rates to H1 / R1 (global memory or LDS), updates sc in place and returns
 // ln (q-ratio * Jacobian) without the root-branch factor (NaN = invalid proposal => reject).
-__device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double t, const Rng& g, int lane, double (&sc)[5],
+__device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double t, const StepDraws& dr, int lane, double (&sc)[5],
                                                   const double* H, const double* R, double* H1, double* R1)
 {
     const int n = M.n_nodes, kind = M.kind[p], v = M.node[p];
@@ -158,12 +190,12 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
     double brace_delta = 0.0;
     switch (kind) {
         case MCD_PROP_SCALE_SCALAR: {
-            const double k = p0 / t, th = t / p0, u = gamma_sample(g, k, th);
+            const double u = dr.u;
 #pragma unroll
             for (int i = 0; i < 5; ++i)
                 if (i == v) sc[i] *= u;
-            lnq = gamma_ratio(k, th, u);
-            lnj = -log(u);
+            lnq = dr.lnq;
+            lnj = -dr.logu;
             break;
         }
         case MCD_PROP_SLIDE_NODE: {
@@ -172,7 +204,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             for (int c = v + 1; c < end; c += M.size[c]) hc = fmax(hc, H[c]);
             const double hp = (v == 0) ? __builtin_huge_val() : H[M.parent[v]];
             double ua, ub, h1;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(H[v], p0, t, hc, hp, ua, h1, lnq);
             pt1 = v;
             pv1 = h1;
@@ -181,7 +214,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
         case MCD_PROP_SCALE_SUBTREE_TIME: {
             const double hp = (v == 0) ? __builtin_huge_val() : H[M.parent[v]];
             double ua, ub, h1;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(H[v], p0, t, 0.0, hp, ua, h1, lnq);
             const double xi = h1 / H[v];
             hlo = v + 1;
@@ -201,7 +235,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             }
             const double a = -fmin(brL, ht - brR), bb = fmin(brR, ht - brL);
             double ua, ub, u;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(0.0, p0, t, a, bb, ua, u, lnq);
             const double hL1 = hL - u, hR1 = hR + u, xiL = hL1 / hL, xiR = hR1 / hR;
             hlo = l + 1; hhi = l + M.size[l]; hmul = xiL; pt1 = l; pv1 = hL1;
@@ -210,31 +245,31 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             break;
         }
         case MCD_PROP_SCALE_BRANCH_RATE: {
-            const double k = p0 / t, th = t / p0, u = gamma_sample(g, k, th);
+            const double u = dr.u;
             rlo = v; rhi = v + 1; rmul = u;
-            lnq = gamma_ratio(k, th, u);
-            lnj = -log(u);
+            lnq = dr.lnq;
+            lnj = -dr.logu;
             break;
         }
         case MCD_PROP_SCALE_SUBTREE_RATE: {
-            const double k = p0 / t, th = t / p0, u = gamma_sample(g, k, th);
+            const double u = dr.u;
             rlo = v; rhi = v + M.size[v]; rmul = u;
-            lnq = gamma_ratio(k, th, u);
-            lnj = (double)(M.n1[p] - 2) * log(u);
+            lnq = dr.lnq;
+            lnj = (double)(M.n1[p] - 2) * dr.logu;
             break;
         }
         case MCD_PROP_SCALE_NORM_TREE: {
-            const double k = p0 / t, th = t / p0, u = gamma_sample(g, k, th);
+            const double u = dr.u;
 #pragma unroll
             for (int i = 0; i < 5; ++i)
                 if (i == v) sc[i] /= u;
             rlo = 1; rhi = n; rmul = u;
-            lnq = gamma_ratio(k, th, u);
-            lnj = (double)((n - 1) - 2 - 1) * log(u);
+            lnq = dr.lnq;
+            lnj = (double)((n - 1) - 2 - 1) * dr.logu;
             break;
         }
         case MCD_PROP_SCALE_VAR_TREE: {
-            const double k = p0 / t, th = t / p0, u = gamma_sample(g, k, th);
+            const double u = dr.u;
             double s = 0.0;
             for (int w = lane; w < n; w += 64) s += (w >= 1) ? R[w] : 0.0;
             s = mh_wave_sum(s);
@@ -243,26 +278,26 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             sc[4] = sc[4] * u * u;
             // (r - mu) u + mu: keep the reference's order of operations
             rlo = 1; rhi = n; rmul = u; radd = mu; rate_positive_guard = true;
-            lnq = gamma_ratio(k, th, u);
+            lnq = dr.lnq;
             lnj = (double)nb * log(u - n1 * u + n1);
             break;
         }
         case MCD_PROP_SCALE_VAR_TREE_AUTO: {
             // The reference recursion y_v = y_parent + u (r_v - r_parent), anchored at rMu for the children of the
             // root, telescopes to y_v = rMu + u (r_v - rMu): one independent expression per lane (equal up to rounding).
-            const double k = p0 / t, th = t / p0, u = gamma_sample(g, k, th);
+            const double u = dr.u;
             sc[4] = sc[4] * u * u;
             rlo = 1; rhi = n; rmul = u; radd = sc[3]; rate_positive_guard = true;
-            lnq = gamma_ratio(k, th, u);
-            lnj = (double)(n - 1) * log(u);
+            lnq = dr.lnq;
+            lnj = (double)(n - 1) * dr.logu;
             break;
         }
         case MCD_PROP_SCALE_CONTRARILY: {
-            const double k = p0 / t, th = M.p1[p] * t, u = gamma_sample(g, k, th);
+            const double u = dr.u;
             sc[2] *= u;
             sc[3] /= u;
-            lnq = gamma_ratio(k, th, u);
-            lnj = -2.0 * log(u);
+            lnq = dr.lnq;
+            lnj = -2.0 * dr.logu;
             break;
         }
         case MCD_PROP_SLIDE_NODE_CONTRA: {   // Contrary.hs:35-77
@@ -271,7 +306,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             for (int c = v + 1; c < end; c += M.size[c]) hc = fmax(hc, H[c]);
             const double hN = H[v], hP = H[M.parent[v]];
             double ua, ub, h1;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(hN, p0, t, hc, hP, ua, h1, lnq);
             pt1 = v;
             pv1 = h1;
@@ -291,7 +327,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
         case MCD_PROP_SCALE_SUBTREE_CONTRA: {   // Contrary.hs:269-326
             const double hN = H[v], hP = H[M.parent[v]];
             double ua, ub, h1;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(hN, p0, t, 0.0, hP, ua, h1, lnq);
             const double xiT = h1 / hN, xiR = 1.0 / xiT, xiStem = (hP - hN) / (hP - h1);
             hlo = v + 1; hhi = v + M.size[v]; hmul = xiT; pt1 = v; pv1 = h1;
@@ -309,7 +346,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             const int l = 1, r = 1 + M.size[1];
             const double ht = sc[2], hL = H[l], hR = H[r];
             double ua, ub, ht1;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(ht, p0, t, ht * fmax(hL, hR), __builtin_huge_val(), ua, ht1, lnq);
             const double u = ht1 / ht;
             const double xil = (1.0 - hL) / (u - hL), xir = (1.0 - hR) / (u - hR);
@@ -323,7 +361,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             const int l = 1, r = 1 + M.size[1];
             const double m = fmax(H[l], H[r]);
             double ua, ub, m1;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(m, p0, t, 0.0, H[0], ua, m1, lnq);
             const double xi = m1 / m;
             hlo = 1; hhi = n; hmul = xi;
@@ -345,7 +384,8 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
                 bb = fmin(bb, H[M.parent[x]] - H[x]);
             }
             double ua, ub;
-            philox_block(g, 0, ua, ub);
+            ua = dr.U;
+            (void)ub;
             tn_sample(0.0, p0, t, a, bb, ua, brace_delta, lnq);
             brace_lo = lo;
             brace_hi = hi;
