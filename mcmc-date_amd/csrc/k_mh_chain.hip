@@ -132,9 +132,17 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
             }
             lj1 = log(1.0 / mh_readlane64(dist, 0));                       // jacobianRootBranch, :393-410
             double d = (dist - mu_l) * iv_l;
-            for (int j = 0; j < n; ++j) {                                  // column sweep of L z = x - mu, row-scaled
-                const double zj = mh_readlane64(d, j);
-                d = fma(-Fs[j * 64 + lane], zj, d);
+            // column sweep of L z = x - mu, row-scaled.  Eight columns per round: their LDS reads are issued together,
+            // then the dependent readlane -> fma chain runs; columns beyond n multiply a zero (z_j = 0 there: exact)
+            for (int j0 = 0; j0 < n; j0 += 8) {
+                double f[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = (j0 + u < n) ? Fs[(j0 + u) * 64 + lane] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double zj = mh_readlane64(d, j0 + u);
+                    d = fma(-f[u], zj, d);
+                }
             }
             const double q = pr_wave_sum(fma(d, d, 0.0));
             ll1 = V.c + (-0.5) * (V.logdet + q);                           // :169
