@@ -193,12 +193,14 @@ int mcd_prior_grad_batch(const mcd_prior_t* p, const double* birth, const double
 #define MCD_PROP_SCALE_BRANCH_RATE 4   /* scaleBranch (Unconstrained.hs:40-66): node; p0 = shape                                 */
 #define MCD_PROP_SCALE_SUBTREE_RATE 5  /* scaleTree on a sub tree (:84-130): node; p0 = shape; n1 = nodes of the sub tree        */
 #define MCD_PROP_SCALE_NORM_TREE 6     /* scaleNormAndTreeContrarily (:221-256): node = 2 (tH) or 3 (rMu); p0 = shape            */
-#define MCD_PROP_SCALE_VAR_TREE 7      /* scaleVarianceAndTree (:286-316): p0 = shape                                            */
+#define MCD_PROP_SCALE_VAR_TREE 7      /* scaleVarianceAndTree (:286-316): p0 = shape; p1 = 1 uses the determinant u^(n-1) as
+                                          Jacobian instead of the reference's (u - u/n + 1/n)^n            */
 #define MCD_PROP_SCALE_VAR_TREE_AUTO 8 /* scaleVarianceAndTreeAutocorrelated (:354-386): p0 = shape                              */
 #define MCD_PROP_SCALE_CONTRARILY 9    /* scaleContrarily k th [mcmc] on (tH, rMu): p0 = k, p1 = th                              */
 #define MCD_PROP_SLIDE_NODE_CONTRA 10  /* slideNodesAtContrarily (Contrary.hs:35-77): node; p0 = sd                              */
 #define MCD_PROP_SCALE_SUBTREE_CONTRA 11 /* scaleSubTreesAtContrarily (:269-326): node; p0 = sd; n1 = inner nodes, n2 = nodes    */
-#define MCD_PROP_SLIDE_ROOT_CONTRA 12  /* slideRootContrarily (:191-223) on (tH, time tree, rate tree): p0 = sd; n1 = inner nodes */
+#define MCD_PROP_SLIDE_ROOT_CONTRA 12  /* slideRootContrarily (:191-223) on (tH, time tree, rate tree): p0 = sd; n1 = exponent of
+                                          1/u in the Jacobian: the reference passes the number of inner nodes INCLUDING the root */
 #define MCD_PROP_SCALE_RATES_TREE_CONTRA 13 /* scaleRatesAndTreeContrarily (:420-446) on (birth rate, rate mean, time tree):
                                           p0 = sd; n1 = inner nodes - 1                                                         */
 #define MCD_PROP_SLIDE_BRACE 14        /* slideBracedNodesUltrametric (Brace.hs:98-156): node = brace index of the prior; p0 = sd */

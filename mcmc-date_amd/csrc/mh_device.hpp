@@ -279,7 +279,9 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             // (r - mu) u + mu: keep the reference's order of operations
             rlo = 1; rhi = n; rmul = u; radd = mu; rate_positive_guard = true;
             lnq = dr.lnq;
-            lnj = (double)nb * log(u - n1 * u + n1);
+            // reference: product of the diagonal of the Jacobian matrix, (u - u/n + 1/n)^n (Unconstrained.hs:321-326);
+            // p1 = 1 selects the determinant u^(n-1) instead (the mean-preserving map has eigenvalues u (n-1 times) and 1)
+            lnj = (M.p1[p] == 1.0) ? (double)(nb - 1) * dr.logu : (double)nb * log(u - n1 * u + n1);
             break;
         }
         case MCD_PROP_SCALE_VAR_TREE_AUTO: {

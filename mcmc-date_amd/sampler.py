@@ -39,7 +39,7 @@ class Proposal:
     kind: int
     node: int = 0
     p0: float = 1.0          # standard deviation or gamma shape
-    p1: float = 1.0
+    p1: float = 0.0          # second parameter (scaleContrarily: gamma scale; scaleVarianceAndTree: 1 = exact Jacobian)
     n1: int = 0
     n2: int = 0
     jac_root: bool = False   # liftProposalWith jacobianRootBranch (the "[R]" proposals)
@@ -91,9 +91,15 @@ def _tables(topo: Topology):
     return size, inner, levels, plen
 
 
-def proposals(topo: Topology, braces: Sequence = (), calibrations_available: bool = False) -> Tuple[List[Proposal], List[str]]:
+def proposals(topo: Topology, braces: Sequence = (), calibrations_available: bool = False,
+              exact_jacobians: bool = False) -> Tuple[List[Proposal], List[str]]:
     """The proposal cycle of `proposals bs calibrationsAvailable x Nothing` (:256-278) in the reference's order.
-    Returns (table, names of reference proposals that are not built yet)."""
+    Returns (table, names of reference proposals that are not built yet).
+
+    exact_jacobians: two proposals of the reference use a Jacobian that is not the determinant of their map (DESIGN.md
+    section 9): scaleVarianceAndTree takes the product of the diagonal, (u - u/n + 1/n)^n instead of u^(n-1), and
+    slideRootContrarily divides by u once more than there are scaled heights.  False (default) restates the reference
+    (parity: same stationary distribution as the reference, small bias included); True uses the determinants."""
     n = topo.n_nodes
     size, inner, levels, plen = _tables(topo)
     leaf = topo.leaves
@@ -133,7 +139,7 @@ def proposals(topo: Topology, braces: Sequence = (), calibrations_available: boo
 
     # proposalsRateTree, :180-201
     ps.append(Proposal("[R] Rate mean, Rate tree", SCALE_NORM_TREE, RATE_MEAN, 100.0, jac_root=True, dim=n, weight=w))
-    ps.append(Proposal("[R] Rate variance, Rate tree", SCALE_VAR_TREE, 0, 100.0, jac_root=True, dim=n, weight=w))
+    ps.append(Proposal("[R] Rate variance, Rate tree", SCALE_VAR_TREE, 0, 100.0, p1=1.0 if exact_jacobians else 0.0, jac_root=True, dim=n, weight=w))
     ps.append(Proposal("[R] Rate variance, Rate tree (autocorrelated)", SCALE_VAR_TREE_AUTO, 0, 100.0, jac_root=True, dim=n, weight=w))
 
     def rate_ps(hn, tag, jac):
@@ -165,7 +171,8 @@ def proposals(topo: Topology, braces: Sequence = (), calibrations_available: boo
         ps.append(Proposal("Time height", SCALE_SCALAR, TIME_HEIGHT, 3000.0, weight=w))
         ps.append(Proposal("Time height, rate mean", SCALE_CONTRARILY, 0, 10.0, 0.1, dim=2, weight=w))
         ps.append(Proposal("[R] Time height, Rate tree", SCALE_NORM_TREE, TIME_HEIGHT, 100.0, jac_root=True, dim=n, weight=w))
-        ps.append(Proposal("[R] Trees", SLIDE_ROOT_CONTRA, 0, 10.0, n1=n_inner, jac_root=True, dim=1 + n_inner + 2, weight=w))
+        ps.append(Proposal("[R] Trees", SLIDE_ROOT_CONTRA, 0, 10.0, n1=n_inner - 1 if exact_jacobians else n_inner, jac_root=True,
+                           dim=1 + n_inner + 2, weight=w))
     return ps, missing
 
 

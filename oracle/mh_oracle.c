@@ -327,7 +327,7 @@ static void propose(const orm_model *M, const int32_t *size, int p, double t, co
                 y->R[w] = (b1 > 0) ? b1 : NAN;
             }
             *lnq = gamma_ratio(k, th, u);
-            *lnj = (double)nb * log(u - n1 * u + n1);
+            *lnj = (M->p1[p] == 1.0) ? (double)(nb - 1) * log(u) : (double)nb * log(u - n1 * u + n1);   /* p1 = 1: the determinant */
             break;
         }
         case ORM_SCALE_VAR_TREE_AUTO: {   /* Unconstrained.hs:354-386: y_v = y_parent + u (r_v - r_parent), root level at rMu */

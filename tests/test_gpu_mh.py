@@ -255,3 +255,45 @@ def test_monitor_files_and_age_summary(gpu, golden, tmp_path):
     summ = MO.summarize_node_ages(tr.ages()[:, 3, :], burn_in=0.25, names=[str(v) for v in range(topo.n_nodes)])
     assert np.all(summ.ci_lower <= summ.mean) and np.all(summ.mean <= summ.ci_upper) and np.all(summ.mean[topo.leaves] == 0)
     assert summ.render().count("\n") == topo.n_nodes + 1
+
+
+def test_device_sampler_recovers_known_marginals(gpu):
+    """Independent of the CPU twin: with a flat likelihood and the root-branch Jacobian lift switched off the chains
+    sample the prior, whose marginals are known in closed form for the uncorrelated gamma clock: rVar ~ gamma(3/2, 1/6)
+    (mean 1/4, variance 1/24) and rMu ~ exponential(1) (mean 1, variance 1); a soft calibration of the root keeps the
+    prior of the time height proper.  A five-leaf tree with a brace lets all sixteen proposal kinds take part,
+    so a wrong ratio or Jacobian in one of them shifts these moments.  The cycle is built with exact_jacobians=True: two
+    Jacobians of the reference are not determinants (tests/test_mh_oracle.py::test_two_reference_jacobians_are_not_
+    determinants) and, restated as they are, move E[rVar] to 0.24 and E[rate of a root child] to 1.03."""
+    import dataclasses
+
+    from mcmc_date_amd import monitor as MO
+
+    # ((a,b),(c,(d,e))): both root children are inner nodes (pulley) and nodes 1 and 6 are braced
+    parent = np.array([-1, 0, 1, 1, 0, 4, 4, 6, 6], np.int32)
+    topo = M.Topology(parent)
+    n = topo.n_nodes - 2
+    lik = M.MvnLikelihood(M.Full(np.full(n, 0.5), np.eye(n) * 1e-12, 0.0)).bind_tree(topo)
+    braces = [M.Brace("b", [1, 6], 0.05)]
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [M.Calibration("root", 0, 0.5, 0.025, 2.0, 0.025)], [], braces, topo)
+    ps, missing = M.proposals(topo, braces, True, exact_jacobians=True)
+    assert missing == []
+    ps = [dataclasses.replace(p, jac_root=False) for p in ps]
+    assert {p.kind for p in ps} == set(range(16))            # every proposal kind takes part
+    B = 512
+    smp = M.Sampler(lik, pf, ps, B, seed=314)
+    smp.set_initial_state(M.State(1.0, 1.0, 1.0, np.array([1.0, 0.5, 0.0, 0.0, 0.8, 0.0, 0.45, 0.0, 0.0]), 1.0, 1.0,
+                                  np.array([0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0])))
+    for period in (50, 50, 100, 100, 200, 200):
+        smp.run(period)
+        smp.autotune()
+    tr = MO.collect(smp, 600, period=20)
+    rvar, rmu = tr.rate_variance.ravel(), tr.rate_mean.ravel()
+    n = rvar.size                                                # 30 samples x 512 chains, chains independent
+    assert abs(rvar.mean() - 0.25) < 0.008 and abs(rvar.var() - 1.0 / 24.0) < 0.005, (rvar.mean(), rvar.var())
+    assert abs(rmu.mean() - 1.0) < 0.04 and abs(rmu.var() - 1.0) < 0.15, (rmu.mean(), rmu.var())
+    r_all = tr.rates[:, :, 1:]
+    assert np.all(np.abs(r_all.mean(axis=(0, 1)) - 1.0) < 0.02), r_all.mean(axis=(0, 1))
+    t, acc, tried = smp.tuning()
+    rate = acc.sum(axis=0) / np.maximum(1, tried.sum(axis=0))
+    assert np.all((rate > 0.05) & (rate < 0.95)), rate     # bounded slides on a three-leaf tree accept often

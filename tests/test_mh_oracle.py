@@ -316,3 +316,45 @@ def test_twin_samples_a_known_target():
     assert abs(rmu.mean() - 1.0) < 0.12, rmu.mean()
     rate = ch.acc.sum(0) / np.maximum(1, ch.tried.sum(0))
     assert np.all((rate > 0.05) & (rate < 0.95))
+
+
+def _prior_chain_moments(ps, n_rounds=500, seed=5):
+    """Flat likelihood, soft calibration of the root, no root-branch lift: the chain samples the prior."""
+    parent = np.array([-1, 0, 1, 1, 0], np.int32)
+    spec = O.PriorSpec(parent, 1.0, "UncorrelatedGamma", [(0, 0.5, 0.025, 2.0, 0.025)], [], [])
+    ps = [dataclasses.replace(p, jac_root=False) for p in ps]
+    model = O.MhModel(parent, np.array([1.0, 0.4, 0.4]), np.eye(3) * 1e-12, 0.0, spec, M.table_arrays(ps))
+    B = 64
+    x0 = M.State(1.0, 1.0, 1.0, np.array([1.0, 0.4, 0.0, 0.0, 0.0]), 1.0, 1.0, np.array([0.0, 1.0, 1.0, 1.0, 1.0]))
+    s = M.StateBatch.from_states([x0] * B)
+    ch = O.MhChains(model, s.time_birth_rate, s.time_death_rate, s.time_height, s.heights, s.rate_mean, s.rate_variance, s.rates, seed=seed)
+    rng = np.random.default_rng(0)
+    for period in (50, 50, 100, 100, 200, 200):
+        ch.run(M.cycle_schedule(ps, period, rng))
+        ch.autotune()
+    rv, rr = [], []
+    for _ in range(n_rounds):
+        ch.run(M.cycle_schedule(ps, 10, rng))
+        rv.append(ch.rVar.copy())
+        rr.append(ch.R[:, [1, 4]].copy())
+    rv, rr = np.array(rv), np.array(rr)
+    return rv.mean(), rv.mean(axis=0).std() / np.sqrt(B), rr.mean(), rr.mean(axis=(0, 2)).std() / np.sqrt(B)
+
+
+def test_two_reference_jacobians_are_not_determinants():
+    """Finding about the reference, kept visible: scaleVarianceAndTree (Unconstrained.hs:321-326) uses the product of
+    the diagonal of its Jacobian matrix, (u - u/n + 1/n)^n, where the determinant of the mean-preserving map is u^(n-1);
+    slideRootContrarily (Contrary.hs:160-170) uses u^-n with n counting the root, where n - 1 heights are divided by u.
+    With a flat likelihood the chain must reproduce the prior: E[rVar] = 1/4 and E[rate] = 1.  The restated reference
+    cycle misses both by many standard errors, the cycle with the determinants (proposals(..., exact_jacobians=True))
+    does not.  The default stays the reference's behaviour (parity)."""
+    topo = M.Topology(np.array([-1, 0, 1, 1, 0], np.int32))
+    ref_cycle, _ = M.proposals(topo, [], True)
+    exact_cycle, _ = M.proposals(topo, [], True, exact_jacobians=True)
+    assert [p.kind for p in ref_cycle] == [p.kind for p in exact_cycle]
+    changed = [(a.kind, a.n1, a.p1, b.n1, b.p1) for a, b in zip(ref_cycle, exact_cycle) if a != b]
+    assert changed == [(SM.SCALE_VAR_TREE, 0, 0.0, 0, 1.0), (SM.SLIDE_ROOT_CONTRA, 2, 0.0, 1, 0.0)]
+    m_ref, se_ref, r_ref, ser_ref = _prior_chain_moments(ref_cycle)
+    m_ex, se_ex, r_ex, ser_ex = _prior_chain_moments(exact_cycle)
+    assert abs(m_ex - 0.25) < 4 * se_ex + 0.002 and abs(r_ex - 1.0) < 4 * ser_ex + 0.004, (m_ex, se_ex, r_ex, ser_ex)
+    assert m_ref < 0.25 - 5 * se_ref and r_ref > 1.0 + 5 * ser_ref, (m_ref, se_ref, r_ref, ser_ref)
