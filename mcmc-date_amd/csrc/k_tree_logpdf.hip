@@ -39,16 +39,18 @@ static hipError_t launch_tree_logpdf_R(const MvnDev& M, const TreeDev& T, const 
                                        const double* tH, const double* rMu, int64_t batch, double* ll, double* logjac,
                                        hipStream_t st)
 {
-    auto go = [&](auto cw_tag) {
-        constexpr int CW = decltype(cw_tag)::value, LW = Cfg<R>::LW;
-        const unsigned grid = (unsigned)((batch + CW - 1) / CW);
-        hipLaunchKernelGGL((k_tree_logpdf<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu,
-                       batch, ll, logjac);
-    };
-    if (pick_geometry(batch).cw == 2)
-        go(std::integral_constant<int, 2>{});
-    else
-        go(std::integral_constant<int, 4>{});
+    const Geometry g = pick_geometry(batch);
+    constexpr int LW = Cfg<R>::LW;
+    if (g.cw == 2) {
+        const unsigned grid = (unsigned)((batch + 1) / 2);
+        hipLaunchKernelGGL((k_tree_logpdf<R, 1, 2, LW>), dim3(grid), dim3(64 * (2 + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch, ll, logjac);
+    } else if (g.bt == 1) {
+        const unsigned grid = (unsigned)((batch + 3) / 4);
+        hipLaunchKernelGGL((k_tree_logpdf<R, 1, 4, LW>), dim3(grid), dim3(64 * (4 + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch, ll, logjac);
+    } else {                                               // large batches: two chains per compute wave share every factor read
+        const unsigned grid = (unsigned)((batch + 7) / 8);
+        hipLaunchKernelGGL((k_tree_logpdf<R, 2, 4, LW>), dim3(grid), dim3(64 * (4 + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch, ll, logjac);
+    }
     return hipGetLastError();
 }
 

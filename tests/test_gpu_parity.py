@@ -224,6 +224,24 @@ def test_synthetic_tree_256(gpu):
         assert abs(out[3][b] - gt) <= 1e-9 * abs(gt) and abs(out[4][b] - gm) <= 1e-9 * abs(gm)
 
 
+def test_tree_large_batch_two_chains_per_wave(gpu):
+    """Tree states: batches above 4096 chains use two chains per compute wave; per chain the same bits as a small batch,
+    and the oracle's values."""
+    topo = S.random_topology(50, seed=7)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=7)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    batch = 4096 + 1500 + 3
+    st = S.random_states(topo, batch, seed=9)
+    tl = M.MvnLikelihood(M.Full(mu, P, logdet)).bind_tree(topo)
+    ll, lj = tl.loglik(st)
+    ll_s, lj_s = tl.loglik(st.slice(batch - 260, batch))
+    assert np.array_equal(ll[-260:], ll_s) and np.array_equal(lj[-260:], lj_s)
+    ref, refj = O.tree_loglik_full_batch(topo.parent, st.heights[-40:], st.rates[-40:], st.time_height[-40:], st.rate_mean[-40:], mu, P, logdet)
+    assert np.max(np.abs(ll[-40:] - ref) / np.abs(ref)) <= 1e-11 and np.max(rel_err(lj[-40:], refj)) <= 1e-12
+
+
 # ------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE sizes
 # ------------------------------------------------------------------------------------------
