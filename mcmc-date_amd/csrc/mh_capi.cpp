@@ -121,6 +121,13 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     if (dev_t != dev_p) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree (device %d) and prior (device %d) live on different GPUs", dev_t, dev_p);
     const int n = m->tree->n_nodes;
     if (m->prior->n_nodes != n) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree has %d nodes, prior %d", n, m->prior->n_nodes);
+    {   // tree and prior must describe the same topology: compare the prior's parent array (device) with the tree's
+        std::vector<int32_t> pp(n);
+        MHIP_TRY(hipSetDevice(dev_p));
+        MHIP_TRY(hipMemcpy(pp.data(), m->prior->parent, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        for (int v = 0; v < n; ++v)
+            if (pp[v] != parent[v]) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree and prior have different topologies (node %d)", v);
+    }
     std::vector<int32_t> size(n, 1);
     for (int v = n - 1; v > 0; --v) size[parent[v]] += size[v];
     // the braces live in the prior's tables (device memory): a host copy for the checks below

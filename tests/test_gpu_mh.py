@@ -192,6 +192,13 @@ def test_rejects_invalid_states_and_tables(gpu, golden):
     fresh = M.Sampler(lik, pf, ps, 4, 0)
     with pytest.raises(M.McdError, match="set_state"):
         fresh.run(1)
+    # a prior built for another topology with the same number of nodes
+    from mcmc_date_amd import synthetic as S
+    other = S.random_topology(12, seed=99)
+    assert other.n_nodes == topo.n_nodes and not np.array_equal(other.parent, topo.parent)
+    pf_other = M.PriorFunction(float(fx["prior_ht"]), "UncorrelatedGamma", [], [], [], other)
+    with pytest.raises(M.McdError, match="different topologies"):
+        M.Sampler(lik, pf_other, ps, 4, 0)
 
 
 def test_posterior_node_ages_within_one_percent(gpu, golden):
