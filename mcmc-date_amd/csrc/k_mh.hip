@@ -23,16 +23,24 @@
 #include <stdint.h>
 
 #include "mh_device.hpp"
+#include "prior_device.hpp"
 
 namespace mcd {
 
-// Writes the proposed state of every chain and ln(q-ratio * Jacobian) without the root-branch factor.
-__global__ __launch_bounds__(256) void k_mh_propose(MhDev M, const int32_t* __restrict__ sched, int64_t sched_idx,
+// Proposes for every chain and evaluates the ln prior of the proposed state in the same launch: the proposed heights and
+// rates are staged in LDS (one region per wave), the prior reads them there, then they go to global memory for the
+// likelihood kernel.  Writes sc1, H1, R1, lnqj (ln q-ratio * Jacobian without the root-branch factor) and post1[0] = ln prior.
+__global__ __launch_bounds__(256) void k_mh_propose(MhDev M, PriorDev P, const int32_t* __restrict__ sched, int64_t sched_idx,
                                                     uint64_t step, uint64_t seed)
 {
+    extern __shared__ double sh[];
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= M.batch) return;
+    const int wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= M.batch) return;                             // wave-uniform; no workgroup barriers in this kernel
+    const int n = M.n_nodes;
+    double* Hs = sh + (size_t)wave * 2 * n;
+    double* Rs = Hs + n;
     const int p = sched[sched_idx];
     const int64_t B = M.batch;
     double sc[5];
@@ -40,7 +48,13 @@ __global__ __launch_bounds__(256) void k_mh_propose(MhDev M, const int32_t* __re
     for (int i = 0; i < 5; ++i) sc[i] = M.sc[i * B + b];
     const double t = M.tune[b * M.n_prop + p];
     const StepDraws dr = mh_step_draws(M, p, t, mh_rng(seed, M.chain0 + b, step));
-    const double lnqj = mh_propose_wave(M, p, t, dr, lane, sc, M.H + b * M.ld, M.R + b * M.ld, M.H1 + b * M.ld, M.R1 + b * M.ld);
+    const double lnqj = mh_propose_wave(M, p, t, dr, lane, sc, M.H + b * M.ld, M.R + b * M.ld, Hs, Rs);
+    __builtin_amdgcn_wave_barrier();
+    const double lp1 = prior_eval_wave(P, lane, sc[0], sc[1], sc[2], sc[3], sc[4], Hs, Rs, nullptr);
+    for (int w = lane; w < n; w += 64) {
+        M.H1[b * M.ld + w] = Hs[w];
+        M.R1[b * M.ld + w] = Rs[w];
+    }
     if (lane < 5) {
         double mine = sc[0];
 #pragma unroll
@@ -48,7 +62,10 @@ __global__ __launch_bounds__(256) void k_mh_propose(MhDev M, const int32_t* __re
             if (lane == i) mine = sc[i];
         M.sc1[lane * B + b] = mine;
     }
-    if (lane == 0) M.lnqj[b] = lnqj;
+    if (lane == 0) {
+        M.lnqj[b] = lnqj;
+        M.post1[b] = lp1;
+    }
 }
 
 // Accept or reject; post = (ln prior, ln likelihood, ln jacobianRootBranch), [3][batch].
@@ -120,10 +137,15 @@ __global__ __launch_bounds__(256) void k_mh_tune(MhDev M)
     M.tried[i] = 0;
 }
 
-hipError_t launch_mh_propose(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed, hipStream_t st)
+hipError_t launch_mh_propose(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
+                             hipStream_t st)
 {
-    const int wpb = 4;
-    hipLaunchKernelGGL(k_mh_propose, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), 0, st, M, sched, sched_idx, step, seed);
+    const size_t per_wave = sizeof(double) * 2 * (size_t)M.n_nodes;
+    int wpb = 4;
+    while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;
+    if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_mh_propose, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, sched, sched_idx,
+                       step, seed);
     return hipGetLastError();
 }
 hipError_t launch_mh_accept(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,

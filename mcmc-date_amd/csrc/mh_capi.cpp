@@ -1,6 +1,7 @@
 // mh_capi.cpp -- C ABI of the lock-step Metropolis-Hastings-Green driver (include/mcmcdate_mvn.h, "mcd_mh_*").
-// One step = propose (k_mh.hip) -> batched prior (k_prior.hip) -> batched likelihood + root-branch Jacobian
-// (k_tree_logpdf.hip) -> accept (k_mh.hip), all enqueued on one stream; the state stays on the device.  No CPU path.
+// Trees of at most 64 nodes: the whole schedule in one launch (k_mh_chain.hip).  Larger trees, per step: propose + ln prior
+// (k_mh.hip) -> batched likelihood + root-branch Jacobian (k_tree_logpdf.hip) -> accept (k_mh.hip), enqueued on one
+// stream; the state stays on the device.  No CPU path.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -341,8 +342,9 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
     for (int64_t it = 0; it < (m->chain_kernel ? 0 : n_iter); ++it) {
         for (int s = 0; s < S; ++s) {
             const int64_t gs = it * S + s;
-            MHIP_TRY(mcd::launch_mh_propose(D, m->d_sched, gs, m->step, m->seed, m->stream));
-            if (int rc = eval_posterior(m, D.sc1, D.H1, D.R1, D.post1)) return rc;
+            MHIP_TRY(mcd::launch_mh_propose(D, *m->prior, m->d_sched, gs, m->step, m->seed, m->stream));   // + ln prior -> post1[0]
+            MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
+                                             D.post1 + D.batch, D.post1 + 2 * D.batch, m->stream));
             MHIP_TRY(mcd::launch_mh_accept(D, m->d_sched, gs, m->step, m->seed, trace ? m->d_trace_alpha + gs * B : nullptr,
                                            trace ? m->d_trace_accept + gs * B : nullptr, m->stream));
             m->step += 1;

@@ -91,7 +91,8 @@ hipError_t launch_prior_grad(const PriorDev& P, const double* birth, const doubl
                              const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
                              double* g_birth, double* g_death, double* g_tH, double* g_H, double* g_rMu, double* g_rVar, double* g_R,
                              hipStream_t st);
-hipError_t launch_mh_propose(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed, hipStream_t st);
+hipError_t launch_mh_propose(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
+                             hipStream_t st);   // propose + ln prior of the proposed state
 hipError_t launch_mh_accept(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
                             double* trace_alpha, int8_t* trace_accept, hipStream_t st);
 hipError_t launch_mh_accumulate(const MhDev& M, hipStream_t st);
