@@ -1,7 +1,7 @@
 // k_mh.hip -- lock-step Metropolis-Hastings-Green steps for a batch of independent chains (gfx950).
 // SURVEY.md 8(f) row f2.  All chains execute the same proposal of the cycle at the same time, each with its own
 // counter-based random numbers, tuning parameter and accept/reject decision; the posterior of the proposed states
-// is evaluated by the batched prior and likelihood kernels between `mh_propose` and `mh_accept`.
+// is evaluated by the prior code inside `k_mh_step` and by the batched likelihood kernel between two `k_mh_step` launches.
 //
 // Proposals restated here (paths relative to the reference):
 //   slide node / scale sub tree / pulley, ultrametric   lib/Mcmc/Tree/Proposal/Ultrametric.hs:50-59, 126-149, 221-286
@@ -27,11 +27,17 @@
 
 namespace mcd {
 
-// Proposes for every chain and evaluates the ln prior of the proposed state in the same launch: the proposed heights and
-// rates are staged in LDS (one region per wave), the prior reads them there, then they go to global memory for the
-// likelihood kernel.  Writes sc1, H1, R1, lnqj (ln q-ratio * Jacobian without the root-branch factor) and post1[0] = ln prior.
-__global__ __launch_bounds__(256) void k_mh_propose(MhDev M, PriorDev P, const int32_t* __restrict__ sched, int64_t sched_idx,
-                                                    uint64_t step, uint64_t seed)
+// One launch between two likelihood launches: ACCEPT step `idx_acc` (its proposed state, ln prior, ln likelihood and
+// ln jacobianRootBranch are in H1/R1/sc1/post1) and PROPOSE step `idx_prop` together with the ln prior of its proposed
+// state.  Either half is skipped with a negative index (first / last launch of a run).  One wave per chain; the current
+// and the proposed heights and rates are staged in LDS (one region per wave), so no lane ever reads through global memory
+// what another lane of its wave has just written.
+//   accept:  post = (ln prior, ln likelihood, ln jacobianRootBranch), [3][batch]; counters; optional trace; running sums
+//            of the absolute node ages tH * h_v when the step closes an iteration (`accumulate_now`)
+//   propose: writes sc1, H1, R1, lnqj (ln q-ratio * Jacobian without the root-branch factor), post1[0] = ln prior
+__global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, const int32_t* __restrict__ sched, int64_t idx_acc,
+                                                 int64_t idx_prop, uint64_t step_acc, uint64_t seed, int accumulate_now,
+                                                 double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
 {
     extern __shared__ double sh[];
     const int lane = threadIdx.x & 63;
@@ -39,16 +45,67 @@ __global__ __launch_bounds__(256) void k_mh_propose(MhDev M, PriorDev P, const i
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (b >= M.batch) return;                             // wave-uniform; no workgroup barriers in this kernel
     const int n = M.n_nodes;
-    double* Hs = sh + (size_t)wave * 2 * n;
-    double* Rs = Hs + n;
-    const int p = sched[sched_idx];
     const int64_t B = M.batch;
+    double* Hc = sh + (size_t)wave * 4 * n;
+    double* Rc = Hc + n;
+    double* Hs = Rc + n;
+    double* Rs = Hs + n;
+    bool ok = false;
+    if (idx_acc >= 0) {
+        const int p = sched[idx_acc];
+        const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
+        const double lp1 = M.post1[b], ll1 = M.post1[B + b], lj1 = M.post1[2 * B + b];
+        double la = (lp1 + ll1) - (lp + ll) + M.lnqj[b];
+        if (M.jac_root[p]) la += lj1 - lj;
+        double ua, ub;
+        philox_block(mh_rng(seed, M.chain0 + b, step_acc), 0xFFFFFFFFu, ua, ub);
+        ok = (la >= 0) || (ua < exp(la));
+        if (lane == 0) {
+            const int64_t i = b * M.n_prop + p;
+            M.tried[i] += 1;
+            if (ok) M.acc[i] += 1;
+            if (trace_alpha) trace_alpha[b] = la;
+            if (trace_accept) trace_accept[b] = ok ? 1 : 0;
+        }
+    }
+    // the current state after the decision, into LDS (and back to global memory when it changed)
+    const double* Hsrc = (ok ? M.H1 : M.H) + b * M.ld;
+    const double* Rsrc = (ok ? M.R1 : M.R) + b * M.ld;
+    for (int w = lane; w < n; w += 64) {
+        const double h = Hsrc[w], r = Rsrc[w];
+        Hc[w] = h;
+        Rc[w] = r;
+        if (ok) {
+            M.H[b * M.ld + w] = h;
+            M.R[b * M.ld + w] = r;
+        }
+    }
     double sc[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) sc[i] = M.sc[i * B + b];
+    for (int i = 0; i < 5; ++i) sc[i] = (ok ? M.sc1 : M.sc)[i * B + b];
+    if (ok) {
+        if (lane < 5) {
+            double mine = sc[0];
+#pragma unroll
+            for (int i = 1; i < 5; ++i)
+                if (lane == i) mine = sc[i];
+            M.sc[lane * B + b] = mine;
+        }
+        if (lane < 3) M.post[lane * B + b] = M.post1[lane * B + b];
+    }
+    if (accumulate_now) {
+        for (int w = lane; w < n; w += 64) {
+            const double a = sc[2] * Hc[w];
+            M.age_sum[b * n + w] += a;
+            M.age_sq[b * n + w] += a * a;
+        }
+    }
+    if (idx_prop < 0) return;
+    __builtin_amdgcn_wave_barrier();
+    const int p = sched[idx_prop];
     const double t = M.tune[b * M.n_prop + p];
-    const StepDraws dr = mh_step_draws(M, p, t, mh_rng(seed, M.chain0 + b, step));
-    const double lnqj = mh_propose_wave(M, p, t, dr, lane, sc, M.H + b * M.ld, M.R + b * M.ld, Hs, Rs);
+    const StepDraws dr = mh_step_draws(M, p, t, mh_rng(seed, M.chain0 + b, step_acc + 1));
+    const double lnqj = mh_propose_wave(M, p, t, dr, lane, sc, Hc, Rc, Hs, Rs);
     __builtin_amdgcn_wave_barrier();
     const double lp1 = prior_eval_wave(P, lane, sc[0], sc[1], sc[2], sc[3], sc[4], Hs, Rs, nullptr);
     for (int w = lane; w < n; w += 64) {
@@ -66,57 +123,6 @@ __global__ __launch_bounds__(256) void k_mh_propose(MhDev M, PriorDev P, const i
         M.lnqj[b] = lnqj;
         M.post1[b] = lp1;
     }
-}
-
-// Accept or reject; post = (ln prior, ln likelihood, ln jacobianRootBranch), [3][batch].
-__global__ __launch_bounds__(256) void k_mh_accept(MhDev M, const int32_t* __restrict__ sched, int64_t sched_idx,
-                                                   uint64_t step, uint64_t seed, double* __restrict__ trace_alpha,
-                                                   int8_t* __restrict__ trace_accept)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= M.batch) return;
-    const int p = sched[sched_idx];
-    const int64_t B = M.batch;
-    const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
-    const double lp1 = M.post1[b], ll1 = M.post1[B + b], lj1 = M.post1[2 * B + b];
-    double la = (lp1 + ll1) - (lp + ll) + M.lnqj[b];
-    if (M.jac_root[p]) la += lj1 - lj;
-    double ua, ub;
-    philox_block(mh_rng(seed, M.chain0 + b, step), 0xFFFFFFFFu, ua, ub);
-    const bool ok = (la >= 0) || (ua < exp(la));
-    if (ok) {
-        const double* H1 = M.H1 + b * M.ld;
-        const double* R1 = M.R1 + b * M.ld;
-        double* H = M.H + b * M.ld;
-        double* R = M.R + b * M.ld;
-        for (int w = lane; w < M.n_nodes; w += 64) {
-            H[w] = H1[w];
-            R[w] = R1[w];
-        }
-        if (lane < 5) M.sc[lane * B + b] = M.sc1[lane * B + b];
-        if (lane < 3) M.post[lane * B + b] = M.post1[lane * B + b];
-    }
-    if (lane == 0) {
-        const int64_t i = b * M.n_prop + p;
-        M.tried[i] += 1;
-        if (ok) M.acc[i] += 1;
-        if (trace_alpha) trace_alpha[b] = la;
-        if (trace_accept) trace_accept[b] = ok ? 1 : 0;
-    }
-}
-
-// After every iteration: running sums of the absolute node ages tH * h_v (the quantity the reference's
-// node-age summaries report, scripts/trees-monitor-summary-ultrametric).
-__global__ __launch_bounds__(256) void k_mh_accumulate(MhDev M)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M.batch * M.n_nodes) return;
-    const int64_t b = i / M.n_nodes;
-    const int v = (int)(i - b * M.n_nodes);
-    const double a = M.sc[2 * M.batch + b] * M.H[b * M.ld + v];
-    M.age_sum[b * M.n_nodes + v] += a;
-    M.age_sq[b * M.n_nodes + v] += a * a;
 }
 
 // mcmc's auto tuning [external]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3); counters reset.
@@ -137,29 +143,15 @@ __global__ __launch_bounds__(256) void k_mh_tune(MhDev M)
     M.tried[i] = 0;
 }
 
-hipError_t launch_mh_propose(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
-                             hipStream_t st)
+hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t idx_acc, int64_t idx_prop, uint64_t step_acc,
+                          uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
 {
-    const size_t per_wave = sizeof(double) * 2 * (size_t)M.n_nodes;
+    const size_t per_wave = sizeof(double) * 4 * (size_t)M.n_nodes;
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;
     if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_mh_propose, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, sched, sched_idx,
-                       step, seed);
-    return hipGetLastError();
-}
-hipError_t launch_mh_accept(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
-                            double* trace_alpha, int8_t* trace_accept, hipStream_t st)
-{
-    const int wpb = 4;
-    hipLaunchKernelGGL(k_mh_accept, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), 0, st, M, sched, sched_idx, step, seed,
-                       trace_alpha, trace_accept);
-    return hipGetLastError();
-}
-hipError_t launch_mh_accumulate(const MhDev& M, hipStream_t st)
-{
-    const int64_t n = M.batch * M.n_nodes;
-    hipLaunchKernelGGL(k_mh_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_mh_step, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, sched, idx_acc, idx_prop,
+                       step_acc, seed, accumulate_now, trace_alpha, trace_accept);
     return hipGetLastError();
 }
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st)

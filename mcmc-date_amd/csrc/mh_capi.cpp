@@ -1,7 +1,7 @@
 // mh_capi.cpp -- C ABI of the lock-step Metropolis-Hastings-Green driver (include/mcmcdate_mvn.h, "mcd_mh_*").
-// Trees of at most 64 nodes: the whole schedule in one launch (k_mh_chain.hip).  Larger trees, per step: propose + ln prior
-// (k_mh.hip) -> batched likelihood + root-branch Jacobian (k_tree_logpdf.hip) -> accept (k_mh.hip), enqueued on one
-// stream; the state stays on the device.  No CPU path.
+// Trees of at most 64 nodes: the whole schedule in one launch (k_mh_chain.hip).  Larger trees, two launches per step:
+// [accept the previous step + propose + ln prior] (k_mh.hip) and [batched likelihood + root-branch Jacobian]
+// (k_tree_logpdf.hip), enqueued on one stream; the state stays on the device.  No CPU path.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -339,19 +339,20 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         m->step += steps;
         if (accumulate) m->n_samples += n_iter;
     }
-    for (int64_t it = 0; it < (m->chain_kernel ? 0 : n_iter); ++it) {
-        for (int s = 0; s < S; ++s) {
-            const int64_t gs = it * S + s;
-            MHIP_TRY(mcd::launch_mh_propose(D, *m->prior, m->d_sched, gs, m->step, m->seed, m->stream));   // + ln prior -> post1[0]
+    if (!m->chain_kernel) {
+        // two launches per step: [accept step s-1 + propose step s + ln prior] and [likelihood + root-branch Jacobian]
+        const int64_t total = (int64_t)steps;
+        if ((size_t)D.n_nodes * 32 > 64 * 1024) return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_run: more than 2048 nodes");
+        MHIP_TRY(mcd::launch_mh_step(D, *m->prior, m->d_sched, -1, 0, m->step - 1, m->seed, 0, nullptr, nullptr, m->stream));
+        for (int64_t gs = 0; gs < total; ++gs) {
             MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
                                              D.post1 + D.batch, D.post1 + 2 * D.batch, m->stream));
-            MHIP_TRY(mcd::launch_mh_accept(D, m->d_sched, gs, m->step, m->seed, trace ? m->d_trace_alpha + gs * B : nullptr,
-                                           trace ? m->d_trace_accept + gs * B : nullptr, m->stream));
+            const bool closes = ((gs + 1) % S) == 0;
+            MHIP_TRY(mcd::launch_mh_step(D, *m->prior, m->d_sched, gs, (gs + 1 < total) ? gs + 1 : -1, m->step, m->seed,
+                                         (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
+                                         trace ? m->d_trace_accept + gs * B : nullptr, m->stream));
             m->step += 1;
-        }
-        if (accumulate) {
-            MHIP_TRY(mcd::launch_mh_accumulate(D, m->stream));
-            m->n_samples += 1;
+            if (accumulate && closes) m->n_samples += 1;
         }
     }
     if (trace_alpha) MHIP_TRY(hipMemcpyAsync(trace_alpha, m->d_trace_alpha, sizeof(double) * steps * B, hipMemcpyDeviceToHost, m->stream));

@@ -91,11 +91,9 @@ hipError_t launch_prior_grad(const PriorDev& P, const double* birth, const doubl
                              const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
                              double* g_birth, double* g_death, double* g_tH, double* g_H, double* g_rMu, double* g_rVar, double* g_R,
                              hipStream_t st);
-hipError_t launch_mh_propose(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
-                             hipStream_t st);   // propose + ln prior of the proposed state
-hipError_t launch_mh_accept(const MhDev& M, const int32_t* sched, int64_t sched_idx, uint64_t step, uint64_t seed,
-                            double* trace_alpha, int8_t* trace_accept, hipStream_t st);
-hipError_t launch_mh_accumulate(const MhDev& M, hipStream_t st);
+// accept step idx_acc (< 0: none) and propose step idx_prop (< 0: none) with the ln prior of its proposed state
+hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t idx_acc, int64_t idx_prop, uint64_t step_acc,
+                          uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
 // whole schedule in one launch (k_mh_chain.hip); needs n_nodes <= 64 and mh_chain_lds_bytes(...) <= 64 KB
 size_t mh_chain_lds_bytes(int n, int n_prop, int wpb);
