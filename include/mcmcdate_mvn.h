@@ -178,6 +178,29 @@ int mcd_prior_grad_batch(const mcd_prior_t* p, const double* birth, const double
                          int64_t ld_state, int64_t batch, int on_device, void* stream, double* lp, double* g_birth,
                          double* g_death, double* g_tH, double* g_heights, double* g_rMu, double* g_rVar, double* g_rates);
 
+/*
+ * Leapfrog integrator of the Hamiltonian proposal on the device (second part).  Potential
+ * U(q) = -ln [prior x likelihood x jacobianRootBranch] (`htargetWith`, app/Hamiltonian.hs:72-92); the position q is the
+ * masked, reversed fold of the state (`getMask`, `toVector`, :33-53): root height, leaf heights and the rate stem are
+ * fixed, the time height moves only when calibrations are available.  The state of `batch` chains lives on the device;
+ *   mcd_hmc_set_state      host state in, evaluates ln target and its gradient
+ *   mcd_hmc_get_position   q [batch][dim], ln target [batch], gradient [batch][dim] of the current state (any may be NULL)
+ *   mcd_hmc_leapfrog       n_steps leapfrog steps with per-chain step size eps[b], per-chain direction dir[b] = +-1 (NULL
+ *                          = forward) and diagonal inverse masses inv_mass[dim]; p [batch][dim] in/out (host)
+ * A state that leaves the support gets NaN gradients; its momentum and ln target turn NaN (the caller rejects).
+ * The NUTS recursion and its tuning (package `mcmc`) are the caller's: they are not part of this library yet.
+ */
+typedef struct mcd_hmc mcd_hmc_t;
+int mcd_hmc_create(mcd_hmc_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int calibrations_available, int64_t batch);
+void mcd_hmc_destroy(mcd_hmc_t* m);
+int mcd_hmc_dim(const mcd_hmc_t* m);
+int mcd_hmc_set_state(mcd_hmc_t* m, const double* birth, const double* death, const double* tH, const double* heights,
+                      const double* rMu, const double* rVar, const double* rates, int64_t ld_state);
+int mcd_hmc_get_state(const mcd_hmc_t* m, double* birth, double* death, double* tH, double* heights, double* rMu,
+                      double* rVar, double* rates, int64_t ld_state);
+int mcd_hmc_get_position(const mcd_hmc_t* m, double* q, double* value, double* grad);
+int mcd_hmc_leapfrog(mcd_hmc_t* m, double* p, const double* eps, const double* dir, const double* inv_mass, int n_steps);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched Metropolis-Hastings-Green driver (FIRST SLICE).  `mcmc`'s `mhg` evaluates one state
  * per call (app/Main.hs:474); here `batch` independent chains execute the same proposal of the cycle at the same

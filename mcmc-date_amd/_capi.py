@@ -52,6 +52,13 @@ SYMBOLS = {
     "mcd_prior_destroy": (None, [_vp]),
     "mcd_prior_logprior_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "mcd_prior_grad_batch": (C.c_int, [_vp] * 8 + [C.c_int64, C.c_int64, C.c_int, _vp] + [_vp] * 8),
+    "mcd_hmc_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, C.c_int64]),
+    "mcd_hmc_destroy": (None, [_vp]),
+    "mcd_hmc_dim": (C.c_int, [_vp]),
+    "mcd_hmc_set_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64]),
+    "mcd_hmc_get_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64]),
+    "mcd_hmc_get_position": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "mcd_hmc_leapfrog": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.c_int]),
     "mcd_mh_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
     "mcd_mh_destroy": (None, [_vp]),
     "mcd_mh_set_chain_offset": (C.c_int, [_vp, C.c_int64]),

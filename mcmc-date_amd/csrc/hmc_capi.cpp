@@ -1,0 +1,233 @@
+// hmc_capi.cpp -- C ABI of the device leapfrog (include/mcmcdate_mvn.h, "mcd_hmc_*").  The state of `batch` chains, their
+// momenta and gradients stay on the device; one leapfrog step = kick, drift (k_hmc.hip), prior gradient (k_prior_grad.hip),
+// likelihood gradient (k_tree_grad.hip).  No CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "../../include/mcmcdate_mvn.h"
+#include "mvn_kernels.h"
+
+extern "C" int mcd_set_last_error_(int code, const char* msg);   // mvn_capi.cpp
+
+namespace {
+
+int hfail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return mcd_set_last_error_(code, buf);
+}
+
+#define HHIP_TRY(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return hfail(MCD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+}  // namespace
+
+struct mcd_hmc {
+    int device = 0;
+    const mcd::MvnDev* mvn = nullptr;
+    const mcd::TreeDev* tree = nullptr;
+    const mcd::PriorDev* prior = nullptr;
+    mcd::HmcDev dev{};
+    double *d_eps = nullptr, *d_dir = nullptr, *d_inv_mass = nullptr;
+    bool have_state = false;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+
+    ~mcd_hmc()
+    {
+        (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+template <class T>
+int halloc(mcd_hmc* m, T** p, size_t count)
+{
+    *p = nullptr;
+    HHIP_TRY(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+    m->allocs.push_back(*p);
+    HHIP_TRY(hipMemset(*p, 0, sizeof(T) * (count ? count : 1)));
+    return MCD_OK;
+}
+
+// ln target and its gradient at the current state: two batched gradient launches
+int eval_gradients(mcd_hmc* m)
+{
+    const mcd::HmcDev& D = m->dev;
+    const int64_t B = D.batch;
+    HHIP_TRY(mcd::launch_prior_grad(*m->prior, D.sc, D.sc + B, D.sc + 2 * B, D.H, D.sc + 3 * B, D.sc + 4 * B, D.R, D.ld, B, D.lp, D.gp_sc,
+                                    D.gp_sc + B, D.gp_sc + 2 * B, D.gp_H, D.gp_sc + 3 * B, D.gp_sc + 4 * B, D.gp_R, m->stream));
+    HHIP_TRY(mcd::launch_tree_grad(*m->mvn, *m->tree, D.H, D.R, D.ld, D.sc + 2 * B, D.sc + 3 * B, B, D.ll, D.gl_H, D.gl_R, D.gl_tH, D.gl_rMu,
+                                   m->stream));
+    return MCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcd_hmc_create(mcd_hmc_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int calibrations_available, int64_t batch)
+{
+    if (!out) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_create: out is NULL");
+    *out = nullptr;
+    if (!tree || !prior) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_create: NULL tree or prior handle");
+    if (batch <= 0) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_create: batch must be positive");
+    std::unique_ptr<mcd_hmc> m(new mcd_hmc());
+    int dev_t = 0, dev_p = 0;
+    const int32_t* parent = nullptr;
+    const double* host_L = nullptr;
+    if (mcd_tree_internal_(tree, &m->mvn, &m->tree, &dev_t, &parent, &host_L) || mcd_prior_internal_(prior, &m->prior, &dev_p))
+        return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_create: invalid handle");
+    if (dev_t != dev_p) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_create: tree and prior live on different GPUs");
+    const int n = m->tree->n_nodes;
+    if (m->prior->n_nodes != n) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_create: tree has %d nodes, prior %d", n, m->prior->n_nodes);
+    // getMask (app/Hamiltonian.hs:33-47) in fold order of the state record, then toVector's reverse order (:49-53)
+    std::vector<char> leaf(n, 1);
+    for (int v = 1; v < n; ++v) leaf[parent[v]] = 0;
+    std::vector<int32_t> field, index;
+    auto push = [&](int f, int v) {
+        field.push_back(f);
+        index.push_back(v);
+    };
+    push(0, 0);
+    push(1, 0);
+    if (calibrations_available) push(2, 0);
+    for (int v = 1; v < n; ++v)
+        if (!leaf[v]) push(3, v);                 // root height and leaf heights are masked
+    push(4, 0);
+    push(5, 0);
+    for (int v = 1; v < n; ++v) push(6, v);       // the stem of the rate tree is masked
+    std::vector<int32_t> rf(field.rbegin(), field.rend()), ri(index.rbegin(), index.rend());
+    const int dim = (int)rf.size();
+    m->device = dev_t;
+    HHIP_TRY(hipSetDevice(m->device));
+    HHIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    mcd::HmcDev& D = m->dev;
+    D.n_nodes = n;
+    D.dim = dim;
+    D.root_right = m->tree->root_right;
+    D.batch = batch;
+    D.ld = (n + 7) / 8 * 8;
+    const size_t B = (size_t)batch, BL = B * (size_t)D.ld, BD = B * (size_t)dim;
+    int32_t *pf = nullptr, *pi = nullptr;
+    int rc = MCD_OK;
+    if ((rc = halloc(m.get(), &pf, (size_t)dim)) || (rc = halloc(m.get(), &pi, (size_t)dim)) || (rc = halloc(m.get(), &D.sc, 5 * B)) ||
+        (rc = halloc(m.get(), &D.H, BL)) || (rc = halloc(m.get(), &D.R, BL)) || (rc = halloc(m.get(), &D.lp, B)) ||
+        (rc = halloc(m.get(), &D.gp_sc, 5 * B)) || (rc = halloc(m.get(), &D.gp_H, BL)) || (rc = halloc(m.get(), &D.gp_R, BL)) ||
+        (rc = halloc(m.get(), &D.ll, B)) || (rc = halloc(m.get(), &D.gl_H, BL)) || (rc = halloc(m.get(), &D.gl_R, BL)) ||
+        (rc = halloc(m.get(), &D.gl_tH, B)) || (rc = halloc(m.get(), &D.gl_rMu, B)) || (rc = halloc(m.get(), &D.q, BD)) ||
+        (rc = halloc(m.get(), &D.p, BD)) || (rc = halloc(m.get(), &D.grad, BD)) || (rc = halloc(m.get(), &D.value, B)) ||
+        (rc = halloc(m.get(), &m->d_eps, B)) || (rc = halloc(m.get(), &m->d_dir, B)) || (rc = halloc(m.get(), &m->d_inv_mass, (size_t)dim)))
+        return rc;
+    HHIP_TRY(hipMemcpy(pf, rf.data(), sizeof(int32_t) * dim, hipMemcpyHostToDevice));
+    HHIP_TRY(hipMemcpy(pi, ri.data(), sizeof(int32_t) * dim, hipMemcpyHostToDevice));
+    D.pos_field = pf;
+    D.pos_index = pi;
+    D.eps = m->d_eps;
+    D.dir = m->d_dir;
+    D.inv_mass = m->d_inv_mass;
+    *out = m.release();
+    return MCD_OK;
+}
+
+void mcd_hmc_destroy(mcd_hmc_t* m) { delete m; }
+
+int mcd_hmc_dim(const mcd_hmc_t* m) { return m ? m->dev.dim : hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_dim: NULL handle"); }
+
+int mcd_hmc_set_state(mcd_hmc_t* m, const double* birth, const double* death, const double* tH, const double* heights,
+                      const double* rMu, const double* rVar, const double* rates, int64_t ld_state)
+{
+    if (!m || !birth || !death || !tH || !heights || !rMu || !rVar || !rates) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_set_state: NULL argument");
+    mcd::HmcDev& D = m->dev;
+    if (ld_state < D.n_nodes) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_set_state: ld_state < n_nodes");
+    HHIP_TRY(hipSetDevice(m->device));
+    const size_t B = (size_t)D.batch;
+    const double* src[5] = {birth, death, tH, rMu, rVar};
+    for (int i = 0; i < 5; ++i) HHIP_TRY(hipMemcpyAsync(D.sc + i * B, src[i], sizeof(double) * B, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpy2DAsync(D.H, sizeof(double) * D.ld, heights, sizeof(double) * ld_state, sizeof(double) * D.n_nodes, B, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpy2DAsync(D.R, sizeof(double) * D.ld, rates, sizeof(double) * ld_state, sizeof(double) * D.n_nodes, B, hipMemcpyHostToDevice, m->stream));
+    if (int rc = eval_gradients(m)) return rc;
+    HHIP_TRY(mcd::launch_hmc_collect(D, m->stream));
+    HHIP_TRY(hipStreamSynchronize(m->stream));
+    m->have_state = true;
+    return MCD_OK;
+}
+
+int mcd_hmc_get_state(const mcd_hmc_t* cm, double* birth, double* death, double* tH, double* heights, double* rMu, double* rVar,
+                      double* rates, int64_t ld_state)
+{
+    if (!cm || !birth || !death || !tH || !heights || !rMu || !rVar || !rates) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_get_state: NULL argument");
+    const mcd::HmcDev& D = cm->dev;
+    if (ld_state < D.n_nodes) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_get_state: ld_state < n_nodes");
+    HHIP_TRY(hipSetDevice(cm->device));
+    HHIP_TRY(hipStreamSynchronize(cm->stream));
+    const size_t B = (size_t)D.batch;
+    double* dst[5] = {birth, death, tH, rMu, rVar};
+    for (int i = 0; i < 5; ++i) HHIP_TRY(hipMemcpy(dst[i], D.sc + i * B, sizeof(double) * B, hipMemcpyDeviceToHost));
+    HHIP_TRY(hipMemcpy2D(heights, sizeof(double) * ld_state, D.H, sizeof(double) * D.ld, sizeof(double) * D.n_nodes, B, hipMemcpyDeviceToHost));
+    HHIP_TRY(hipMemcpy2D(rates, sizeof(double) * ld_state, D.R, sizeof(double) * D.ld, sizeof(double) * D.n_nodes, B, hipMemcpyDeviceToHost));
+    return MCD_OK;
+}
+
+int mcd_hmc_get_position(const mcd_hmc_t* cm, double* q, double* value, double* grad)
+{
+    if (!cm) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_get_position: NULL handle");
+    if (!cm->have_state) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_get_position: call mcd_hmc_set_state first");
+    const mcd::HmcDev& D = cm->dev;
+    HHIP_TRY(hipSetDevice(cm->device));
+    HHIP_TRY(hipStreamSynchronize(cm->stream));
+    const size_t B = (size_t)D.batch, BD = B * (size_t)D.dim;
+    if (q) HHIP_TRY(hipMemcpy(q, D.q, sizeof(double) * BD, hipMemcpyDeviceToHost));
+    if (value) HHIP_TRY(hipMemcpy(value, D.value, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (grad) HHIP_TRY(hipMemcpy(grad, D.grad, sizeof(double) * BD, hipMemcpyDeviceToHost));
+    return MCD_OK;
+}
+
+int mcd_hmc_leapfrog(mcd_hmc_t* m, double* p, const double* eps, const double* dir, const double* inv_mass, int n_steps)
+{
+    if (!m || !p || !eps || !inv_mass) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_leapfrog: NULL argument");
+    if (!m->have_state) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_leapfrog: call mcd_hmc_set_state first");
+    if (n_steps < 0) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_leapfrog: negative number of steps");
+    mcd::HmcDev& D = m->dev;
+    const size_t B = (size_t)D.batch, BD = B * (size_t)D.dim;
+    for (int k = 0; k < D.dim; ++k)
+        if (!(inv_mass[k] > 0) || !std::isfinite(inv_mass[k])) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_leapfrog: inverse masses must be positive");
+    HHIP_TRY(hipSetDevice(m->device));
+    HHIP_TRY(hipMemcpyAsync(D.p, p, sizeof(double) * BD, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpyAsync(m->d_eps, eps, sizeof(double) * B, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpyAsync(m->d_inv_mass, inv_mass, sizeof(double) * D.dim, hipMemcpyHostToDevice, m->stream));
+    if (dir) {
+        HHIP_TRY(hipMemcpyAsync(m->d_dir, dir, sizeof(double) * B, hipMemcpyHostToDevice, m->stream));
+        D.dir = m->d_dir;
+    } else {
+        D.dir = nullptr;
+    }
+    // p += eps/2 g;  [ q += eps Minv p;  g = grad(q);  p += eps g ] x (n - 1);  q += eps Minv p;  g = grad(q);  p += eps/2 g
+    for (int s = 0; s < n_steps; ++s) {
+        HHIP_TRY(mcd::launch_hmc_kick(D, (s == 0) ? 0.5 : 1.0, m->stream));
+        HHIP_TRY(mcd::launch_hmc_drift(D, m->stream));
+        if (int rc = eval_gradients(m)) return rc;
+    }
+    if (n_steps > 0) HHIP_TRY(mcd::launch_hmc_kick(D, 0.5, m->stream));
+    HHIP_TRY(mcd::launch_hmc_collect(D, m->stream));
+    HHIP_TRY(hipMemcpyAsync(p, D.p, sizeof(double) * BD, hipMemcpyDeviceToHost, m->stream));
+    HHIP_TRY(hipStreamSynchronize(m->stream));
+    return MCD_OK;
+}
+
+}  // extern "C"

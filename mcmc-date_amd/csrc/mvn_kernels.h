@@ -70,6 +70,18 @@ struct MhDev {
     double *age_sum, *age_sq;  // [batch][n_nodes]
 };
 
+// Workspace of the device leapfrog (k_hmc.hip); all pointers are device memory.
+struct HmcDev {
+    int n_nodes, dim, root_right;
+    int64_t batch, ld;
+    const int32_t *pos_field, *pos_index;   // [dim] position layout (toVector order)
+    double *sc, *H, *R;                     // state: scalars [5][batch] (birth, death, tH, rMu, rVar), heights / rates [batch][ld]
+    double *lp, *gp_sc, *gp_H, *gp_R;       // prior: value [batch], gradient wrt the scalars [5][batch], heights, rates
+    double *ll, *gl_H, *gl_R, *gl_tH, *gl_rMu;   // likelihood: value and gradient
+    double *q, *p, *grad, *value;           // [batch][dim] position, momentum, gradient; [batch] ln target
+    const double *eps, *dir, *inv_mass;     // [batch] step sizes, [batch] +-1 or null, [dim] inverse masses
+};
+
 int padded_blocks(int n);          // supported R for dimension n, or -1
 int sweep_chunk_columns(int R);    // columns per register buffer (ncols granularity)
 
@@ -91,6 +103,9 @@ hipError_t launch_prior_grad(const PriorDev& P, const double* birth, const doubl
                              const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
                              double* g_birth, double* g_death, double* g_tH, double* g_H, double* g_rMu, double* g_rVar, double* g_R,
                              hipStream_t st);
+hipError_t launch_hmc_kick(const HmcDev& D, double kick, hipStream_t st);     // p += kick eps grad(q)
+hipError_t launch_hmc_drift(const HmcDev& D, hipStream_t st);                 // q += eps Minv p, scattered into the state
+hipError_t launch_hmc_collect(const HmcDev& D, hipStream_t st);               // q, grad, value from the state and the gradient kernels
 // accept step idx_acc (< 0: none) and propose step idx_prop (< 0: none) with the ln prior of its proposed state
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t idx_acc, int64_t idx_prop, uint64_t step_acc,
                           uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st);

@@ -211,3 +211,109 @@ def test_hamiltonian_target_gradient_in_position_layout(gpu, golden):
             fd = (-f(2) + 8 * f(1) - 8 * f(-1) + f(-2)) / (12 * h)
             an = float(grad[b] @ d)
             assert abs(an - fd) <= 1e-5 * max(1.0, abs(fd)), (b, an, fd)
+
+
+def test_device_leapfrog(gpu, golden):
+    """Row f3, second part: the leapfrog integrator on the device.  Position, value and gradient agree with
+    hamiltonian.target_grad; the map is reversible (forward, flip the momenta, forward again returns to the start); the
+    energy error falls fourfold when the step is halved (second order); direction -1 equals flipped momenta."""
+    fx = golden["24-leaves-braces"]
+    topo = M.Topology(fx["parent"])
+    cal, con, br = tables(fx)
+    pf = M.PriorFunction(float(fx["prior_ht"]), "UncorrelatedGamma", cal, con, br, topo)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    B = 8
+    # typical posterior states: a short Metropolis-Hastings run from the initial state
+    ps, _ = M.proposals(topo, br, calibrations_available=True)
+    smp = M.Sampler(lik, pf, ps, B, seed=2)
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    x0.time_height = float(fx["prior_ht"])
+    smp.set_initial_state(x0)
+    for period in (50, 50, 100, 100):
+        smp.run(period)
+        smp.autotune()
+    s = smp.state()
+    lf = M.Leapfrog(lik, pf, True, B)
+    assert lf.dim == 73
+    lf.set_state(s)
+    q0, v0, g0 = lf.position()
+    mask = M.get_mask(True, topo)
+    val, grad = M.target_grad(mask, lik, pf, s)
+    assert np.allclose(v0, val, rtol=1e-13) and np.allclose(g0, grad, rtol=1e-11, atol=1e-9)
+    for b in range(B):
+        x = M.State(s.time_birth_rate[b], s.time_death_rate[b], s.time_height[b], s.heights[b], s.rate_mean[b], s.rate_variance[b], s.rates[b])
+        assert np.array_equal(q0[b], M.to_vector(mask, x))
+    rng = np.random.default_rng(3)
+    inv_mass = np.full(lf.dim, 1.0)
+    scale = 1.0 / np.maximum(1.0, np.abs(g0).max(axis=1))            # keep the trajectories inside the support
+    p0 = rng.normal(size=(B, lf.dim))
+    eps = 2e-2 * scale
+    # reversibility
+    p1 = lf.leapfrog(p0, eps, inv_mass, 12)
+    q1, v1, _ = lf.position()
+    assert np.all(np.isfinite(v1)) and np.all(np.abs(q1 - q0).max(axis=1) > 1e-6)
+    p2 = lf.leapfrog(-p1, eps, inv_mass, 12)
+    q2, v2, _ = lf.position()
+    assert np.allclose(q2, q0, rtol=1e-10, atol=1e-12) and np.allclose(-p2, p0, rtol=1e-8, atol=1e-10) and np.allclose(v2, v0, rtol=1e-11)
+    # direction -1 from the start equals integrating with flipped momenta
+    lf.set_state(s)
+    pb = lf.leapfrog(p0, eps, inv_mass, 5, direction=-np.ones(B))
+    qb, _, _ = lf.position()
+    lf.set_state(s)
+    pf2 = lf.leapfrog(-p0, eps, inv_mass, 5)
+    qf, _, _ = lf.position()
+    assert np.allclose(qb, qf, rtol=1e-12, atol=0) and np.allclose(pb, -pf2, rtol=1e-12, atol=1e-14)
+    # second order: energy error over a fixed time T = n eps
+    def energy_error(n):
+        lf.set_state(s)
+        pn = lf.leapfrog(p0, eps * (16.0 / n), inv_mass, n)
+        _, vn, _ = lf.position()
+        return np.abs((-vn + 0.5 * np.sum(pn * pn, axis=1)) - (-v0 + 0.5 * np.sum(p0 * p0, axis=1)))
+    e16, e32 = energy_error(16), energy_error(32)
+    ratio = e16 / e32
+    assert np.all(e16 < 0.5) and np.median(ratio) > 3.0 and np.median(ratio) < 5.0, (e16, e32)
+
+
+def test_hmc_chains_agree_with_metropolis_hastings_chains(gpu, golden):
+    """End to end: fixed-length HMC transitions on the device leapfrog sample ln [prior x likelihood x
+    jacobianRootBranch]; Metropolis-Hastings chains in which EVERY proposal carries the root-branch lift have the same
+    target.  Node-age means of the two samplers on tests/12-leaves-variable-rate agree within 2 %."""
+    import dataclasses
+
+    from mcmc_date_amd import monitor as MO
+
+    fx = golden["12-leaves-variable-rate"]
+    topo = M.Topology(fx["parent"])
+    cal, con, br = tables(fx)
+    ht = float(fx["prior_ht"])
+    pf = M.PriorFunction(ht, "UncorrelatedGamma", cal, con, br, topo)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    B = 64
+    ps, _ = M.proposals(topo, br, calibrations_available=True, exact_jacobians=True)
+    ps = [dataclasses.replace(p, jac_root=True) for p in ps]
+    smp = M.Sampler(lik, pf, ps, B, seed=77)
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    x0.time_height = ht
+    smp.set_initial_state(x0)
+    smp.burn_in(fast=[10, 10, 20, 40, 80], slow=[100, 200, 300, 400])
+    tr = MO.collect(smp, 3000, period=50, accumulate=True)
+    ages_mh = smp.node_age_summary()[0]
+    mask = M.get_mask(True, topo)
+    qs = np.array([M.to_vector(mask, M.State(tr.time_birth_rate[k, b], tr.time_death_rate[k, b], tr.time_height[k, b], tr.heights[k, b],
+                                             tr.rate_mean[k, b], tr.rate_variance[k, b], tr.rates[k, b]))
+                   for k in range(tr.heights.shape[0]) for b in range(0, B, 4)])
+    inv_mass = qs.var(axis=0)                                   # masses = inverse posterior variances
+    lf = M.Leapfrog(lik, pf, True, B)
+    lf.set_state(smp.state())
+    rng = np.random.default_rng(5)
+    acc, ages, n_tr = [], np.zeros(topo.n_nodes), 1500
+    for it in range(n_tr):
+        a = M.hmc_transition(lf, rng, 0.04, inv_mass, 12)
+        acc.append(a.mean())
+        s = lf.state()
+        ages += (s.time_height[:, None] * s.heights).mean(axis=0)
+    ages_hmc = ages / n_tr
+    inner = ~topo.leaves
+    rel = np.abs(ages_hmc[inner] - ages_mh[inner]) / ages_mh[inner]
+    assert 0.5 < np.mean(acc) <= 1.0, np.mean(acc)
+    assert rel.max() <= 0.02, (rel, np.mean(acc))
