@@ -200,6 +200,11 @@ int mcd_hmc_get_state(const mcd_hmc_t* m, double* birth, double* death, double* 
                       double* rVar, double* rates, int64_t ld_state);
 int mcd_hmc_get_position(const mcd_hmc_t* m, double* q, double* value, double* grad);
 int mcd_hmc_leapfrog(mcd_hmc_t* m, double* p, const double* eps, const double* dir, const double* inv_mass, int n_steps);
+/* One leapfrog step from ARBITRARY phase points (what a NUTS tree needs: it extends either end of a trajectory):
+ * q, p, grad [batch][dim] in/out (host), value [batch] out (ln target at the new point, may be NULL).  have_grad = 0:
+ * the gradient at q is evaluated first (grad is output only).  The handle's own state becomes the new point. */
+int mcd_hmc_step_from(mcd_hmc_t* m, double* q, double* p, double* grad, int have_grad, const double* eps, const double* dir,
+                      const double* inv_mass, double* value);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched Metropolis-Hastings-Green driver (FIRST SLICE).  `mcmc`'s `mhg` evaluates one state

@@ -219,13 +219,52 @@ int mcd_hmc_leapfrog(mcd_hmc_t* m, double* p, const double* eps, const double* d
     }
     // p += eps/2 g;  [ q += eps Minv p;  g = grad(q);  p += eps g ] x (n - 1);  q += eps Minv p;  g = grad(q);  p += eps/2 g
     for (int s = 0; s < n_steps; ++s) {
-        HHIP_TRY(mcd::launch_hmc_kick(D, (s == 0) ? 0.5 : 1.0, m->stream));
+        HHIP_TRY(mcd::launch_hmc_kick(D, (s == 0) ? 0.5 : 1.0, 0, m->stream));
         HHIP_TRY(mcd::launch_hmc_drift(D, m->stream));
         if (int rc = eval_gradients(m)) return rc;
     }
-    if (n_steps > 0) HHIP_TRY(mcd::launch_hmc_kick(D, 0.5, m->stream));
+    if (n_steps > 0) HHIP_TRY(mcd::launch_hmc_kick(D, 0.5, 0, m->stream));
     HHIP_TRY(mcd::launch_hmc_collect(D, m->stream));
     HHIP_TRY(hipMemcpyAsync(p, D.p, sizeof(double) * BD, hipMemcpyDeviceToHost, m->stream));
+    HHIP_TRY(hipStreamSynchronize(m->stream));
+    return MCD_OK;
+}
+
+int mcd_hmc_step_from(mcd_hmc_t* m, double* q, double* p, double* grad, int have_grad, const double* eps, const double* dir,
+                      const double* inv_mass, double* value)
+{
+    if (!m || !q || !p || !grad || !eps || !inv_mass) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_step_from: NULL argument");
+    if (!m->have_state) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_step_from: call mcd_hmc_set_state first (fixes the masked entries)");
+    mcd::HmcDev& D = m->dev;
+    const size_t B = (size_t)D.batch, BD = B * (size_t)D.dim;
+    for (int k = 0; k < D.dim; ++k)
+        if (!(inv_mass[k] > 0) || !std::isfinite(inv_mass[k])) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_step_from: inverse masses must be positive");
+    HHIP_TRY(hipSetDevice(m->device));
+    HHIP_TRY(hipMemcpyAsync(D.q, q, sizeof(double) * BD, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpyAsync(D.p, p, sizeof(double) * BD, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpyAsync(m->d_eps, eps, sizeof(double) * B, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpyAsync(m->d_inv_mass, inv_mass, sizeof(double) * D.dim, hipMemcpyHostToDevice, m->stream));
+    if (dir) {
+        HHIP_TRY(hipMemcpyAsync(m->d_dir, dir, sizeof(double) * B, hipMemcpyHostToDevice, m->stream));
+        D.dir = m->d_dir;
+    } else {
+        D.dir = nullptr;
+    }
+    HHIP_TRY(mcd::launch_hmc_scatter(D, m->stream));
+    if (have_grad) {
+        HHIP_TRY(hipMemcpyAsync(D.grad, grad, sizeof(double) * BD, hipMemcpyHostToDevice, m->stream));
+    } else {
+        if (int rc = eval_gradients(m)) return rc;
+    }
+    HHIP_TRY(mcd::launch_hmc_kick(D, 0.5, have_grad ? 1 : 0, m->stream));
+    HHIP_TRY(mcd::launch_hmc_drift(D, m->stream));
+    if (int rc = eval_gradients(m)) return rc;
+    HHIP_TRY(mcd::launch_hmc_kick(D, 0.5, 0, m->stream));
+    HHIP_TRY(mcd::launch_hmc_collect(D, m->stream));
+    HHIP_TRY(hipMemcpyAsync(q, D.q, sizeof(double) * BD, hipMemcpyDeviceToHost, m->stream));
+    HHIP_TRY(hipMemcpyAsync(p, D.p, sizeof(double) * BD, hipMemcpyDeviceToHost, m->stream));
+    HHIP_TRY(hipMemcpyAsync(grad, D.grad, sizeof(double) * BD, hipMemcpyDeviceToHost, m->stream));
+    if (value) HHIP_TRY(hipMemcpyAsync(value, D.value, sizeof(double) * B, hipMemcpyDeviceToHost, m->stream));
     HHIP_TRY(hipStreamSynchronize(m->stream));
     return MCD_OK;
 }

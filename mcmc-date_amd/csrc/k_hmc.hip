@@ -61,7 +61,9 @@ __device__ __forceinline__ double* hmc_state_slot(const HmcDev& D, int64_t b, in
 // p += kick * eps_b * dir_b * grad.  `dir` (+1 / -1 per chain, may be null = +1) integrates backwards in time (NUTS-style
 // doubling).  The drift is a separate launch (k_hmc_drift): the Jacobian term of one coordinate reads state entries that
 // belong to other coordinates, so every gradient entry is read before any position is written.
-__global__ __launch_bounds__(256) void k_hmc_kick(HmcDev D, double kick)
+// use_pos_grad != 0: the gradient is taken from D.grad (position layout, supplied by the caller with the position)
+// instead of being assembled from the outputs of the gradient kernels
+__global__ __launch_bounds__(256) void k_hmc_kick(HmcDev D, double kick, int use_pos_grad)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.batch * D.dim) return;
@@ -69,9 +71,19 @@ __global__ __launch_bounds__(256) void k_hmc_kick(HmcDev D, double kick)
     const int k = (int)(i - b * D.dim);
     const int field = D.pos_field[k], v = D.pos_index[k];
     const double e = D.eps[b] * (D.dir ? D.dir[b] : 1.0);
-    const double g = hmc_grad_entry(D, b, field, v);
+    const double g = use_pos_grad ? D.grad[i] : hmc_grad_entry(D, b, field, v);
     D.p[i] = D.p[i] + kick * e * g;
     D.grad[i] = g;
+}
+
+// the state arrays receive the position D.q (masked-out entries keep their values)
+__global__ __launch_bounds__(256) void k_hmc_scatter(HmcDev D)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.batch * D.dim) return;
+    const int64_t b = i / D.dim;
+    const int k = (int)(i - b * D.dim);
+    *hmc_state_slot(D, b, D.pos_field[k], D.pos_index[k]) = D.q[i];
 }
 
 __global__ __launch_bounds__(256) void k_hmc_drift(HmcDev D)
@@ -109,9 +121,14 @@ __global__ __launch_bounds__(256) void k_hmc_collect(HmcDev D)
 
 static unsigned hmc_grid(const HmcDev& D) { return (unsigned)((D.batch * D.dim + 255) / 256); }
 
-hipError_t launch_hmc_kick(const HmcDev& D, double kick, hipStream_t st)
+hipError_t launch_hmc_kick(const HmcDev& D, double kick, int use_pos_grad, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_hmc_kick, dim3(hmc_grid(D)), dim3(256), 0, st, D, kick);
+    hipLaunchKernelGGL(k_hmc_kick, dim3(hmc_grid(D)), dim3(256), 0, st, D, kick, use_pos_grad);
+    return hipGetLastError();
+}
+hipError_t launch_hmc_scatter(const HmcDev& D, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_hmc_scatter, dim3(hmc_grid(D)), dim3(256), 0, st, D);
     return hipGetLastError();
 }
 hipError_t launch_hmc_drift(const HmcDev& D, hipStream_t st)

@@ -103,7 +103,8 @@ hipError_t launch_prior_grad(const PriorDev& P, const double* birth, const doubl
                              const double* rMu, const double* rVar, const double* Rt, int64_t lds, int64_t batch, double* lp,
                              double* g_birth, double* g_death, double* g_tH, double* g_H, double* g_rMu, double* g_rVar, double* g_R,
                              hipStream_t st);
-hipError_t launch_hmc_kick(const HmcDev& D, double kick, hipStream_t st);     // p += kick eps grad(q)
+hipError_t launch_hmc_kick(const HmcDev& D, double kick, int use_pos_grad, hipStream_t st);   // p += kick eps grad(q)
+hipError_t launch_hmc_scatter(const HmcDev& D, hipStream_t st);               // state arrays <- D.q
 hipError_t launch_hmc_drift(const HmcDev& D, hipStream_t st);                 // q += eps Minv p, scattered into the state
 hipError_t launch_hmc_collect(const HmcDev& D, hipStream_t st);               // q, grad, value from the state and the gradient kernels
 // accept step idx_acc (< 0: none) and propose step idx_prop (< 0: none) with the ln prior of its proposed state

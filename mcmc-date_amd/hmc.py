@@ -4,14 +4,19 @@
 ln [prior x likelihood x jacobianRootBranch] (`htargetWith`, app/Hamiltonian.hs:72-92) live on the device; positions
 use the reference's layout (`getMask` / `toVector`, :33-53; identical to `hamiltonian.to_vector`).
 
-The reference's proposal is NUTS with step-size and mass tuning from the `mcmc` package (`nutsWith`, :95-105), which is
-not restated here.  `hmc_transition` is the textbook fixed-length HMC step (momentum refresh, n leapfrog steps,
-Metropolis correction) -- enough to exercise the integrator end to end and to check its stationary distribution
-against Metropolis-Hastings chains with the same target.
+The reference's proposal is NUTS from the `mcmc` package (`nutsWith`, :95-105; dschrempf/mcmc 542c43f6, not vendored).
+Restated here from the published algorithm it implements -- Hoffman & Gelman, "The No-U-Turn Sampler", JMLR 15 (2014):
+`nuts_transition` is Algorithm 3 (efficient NUTS: slice variable, recursive doubling, U-turn and divergence stops,
+uniform sampling from the admissible set), `DualAveraging` the step-size adaptation of Algorithm 6 -- with the device
+doing every leapfrog step for all chains at once and the per-chain recursion as host-side control flow (one Python
+generator per chain; the driver gathers the leapfrog requests of all active chains into one `mcd_hmc_step_from` call).
+`mcmc`'s own tuning (`HTuneLeapfrog HTuneAllMasses`) and its defaults are NOT restated: parity unpinned for this part.
+`hmc_transition` is the textbook fixed-length HMC step, kept as the simplest end-to-end exercise of the integrator.
 """
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -84,6 +89,20 @@ class Leapfrog:
         return p
 
 
+    def step_from(self, q, p, grad, eps, inv_mass, direction=None, have_grad=True):
+        """One leapfrog step from the given phase points (all [B, dim]); returns (q', p', grad', ln target')."""
+        q = np.array(q, dtype=np.float64, order="C")
+        p = np.array(p, dtype=np.float64, order="C")
+        g = np.array(grad, dtype=np.float64, order="C")
+        eps = np.ascontiguousarray(np.broadcast_to(np.asarray(eps, np.float64), (self.batch,)))
+        inv_mass = np.ascontiguousarray(np.broadcast_to(np.asarray(inv_mass, np.float64), (self.dim,)))
+        d = None if direction is None else np.ascontiguousarray(direction, dtype=np.float64)
+        v = np.empty(self.batch)
+        _capi.check(_capi.lib().mcd_hmc_step_from(self._h, _p(q), _p(p), _p(g), int(bool(have_grad)), _p(eps),
+                                                  _p(d) if d is not None else None, _p(inv_mass), _p(v)))
+        return q, p, g, v
+
+
 def hmc_transition(lf: Leapfrog, rng: np.random.Generator, eps, inv_mass, n_steps: int) -> np.ndarray:
     """One fixed-length HMC transition for every chain: p ~ N(0, M), n leapfrog steps, accept with probability
     min(1, exp(H_old - H_new)), H = -ln target + 1/2 p^T M^-1 p.  Rejected chains (and chains that left the support:
@@ -108,3 +127,135 @@ def hmc_transition(lf: Leapfrog, rng: np.random.Generator, eps, inv_mass, n_step
                             np.where(keep, new.rate_variance, old.rate_variance))
         lf.set_state(merged)
     return accept
+
+
+# ---- NUTS: Hoffman & Gelman (2014), Algorithm 3, one generator per chain -----------------------------------------------
+DELTA_MAX = 1000.0
+
+
+def _nuts_chain(q0, g0, logp0, r0, log_u, rng, inv_mass, max_depth, stats):
+    """Generator of one chain's transition.  Yields leapfrog requests (q, r, grad, direction) and receives
+    (q', r', grad', ln target'); returns the selected (q, grad, ln target)."""
+
+    def kinetic(r):
+        return 0.5 * float(np.sum(r * r * inv_mass))
+
+    def no_u_turn(qm, rm, qp, rp):
+        d = qp - qm
+        return float(np.dot(d, rm * inv_mass)) >= 0.0 and float(np.dot(d, rp * inv_mass)) >= 0.0
+
+    def build_tree(q, r, g, v, j):
+        if j == 0:
+            q1, r1, g1, lp1 = yield (q, r, g, v)
+            joint = lp1 - kinetic(r1)                       # -H
+            if not math.isfinite(joint):
+                joint = -math.inf
+            n1 = 1 if log_u <= joint else 0
+            s1 = log_u < DELTA_MAX + joint
+            stats["alpha"] += min(1.0, math.exp(min(0.0, joint - stats["joint0"])))
+            stats["n_alpha"] += 1
+            return q1, r1, g1, q1, r1, g1, q1, g1, lp1, n1, s1
+        qm, rm, gm, qp, rp, gp, qc, gc, lpc, n1, s1 = yield from build_tree(q, r, g, v, j - 1)
+        if s1:
+            if v == -1:
+                qm, rm, gm, _, _, _, qc2, gc2, lpc2, n2, s2 = yield from build_tree(qm, rm, gm, v, j - 1)
+            else:
+                _, _, _, qp, rp, gp, qc2, gc2, lpc2, n2, s2 = yield from build_tree(qp, rp, gp, v, j - 1)
+            if n2 > 0 and rng.uniform() < n2 / max(1, n1 + n2):
+                qc, gc, lpc = qc2, gc2, lpc2
+            s1 = s2 and no_u_turn(qm, rm, qp, rp)
+            n1 += n2
+        return qm, rm, gm, qp, rp, gp, qc, gc, lpc, n1, s1
+
+    qm = qp = q0
+    rm = rp = r0
+    gm = gp = g0
+    q_new, g_new, lp_new = q0, g0, logp0
+    n, s, j = 1, True, 0
+    while s and j < max_depth:
+        v = -1 if rng.uniform() < 0.5 else 1
+        if v == -1:
+            qm, rm, gm, _, _, _, qc, gc, lpc, n1, s1 = yield from build_tree(qm, rm, gm, v, j)
+        else:
+            _, _, _, qp, rp, gp, qc, gc, lpc, n1, s1 = yield from build_tree(qp, rp, gp, v, j)
+        if s1 and rng.uniform() < min(1.0, n1 / n):
+            q_new, g_new, lp_new = qc, gc, lpc
+        n += n1
+        s = s1 and no_u_turn(qm, rm, qp, rp)
+        j += 1
+    stats["depth"] = j
+    return q_new, g_new, lp_new
+
+
+def nuts_transition(lf: Leapfrog, rng: np.random.Generator, eps, inv_mass, max_depth: int = 8):
+    """One NUTS transition (Algorithm 3) for every chain of `lf`, all chains advancing their trees in lock step on the
+    device.  eps: scalar or [B].  Returns (mean acceptance statistic alpha / n_alpha per chain [B], tree depth [B]);
+    the chains' new states are on the device (lf.state(), lf.position())."""
+    B, D = lf.batch, lf.dim
+    inv_mass = np.ascontiguousarray(np.broadcast_to(np.asarray(inv_mass, np.float64), (D,)))
+    eps = np.ascontiguousarray(np.broadcast_to(np.asarray(eps, np.float64), (B,)))
+    q0, lp0, g0 = lf.position()
+    r0 = rng.normal(size=(B, D)) / np.sqrt(inv_mass)
+    joint0 = lp0 - 0.5 * np.sum(r0 * r0 * inv_mass, axis=1)
+    log_u = joint0 + np.log(rng.uniform(size=B))
+    chain_rngs = [np.random.default_rng(rng.integers(0, 2 ** 63)) for _ in range(B)]
+    stats = [{"alpha": 0.0, "n_alpha": 0, "joint0": float(joint0[b]), "depth": 0} for b in range(B)]
+    gens = [_nuts_chain(q0[b].copy(), g0[b].copy(), float(lp0[b]), r0[b].copy(), float(log_u[b]), chain_rngs[b], inv_mass, max_depth, stats[b])
+            for b in range(B)]
+    result = [None] * B
+    request = [None] * B
+    for b in range(B):
+        try:
+            request[b] = next(gens[b])
+        except StopIteration as done:               # cannot happen before the first leapfrog, kept for completeness
+            result[b] = done.value
+    q_in, p_in, g_in = q0.copy(), r0.copy(), g0.copy()
+    direction = np.ones(B)
+    while any(r is not None for r in request):
+        for b in range(B):
+            if request[b] is not None:
+                q_in[b], p_in[b], g_in[b], v = request[b]
+                direction[b] = float(v)
+            else:                                    # finished chains ride along with a harmless step from their result
+                q_in[b], g_in[b] = result[b][0], result[b][1]
+                p_in[b] = 0.0
+                direction[b] = 1.0
+        q1, p1, g1, lp1 = lf.step_from(q_in, p_in, g_in, eps, inv_mass, direction=direction, have_grad=True)
+        for b in range(B):
+            if request[b] is None:
+                continue
+            try:
+                request[b] = gens[b].send((q1[b].copy(), p1[b].copy(), g1[b].copy(), float(lp1[b])))
+            except StopIteration as done:
+                request[b] = None
+                result[b] = done.value
+    # the selected points become the chains' states (zero-length step: the device evaluates ln target and gradient there)
+    q_sel = np.array([r[0] for r in result])
+    lf.step_from(q_sel, np.zeros((B, D)), np.array([r[1] for r in result]), np.zeros(B), inv_mass, have_grad=True)
+    alpha = np.array([s["alpha"] / max(1, s["n_alpha"]) for s in stats])
+    return alpha, np.array([s["depth"] for s in stats])
+
+
+class DualAveraging:
+    """Step-size adaptation of Hoffman & Gelman, Algorithm 6 (one instance per chain set; vectorised over chains)."""
+
+    def __init__(self, eps0, delta: float = 0.65, gamma: float = 0.05, t0: float = 10.0, kappa: float = 0.75):
+        eps0 = np.asarray(eps0, np.float64)
+        self.mu = np.log(10.0 * eps0)
+        self.delta, self.gamma, self.t0, self.kappa = delta, gamma, t0, kappa
+        self.h_bar = np.zeros_like(eps0)
+        self.log_eps = np.log(eps0)
+        self.log_eps_bar = np.zeros_like(eps0)
+        self.m = 0
+
+    def update(self, alpha):
+        self.m += 1
+        m = self.m
+        self.h_bar = (1.0 - 1.0 / (m + self.t0)) * self.h_bar + (self.delta - np.asarray(alpha)) / (m + self.t0)
+        self.log_eps = self.mu - math.sqrt(m) / self.gamma * self.h_bar
+        w = m ** (-self.kappa)
+        self.log_eps_bar = w * self.log_eps + (1.0 - w) * self.log_eps_bar
+        return np.exp(self.log_eps)
+
+    def final(self):
+        return np.exp(self.log_eps_bar)

@@ -317,3 +317,56 @@ def test_hmc_chains_agree_with_metropolis_hastings_chains(gpu, golden):
     rel = np.abs(ages_hmc[inner] - ages_mh[inner]) / ages_mh[inner]
     assert 0.5 < np.mean(acc) <= 1.0, np.mean(acc)
     assert rel.max() <= 0.02, (rel, np.mean(acc))
+
+
+def test_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden):
+    """NUTS (Hoffman & Gelman 2014, Algorithm 3) with dual-averaging step sizes (Algorithm 6) on the device leapfrog
+    against Metropolis-Hastings chains with the same target (every proposal lifted with jacobianRootBranch): node-age
+    means on tests/12-leaves-variable-rate within 2.5 %; the adapted step size gives the target acceptance statistic."""
+    import dataclasses
+
+    from mcmc_date_amd import monitor as MO
+
+    fx = golden["12-leaves-variable-rate"]
+    topo = M.Topology(fx["parent"])
+    cal, con, br = tables(fx)
+    ht = float(fx["prior_ht"])
+    pf = M.PriorFunction(ht, "UncorrelatedGamma", cal, con, br, topo)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    B = 32
+    ps, _ = M.proposals(topo, br, calibrations_available=True, exact_jacobians=True)
+    ps = [dataclasses.replace(p, jac_root=True) for p in ps]
+    smp = M.Sampler(lik, pf, ps, B, seed=78)
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    x0.time_height = ht
+    smp.set_initial_state(x0)
+    smp.burn_in(fast=[10, 10, 20, 40, 80], slow=[100, 200, 300, 400])
+    tr = MO.collect(smp, 4000, period=50, accumulate=True)
+    ages_mh = smp.node_age_summary()[0]
+    mask = M.get_mask(True, topo)
+    qs = np.array([M.to_vector(mask, M.State(tr.time_birth_rate[k, b], tr.time_death_rate[k, b], tr.time_height[k, b], tr.heights[k, b],
+                                             tr.rate_mean[k, b], tr.rate_variance[k, b], tr.rates[k, b]))
+                   for k in range(tr.heights.shape[0]) for b in range(0, B, 2)])
+    inv_mass = qs.var(axis=0)
+    lf = M.Leapfrog(lik, pf, True, B)
+    lf.set_state(smp.state())
+    rng = np.random.default_rng(6)
+    da = M.DualAveraging(np.full(B, 0.03), delta=0.65)
+    eps = np.full(B, 0.03)
+    for _ in range(120):                                       # warm-up: step sizes only (masses come from the MH sample)
+        alpha, depth = M.nuts_transition(lf, rng, eps, inv_mass, max_depth=6)
+        eps = da.update(alpha)
+    eps = da.final()
+    assert np.all((eps > 0.005) & (eps < 0.5)), eps
+    ages, alphas, depths, n_tr = np.zeros(topo.n_nodes), [], [], 350
+    for _ in range(n_tr):
+        alpha, depth = M.nuts_transition(lf, rng, eps, inv_mass, max_depth=6)
+        alphas.append(alpha.mean())
+        depths.append(depth.mean())
+        s = lf.state()
+        ages += (s.time_height[:, None] * s.heights).mean(axis=0)
+    ages_nuts = ages / n_tr
+    inner = ~topo.leaves
+    rel = np.abs(ages_nuts[inner] - ages_mh[inner]) / ages_mh[inner]
+    assert 0.45 < np.mean(alphas) < 0.9 and 1.5 < np.mean(depths) <= 6.0, (np.mean(alphas), np.mean(depths))
+    assert rel.max() <= 0.025, (rel, np.mean(alphas), np.mean(depths))

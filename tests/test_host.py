@@ -176,3 +176,59 @@ def test_node_age_summary_follows_the_reference_script():
     assert (tiny.ci_lower[0], tiny.ci_upper[0], tiny.minimum[0], tiny.maximum[0]) == (1.0, 4.0, 1.0, 5.0)
     with pytest.raises(ValueError):
         MO.summarize_node_ages(np.zeros((1, 2)), burn_in=0.9)
+
+
+class _GaussianLeapfrog:
+    """Stand-in for mcmc_date_amd.hmc.Leapfrog with an analytic target (independent normals with given sds): the NUTS
+    control flow is host code and can be exercised without a device."""
+
+    def __init__(self, batch, sds, seed=0):
+        self.batch, self.dim = batch, len(sds)
+        self.sd = np.asarray(sds, float)
+        self.q = np.random.default_rng(seed).normal(size=(batch, self.dim)) * self.sd
+
+    def _lp_grad(self, q):
+        return -0.5 * np.sum((q / self.sd) ** 2, axis=1), -q / self.sd ** 2
+
+    def position(self):
+        lp, g = self._lp_grad(self.q)
+        return self.q.copy(), lp, g
+
+    def step_from(self, q, p, grad, eps, inv_mass, direction=None, have_grad=True):
+        e = np.asarray(eps, float)[:, None] * (np.ones((self.batch, 1)) if direction is None else np.asarray(direction)[:, None])
+        p = p + 0.5 * e * grad
+        q = q + e * inv_mass * p
+        lp, g = self._lp_grad(q)
+        p = p + 0.5 * e * g
+        self.q = q.copy()
+        return q, p, g, lp
+
+
+def test_nuts_control_flow_on_an_analytic_target():
+    """Hoffman & Gelman's Algorithm 3 + 6 as restated in mcmc_date_amd/hmc.py, on independent normals with very
+    different scales: after dual-averaging warm-up the chains reproduce means and variances."""
+    from mcmc_date_amd.hmc import DualAveraging, nuts_transition
+
+    sds = np.array([0.2, 1.0, 3.0, 0.5])
+    B = 32
+    lf = _GaussianLeapfrog(B, sds, seed=1)
+    rng = np.random.default_rng(2)
+    inv_mass = np.ones(4)                                   # unit masses: the step size must adapt to the smallest scale
+    da = DualAveraging(np.full(B, 0.05), delta=0.65)
+    eps = np.full(B, 0.05)
+    for _ in range(200):
+        alpha, depth = nuts_transition(lf, rng, eps, inv_mass, max_depth=7)
+        eps = da.update(alpha)
+    eps = da.final()
+    assert np.all((eps > 0.04) & (eps < 0.8)), eps          # stability limit 2 * min(sd) = 0.4; delta = 0.65 sits around it
+    draws, alphas, depths = [], [], []
+    for _ in range(250):
+        alpha, depth = nuts_transition(lf, rng, eps, inv_mass, max_depth=7)
+        alphas.append(alpha.mean())
+        depths.append(depth.mean())
+        draws.append(lf.q.copy())
+    x = np.array(draws).reshape(-1, 4)
+    assert 0.5 < np.mean(alphas) < 0.95, np.mean(alphas)   # the averaged step size is a little conservative after a short warm-up
+    assert np.all(np.abs(x.mean(axis=0)) < 0.06 * sds * 4), x.mean(axis=0) / sds
+    assert np.all(np.abs(x.std(axis=0) / sds - 1.0) < 0.08), x.std(axis=0) / sds
+    assert 2.5 < np.mean(depths) <= 7.0                     # the widest coordinate needs long trajectories
