@@ -170,8 +170,9 @@ int mcd_prior_logprior_batch(const mcd_prior_t* p, const double* birth, const do
  * Log prior and its gradient with respect to the seven fields of the state (first part): the prior
  * factor of the Hamiltonian target `htargetWith` (app/Hamiltonian.hs:72-92), which the reference differentiates by AD.
  * g_heights / g_rates: [batch][ld_state] (every node; masking per app/Hamiltonian.hs:33-47 is the caller's business;
- * g_rates[.][0] = 0).  Outside the support (ln prior = -inf or NaN) and in the near-critical regime of the birth-death
- * prior (|birth - death| < 1e-6, BirthDeath.hs:117-118) every gradient entry of that chain is NaN.
+ * g_rates[.][0] = 0).  Outside the support (ln prior = -inf or NaN) every gradient entry of that chain is NaN.  In the
+ * near-critical regime of the birth-death prior (|birth - death| < 1e-6, BirthDeath.hs:117-118) the gradient is the one
+ * of the exact formulas at the edge of that regime (relative deviation O(1e-6) from the first-order value's derivative).
  */
 int mcd_prior_grad_batch(const mcd_prior_t* p, const double* birth, const double* death, const double* tH,
                          const double* heights, const double* rMu, const double* rVar, const double* rates,

@@ -11,8 +11,10 @@
 // gathered by the parent lane from its (at most two) children; the soft node priors (calibrations, constraints,
 // braces) are few and are added by lane 0 one after the other (fixed order: bit-reproducible).
 // Outside the support (ln prior = -inf or NaN) the gradient is NaN.  In the near-critical regime |la - mu| < 1e-6 the
-// reference's first-order formulas are a recursion over a chain of nodes; its derivative is not built: the gradient of
-// the birth-death block is NaN there (a Hamiltonian proposal is then rejected; Metropolis-Hastings steps are unaffected).
+// reference switches the VALUE to first-order formulas composed along a chain of nodes (BirthDeath.hs:90-118); the
+// initial state of every analysis sits there (birth = death = 1, app/Definitions.hs:99-100).  The gradient is then taken
+// from the exact formulas at the edge of that regime (la moved to mu +- 1e-6): it differs from the derivative of the
+// first-order value by O(1e-6) relative, which a Hamiltonian trajectory does not notice (its accept step uses values).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -151,6 +153,7 @@ __global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __
     const double* r = Rt + b * lds;
     const double la = birth[b], mu = death[b], th = tH[b], rm = rMu[b], va = rVar[b];
     const bool near = 1e-6 > fabs(la - mu);
+    const double la_d = near ? mu + ((la >= mu) ? 1e-6 : -1e-6) : la;     // see the note on the near-critical regime above
     double bd = 0.0, clock = 0.0, s_la = 0.0, s_mu = 0.0, s_va = 0.0;
     for (int v = lane; v < n; v += 64) {
         if (v == 0) {
@@ -162,13 +165,11 @@ __global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __
         const int pv = P.parent[v];
         const int nc = P.n_children[v];
         // ---- birth-death term of node v: tangents (la, mu, h_v, h_parent) -------------------------------------
-        const D4 dla = var(la, 0), dmu = var(mu, 1), hv = var(h[v], 2), hp = var(h[pv], 3);
+        const D4 dla = var(la_d, 0), dmu = var(mu, 1), hv = var(h[v], 2), hp = var(h[pv], 3);
         const D4 br = hp - hv;
         D4 term_bd;
         if (br.v <= 0) {
             term_bd = cst(kNegInf);
-        } else if (near) {
-            term_bd = cst(__builtin_nan(""));
         } else {
             D4 e0 = cst(0.0);
             if (nc > 0) {
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __
     const double gla = pr_wave_sum(s_la), gmu = pr_wave_sum(s_mu), gva = pr_wave_sum(s_va);
     // the value is the one of mcd_prior_logprior_batch (same code); the dual values above only carry the tangents
     const double total = c0 + prior_bd_wave(P, lane, la, mu, h) + prior_clock_wave(P, lane, rm, va, h, r);
-    const bool ok = total == total && total > kNegInf && !near;   // inside the support and away from the near-critical regime
+    const bool ok = total == total && total > kNegInf;            // inside the support
     (void)bd;
     (void)clock;
     const double bad = __builtin_nan("");

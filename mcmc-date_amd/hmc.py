@@ -259,3 +259,31 @@ class DualAveraging:
 
     def final(self):
         return np.exp(self.log_eps_bar)
+
+
+def nuts_warmup(lf: Leapfrog, rng: np.random.Generator, n_windows: int = 3, window: int = 60, eps0: float = 0.02, delta: float = 0.65,
+                max_depth: int = 6):
+    """Warm-up of step sizes and diagonal masses (the reference tunes both: `HTuningConf HTuneLeapfrog HTuneAllMasses`,
+    app/Hamiltonian.hs:62-63; `mcmc`'s own scheme is not restated).  Windows of `window` transitions: dual averaging
+    of the step sizes inside a window, then the inverse masses are set to the pooled variance of the positions visited
+    in that window (over chains and transitions, shrunk towards their mean for stability).  The first window starts
+    from inverse masses (0.1 q)^2.  Returns (eps [B], inv_mass [dim])."""
+    q0, _, _ = lf.position()
+    inv_mass = np.maximum((0.1 * np.abs(q0)).mean(axis=0) ** 2, 1e-12)
+    eps = np.full(lf.batch, float(eps0))
+    for w in range(n_windows):
+        da = DualAveraging(eps, delta=delta)
+        qs = []
+        for _ in range(window):
+            alpha, _ = nuts_transition(lf, rng, eps, inv_mass, max_depth=max_depth)
+            eps = da.update(alpha)
+            qs.append(lf.position()[0])
+        eps = da.final()
+        var = np.concatenate(qs[window // 4:]).var(axis=0)
+        n_eff = lf.batch * (window - window // 4)
+        inv_mass = (n_eff / (n_eff + 5.0)) * var + 1e-3 * (5.0 / (n_eff + 5.0))      # Stan-style shrinkage
+    da = DualAveraging(eps, delta=delta)
+    for _ in range(window):
+        alpha, _ = nuts_transition(lf, rng, eps, inv_mass, max_depth=max_depth)
+        eps = da.update(alpha)
+    return da.final(), inv_mass

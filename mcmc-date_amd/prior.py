@@ -204,7 +204,7 @@ class PriorFunction:
     def grad(self, s: StateBatch):
         """ln prior and its gradient with respect to the seven fields of the state (host arrays):
         (lp [B], dict(time_birth_rate, time_death_rate, time_height, heights [B, n_nodes], rate_mean, rate_variance,
-        rates [B, n_nodes])).  NaN outside the support and in the birth-death prior's near-critical regime."""
+        rates [B, n_nodes])).  NaN outside the support."""
         if s.time_birth_rate is None or s.time_death_rate is None or s.rate_variance is None:
             raise ValueError("grad: the state batch lacks time_birth_rate / time_death_rate / rate_variance")
         nn = self.topo.n_nodes

@@ -135,9 +135,8 @@ def test_prior_gradient_against_differences_of_the_oracle(gpu, golden, name, mod
     for b in range(6):
         base = [s.time_birth_rate[b], s.time_death_rate[b], s.time_height[b], s.heights[b].copy(), s.rate_mean[b], s.rate_variance[b], s.rates[b].copy()]
         assert np.isfinite(lp[b])
-        if abs(base[0] - base[1]) < 1e-6:                      # the fixtures' chain 1 sits in the near-critical regime on purpose
-            assert np.all(np.isnan(g["heights"][b])) and np.isnan(g["time_birth_rate"][b])
-            continue
+        near = abs(base[0] - base[1]) < 1e-6                   # the fixtures' chain 1 sits in the near-critical regime on purpose
+        tol = 2e-4 if near else 2e-5                           # there: exact formulas at the regime's edge vs first-order value
 
         def at(i, v, x):
             a = list(base)
@@ -157,7 +156,9 @@ def test_prior_gradient_against_differences_of_the_oracle(gpu, golden, name, mod
 
         for i, key in ((0, "time_birth_rate"), (1, "time_death_rate"), (2, "time_height"), (4, "rate_mean"), (5, "rate_variance")):
             fd = fd_scalar(i)
-            assert abs(g[key][b] - fd) <= 2e-5 * max(1.0, abs(fd)), (key, b, g[key][b], fd)
+            if near and i in (0, 1):
+                continue                                       # the value has a kink of order 1e-6 across the regime's edge
+            assert abs(g[key][b] - fd) <= tol * max(1.0, abs(fd)), (key, b, g[key][b], fd)
         assert g["rate_mean"][b] == -ht and g["rates"][b, 0] == 0.0
         for v in range(1, n):
             for i, key in ((3, "heights"), (6, "rates")):
@@ -165,16 +166,20 @@ def test_prior_gradient_against_differences_of_the_oracle(gpu, golden, name, mod
                 if x0 == 0.0:
                     continue                                   # leaves: heights are not free parameters (mask)
                 fd = stencil(i, v, x0)
-                assert abs(g[key][b, v] - fd) <= 2e-5 * max(1.0, abs(fd)), (key, b, v, g[key][b, v], fd)
-    # outside the support the gradient is NaN, and in the near-critical regime as well
+                assert abs(g[key][b, v] - fd) <= tol * max(1.0, abs(fd)), (key, b, v, g[key][b, v], fd)
+    # outside the support the gradient is NaN; in the near-critical regime it is finite and continuous across the edge
     bad = batch(fx).slice(0, 3)
     R = bad.rates.copy(); R[0, 3] = -1.0
     birth = bad.time_birth_rate.copy(); death = bad.time_death_rate.copy()
     birth[1] = death[1] + 1e-9
+    birth[2] = death[2] = 1.0
     lp2, g2 = pf.grad(M.StateBatch(bad.heights, R, bad.time_height, bad.rate_mean, birth, death, bad.rate_variance))
     assert lp2[0] == -np.inf and np.all(np.isnan(g2["heights"][0])) and np.isnan(g2["rate_variance"][0])
-    assert np.isfinite(lp2[1]) and np.all(np.isnan(g2["heights"][1])) and np.isnan(g2["time_birth_rate"][1])
-    assert np.isfinite(lp2[2]) and np.all(np.isfinite(g2["heights"][2]))
+    assert np.isfinite(lp2[1]) and np.all(np.isfinite(g2["heights"][1])) and np.isfinite(g2["time_birth_rate"][1])
+    birth[1] = death[1] + 2e-6                                 # just outside the regime: the exact formulas
+    _, g3 = pf.grad(M.StateBatch(bad.heights, R, bad.time_height, bad.rate_mean, birth, death, bad.rate_variance))
+    assert np.allclose(g2["heights"][1], g3["heights"][1], rtol=1e-4, atol=1e-6)
+    assert np.isfinite(lp2[2]) and np.all(np.isfinite(g2["heights"][2])) and np.isfinite(g2["time_birth_rate"][2])
 
 
 def test_hamiltonian_target_gradient_in_position_layout(gpu, golden):
@@ -370,3 +375,13 @@ def test_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden):
     rel = np.abs(ages_nuts[inner] - ages_mh[inner]) / ages_mh[inner]
     assert 0.45 < np.mean(alphas) < 0.9 and 1.5 < np.mean(depths) <= 6.0, (np.mean(alphas), np.mean(depths))
     assert rel.max() <= 0.025, (rel, np.mean(alphas), np.mean(depths))
+    # warm-up of step sizes AND diagonal masses without outside knowledge, from states the Metropolis-Hastings cycle has
+    # brought to the posterior (the reference runs NUTS as one proposal of that cycle): the masses it finds are the
+    # posterior variances of the Metropolis-Hastings sample, typically within a factor 1.6
+    lf2 = M.Leapfrog(lik, pf, True, B)
+    lf2.set_state(smp.state())
+    eps_w, inv_mass_w = M.nuts_warmup(lf2, np.random.default_rng(8), n_windows=4, window=50)
+    ratio = inv_mass_w / inv_mass
+    assert np.median(np.abs(np.log(ratio))) < np.log(1.6) and np.mean(np.abs(np.log(ratio)) < np.log(3.0)) > 0.9, ratio
+    alpha, _ = M.nuts_transition(lf2, np.random.default_rng(9), eps_w, inv_mass_w, max_depth=6)
+    assert 0.3 < alpha.mean() <= 1.0
