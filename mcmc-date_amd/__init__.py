@@ -8,7 +8,7 @@ from . import _capi, monitor
 from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating
 from .likelihood import (Full, LikelihoodData, MvnLikelihood, NoData, Sparse, TreeLikelihood, Univariate,
                          jacobian_root_branch, likelihood_function, read_data_file, write_data_file)
-from .hmc import DualAveraging, Leapfrog, hmc_transition, nuts_transition, nuts_warmup
+from .hmc import DualAveraging, Leapfrog, hmc_transition, nuts_transition, nuts_warmup, run_cycle_with_nuts
 from .hamiltonian import from_vector_with, get_mask, grad_to_vector, target_grad, to_vector
 from .prior import (Brace, Calibration, Constraint, PriorFunction, get_mean_root_height, load_braces,
                     load_calibrations, load_constraints, prior_function)
@@ -25,6 +25,6 @@ __all__ = [
     "Calibration", "Constraint", "Brace", "PriorFunction", "prior_function", "load_calibrations", "load_constraints",
     "load_braces", "get_mean_root_height",
     "Proposal", "Sampler", "cycle_schedule", "init_with", "proposals", "table_arrays", "weight_n_branches",
-    "Leapfrog", "hmc_transition", "nuts_transition", "nuts_warmup", "DualAveraging", "get_mask", "to_vector", "from_vector_with", "grad_to_vector", "target_grad",
+    "Leapfrog", "hmc_transition", "nuts_transition", "nuts_warmup", "run_cycle_with_nuts", "DualAveraging", "get_mask", "to_vector", "from_vector_with", "grad_to_vector", "target_grad",
     "McdError", "NotPositiveDefinite", "RootNotBifurcating", "NoDevice",
 ]

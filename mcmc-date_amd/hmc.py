@@ -287,3 +287,25 @@ def nuts_warmup(lf: Leapfrog, rng: np.random.Generator, n_windows: int = 3, wind
         alpha, _ = nuts_transition(lf, rng, eps, inv_mass, max_depth=max_depth)
         eps = da.update(alpha)
     return da.final(), inv_mass
+
+
+def run_cycle_with_nuts(sampler, lf: Leapfrog, rng: np.random.Generator, n_iter: int, eps, inv_mass, max_depth: int = 6,
+                        accumulate: bool = False):
+    """The reference's `--hamiltonian` mode: the Metropolis-Hastings cycle plus one NUTS proposal per iteration
+    (`maybeHamiltonianProposal`, weight 1, app/Definitions.hs:272-274, 104-105 of app/Hamiltonian.hs).  The cycle runs in the lock-step
+    driver, the NUTS transition on the device leapfrog; the states move between the two handles through the host once per
+    iteration (a few KB).  The reference shuffles the NUTS proposal into the cycle; here it closes every iteration.
+    Returns (mean acceptance statistic of the NUTS transitions, mean absolute node ages tH * h_v over chains and
+    iterations [n_nodes] or None)."""
+    alphas = []
+    ages = np.zeros(lf.topo.n_nodes) if accumulate else None
+    for _ in range(n_iter):
+        sampler.run(1)
+        lf.set_state(sampler.state())
+        alpha, _ = nuts_transition(lf, rng, eps, inv_mass, max_depth=max_depth)
+        alphas.append(alpha.mean())
+        s = lf.state()
+        sampler.set_state(s)
+        if accumulate:
+            ages += (s.time_height[:, None] * s.heights).mean(axis=0)
+    return (float(np.mean(alphas)) if alphas else float("nan")), (ages / max(1, n_iter) if accumulate else None)

@@ -385,3 +385,13 @@ def test_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden):
     assert np.median(np.abs(np.log(ratio))) < np.log(1.6) and np.mean(np.abs(np.log(ratio)) < np.log(3.0)) > 0.9, ratio
     alpha, _ = M.nuts_transition(lf2, np.random.default_rng(9), eps_w, inv_mass_w, max_depth=6)
     assert 0.3 < alpha.mean() <= 1.0
+    # the reference's --hamiltonian mode: the Metropolis-Hastings cycle plus one NUTS proposal per iteration
+    a_mean, ages_mix = M.run_cycle_with_nuts(smp, lf2, np.random.default_rng(10), 150, eps_w, inv_mass_w, accumulate=True)
+    rel_mix = np.abs(ages_mix[inner] - ages_mh[inner]) / ages_mh[inner]
+    assert 0.3 < a_mean <= 1.0 and rel_mix.max() <= 0.04, (a_mean, rel_mix)
+    # leapfrog throughput of the device integrator (reported in DESIGN.md)
+    import time
+    lf2.leapfrog(np.zeros((B, lf2.dim)), 1e-3, inv_mass_w, 10)
+    t0 = time.perf_counter()
+    lf2.leapfrog(np.zeros((B, lf2.dim)), 1e-3, inv_mass_w, 200)
+    print("leapfrog: %.1f us per step for %d chains" % (1e6 * (time.perf_counter() - t0) / 200, B))
