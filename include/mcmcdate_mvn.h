@@ -270,6 +270,10 @@ int mcd_mh_tune(mcd_mh_t* m);
 int mcd_mh_get_tuning(const mcd_mh_t* m, double* tune, int32_t* accepted, int32_t* tried);
 int mcd_mh_set_tuning(mcd_mh_t* m, const double* tune);
 int mcd_mh_reset_counters(mcd_mh_t* m);
+/* Reciprocal temperatures beta[batch] in (0, 1] (default 1): chain b accepts with (prior x likelihood)^beta[b], the
+ * heated chains of Metropolis-coupled MCMC (`mc3`, app/Main.hs:476-478; package `mcmc`).  The swap step is the caller's
+ * (mcmc_date_amd.sampler.MC3): it only needs mcd_mh_get_posterior and this call. */
+int mcd_mh_set_temperatures(mcd_mh_t* m, const double* beta);
 /* age_sum / age_sq: [batch][n_nodes] running sums over *n_samples accumulated iterations; reset with the call below. */
 int mcd_mh_get_age_sums(const mcd_mh_t* m, double* age_sum, double* age_sq, int64_t* n_samples);
 int mcd_mh_reset_age_sums(mcd_mh_t* m);

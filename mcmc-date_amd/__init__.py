@@ -12,7 +12,7 @@ from .hmc import DualAveraging, Leapfrog, hmc_transition, nuts_transition, nuts_
 from .hamiltonian import from_vector_with, get_mask, grad_to_vector, target_grad, to_vector
 from .prior import (Brace, Calibration, Constraint, PriorFunction, get_mean_root_height, load_braces,
                     load_calibrations, load_constraints, prior_function)
-from .sampler import Proposal, Sampler, cycle_schedule, init_with, proposals, table_arrays, weight_n_branches
+from .sampler import MC3, Proposal, Sampler, cycle_schedule, init_with, proposals, table_arrays, weight_n_branches
 from .state import State, StateBatch
 from .tree import (Topology, TreeError, branch_slots, get_branches, height_tree_to_length_tree, parse_newick,
                    read_newick_file, sum_first_two)
@@ -24,7 +24,7 @@ __all__ = [
     "sum_first_two", "branch_slots", "height_tree_to_length_tree",
     "Calibration", "Constraint", "Brace", "PriorFunction", "prior_function", "load_calibrations", "load_constraints",
     "load_braces", "get_mean_root_height",
-    "Proposal", "Sampler", "cycle_schedule", "init_with", "proposals", "table_arrays", "weight_n_branches",
+    "MC3", "Proposal", "Sampler", "cycle_schedule", "init_with", "proposals", "table_arrays", "weight_n_branches",
     "Leapfrog", "hmc_transition", "nuts_transition", "nuts_warmup", "run_cycle_with_nuts", "DualAveraging", "get_mask", "to_vector", "from_vector_with", "grad_to_vector", "target_grad",
     "McdError", "NotPositiveDefinite", "RootNotBifurcating", "NoDevice",
 ]

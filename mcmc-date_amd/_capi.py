@@ -71,6 +71,7 @@ SYMBOLS = {
     "mcd_mh_get_tuning": (C.c_int, [_vp, _dp, _ip, _ip]),
     "mcd_mh_set_tuning": (C.c_int, [_vp, _dp]),
     "mcd_mh_reset_counters": (C.c_int, [_vp]),
+    "mcd_mh_set_temperatures": (C.c_int, [_vp, _dp]),
     "mcd_mh_get_age_sums": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64)]),
     "mcd_mh_reset_age_sums": (C.c_int, [_vp]),
 }

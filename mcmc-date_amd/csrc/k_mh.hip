@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, const int3
         const int p = sched[idx_acc];
         const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
         const double lp1 = M.post1[b], ll1 = M.post1[B + b], lj1 = M.post1[2 * B + b];
-        double la = (lp1 + ll1) - (lp + ll) + M.lnqj[b];
+        double la = M.beta[b] * ((lp1 + ll1) - (lp + ll)) + M.lnqj[b];     // heated chains of MC3: posterior^beta; beta = 1 is exact
         if (M.jac_root[p]) la += lj1 - lj;
         double ua, ub;
         philox_block(mh_rng(seed, M.chain0 + b, step_acc), 0xFFFFFFFFu, ua, ub);

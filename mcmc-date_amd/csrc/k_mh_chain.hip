@@ -75,6 +75,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
     const int slot_par = (slot >= 0) ? T.parent[slot] : 0;
     const int rr = T.root_right;
     double age_s = 0.0, age_q = 0.0;
+    const double beta = M.beta[b];
 #ifdef MCD_MH_STAMP
     uint64_t tk[6] = {0, 0, 0, 0, 0, 0};
 #define MH_TICK(i)                                        \
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
             ll1 = V.c + (-0.5) * (V.logdet + q);                           // :169
         }
         MH_TICK(3)
-        double la = (lp1 + ll1) - (lp + ll) + lnqj;
+        double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
         if (M.jac_root[p]) la += lj1 - lj;
         const bool ok = (la >= 0) || (dr.Uacc < exp(la));
         if (ok) {

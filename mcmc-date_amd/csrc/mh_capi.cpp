@@ -217,7 +217,7 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
         (rc = dev_alloc(m.get(), &D.H, BL, true)) || (rc = dev_alloc(m.get(), &D.R, BL, true)) ||
         (rc = dev_alloc(m.get(), &D.sc1, 5 * B, true)) || (rc = dev_alloc(m.get(), &D.H1, BL, true)) ||
         (rc = dev_alloc(m.get(), &D.R1, BL, true)) || (rc = dev_alloc(m.get(), &D.post, 3 * B, true)) ||
-        (rc = dev_alloc(m.get(), &D.post1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.lnqj, B, true)) ||
+        (rc = dev_alloc(m.get(), &D.post1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.lnqj, B, true)) || (rc = dev_alloc(m.get(), &D.beta, B, false)) ||
         (rc = dev_alloc(m.get(), &D.tune, BP, false)) || (rc = dev_alloc(m.get(), &D.acc, BP, true)) ||
         (rc = dev_alloc(m.get(), &D.tried, BP, true)) || (rc = dev_alloc(m.get(), &D.age_sum, BN, true)) ||
         (rc = dev_alloc(m.get(), &D.age_sq, BN, true)))
@@ -236,8 +236,9 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
         m->chain_kernel = true;
     }
     {
-        std::vector<double> ones(BP, 1.0);
+        std::vector<double> ones(BP > B ? BP : B, 1.0);
         MHIP_TRY(hipMemcpy(D.tune, ones.data(), sizeof(double) * BP, hipMemcpyHostToDevice));
+        MHIP_TRY(hipMemcpy(D.beta, ones.data(), sizeof(double) * B, hipMemcpyHostToDevice));
     }
     *out = m.release();
     return MCD_OK;
@@ -393,6 +394,18 @@ int mcd_mh_set_tuning(mcd_mh_t* m, const double* tune)
     MHIP_TRY(hipSetDevice(m->device));
     MHIP_TRY(hipStreamSynchronize(m->stream));
     MHIP_TRY(hipMemcpy(D.tune, tune, sizeof(double) * BP, hipMemcpyHostToDevice));
+    return MCD_OK;
+}
+
+int mcd_mh_set_temperatures(mcd_mh_t* m, const double* beta)
+{
+    if (!m || !beta) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_set_temperatures: NULL argument");
+    const mcd::MhDev& D = m->dev;
+    for (int64_t b = 0; b < D.batch; ++b)
+        if (!(beta[b] > 0) || !(beta[b] <= 1.0)) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_set_temperatures: reciprocal temperatures must be in (0, 1]");
+    MHIP_TRY(hipSetDevice(m->device));
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    MHIP_TRY(hipMemcpy(D.beta, beta, sizeof(double) * (size_t)D.batch, hipMemcpyHostToDevice));
     return MCD_OK;
 }
 

@@ -65,6 +65,7 @@ struct MhDev {
     double *sc1, *H1, *R1;     // proposed state
     double *post, *post1;      // [3][batch] ln prior, ln likelihood, ln jacobianRootBranch (current, proposed)
     double* lnqj;              // [batch] ln (q-ratio * Jacobian) of the pending proposal
+    double* beta;              // [batch] reciprocal temperatures (1 = cold chain); prior and likelihood are raised to beta
     double* tune;              // [batch][n_prop]
     int32_t *acc, *tried;      // [batch][n_prop]
     double *age_sum, *age_sq;  // [batch][n_nodes]

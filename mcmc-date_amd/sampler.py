@@ -314,6 +314,13 @@ class Sampler:
     def reset_counters(self):
         _capi.check(_capi.lib().mcd_mh_reset_counters(self._h))
 
+    def set_temperatures(self, beta: np.ndarray):
+        """Reciprocal temperatures in (0, 1] per chain: chain b accepts with (prior x likelihood)^beta[b] (MC3)."""
+        beta = np.ascontiguousarray(beta, dtype=np.float64)
+        if beta.shape != (self.batch,):
+            raise ValueError("set_temperatures: expected [batch]")
+        _capi.check(_capi.lib().mcd_mh_set_temperatures(self._h, beta.ctypes.data_as(_dp)))
+
     def age_sums(self):
         """(sum, sum of squares [B, n_nodes], n): running sums of the absolute node ages tH * h_v."""
         B, nn = self.batch, self.topo.n_nodes
@@ -336,3 +343,69 @@ class Sampler:
         var = q.sum(axis=0) / (n * self.batch) - mean * mean
         sem = per_chain.std(axis=0, ddof=1) / math.sqrt(self.batch) if self.batch > 1 else np.full_like(mean, np.nan)
         return mean, var, sem
+
+
+# ---- Metropolis-coupled MCMC -- `mc3 (MC3Settings (NChains 4) (SwapPeriod 2) (NSwaps 3))`, app/Main.hs:476-478 -----------
+class MC3:
+    """Metropolis-coupled MCMC (Geyer 1991; Altekar et al. 2004) over the lock-step driver: the batch is cut into groups of
+    `n_chains` chains with reciprocal temperatures `betas` (rank 0 = cold, beta = 1); every `swap_period` iterations
+    `n_swaps` adjacent temperature pairs per group propose to swap, with probability
+    min(1, exp((beta_i - beta_j) (ln pi(x_j) - ln pi(x_i)))), pi = prior x likelihood.  Temperatures move between chains
+    (the states stay where they are), which is the same Markov chain as swapping states.  Only cold chains are
+    reported, like the reference's monitors.  The algorithm lives in the package `mcmc` [external, not vendored]: its
+    initial ladder and its tuning of the ladder are not restated (parity unpinned); the default ladder 0.97^i is this
+    build's choice.  `backend` is a `Sampler` (or anything with run / posterior / set_temperatures / state / batch)."""
+
+    def __init__(self, backend, n_chains: int = 4, swap_period: int = 2, n_swaps: int = 3, betas: Optional[Sequence[float]] = None,
+                 seed: int = 0):
+        if n_chains < 2 or backend.batch % n_chains != 0:
+            raise ValueError("MC3: the batch must be a multiple of n_chains >= 2")
+        if swap_period < 1 or not (1 <= n_swaps <= n_chains - 1):
+            raise ValueError("MC3: need swap_period >= 1 and 1 <= n_swaps <= n_chains - 1")       # mcmc's own checks
+        self.backend, self.n, self.period, self.n_swaps = backend, int(n_chains), int(swap_period), int(n_swaps)
+        self.ladder = np.asarray(betas if betas is not None else [0.97 ** i for i in range(n_chains)], dtype=np.float64)
+        if self.ladder.shape != (n_chains,) or self.ladder[0] != 1.0 or np.any(np.diff(self.ladder) >= 0) or np.any(self.ladder <= 0):
+            raise ValueError("MC3: betas must start at 1 and decrease")
+        self.groups = backend.batch // n_chains
+        self.rank = np.tile(np.arange(n_chains), self.groups)          # temperature rank of every chain
+        self.rng = np.random.default_rng([int(seed), 0x3C3])
+        self.swaps_tried = np.zeros(n_chains - 1, np.int64)
+        self.swaps_accepted = np.zeros(n_chains - 1, np.int64)
+        self.backend.set_temperatures(self.ladder[self.rank])
+
+    def cold(self) -> np.ndarray:
+        """Indices of the chains that are cold right now (one per group)."""
+        return np.nonzero(self.rank == 0)[0]
+
+    def swap(self):
+        """One swap phase: n_swaps distinct adjacent pairs per group, applied one after the other."""
+        post = self.backend.posterior()
+        lnpi = post[:, 0] + post[:, 1]
+        for g in range(self.groups):
+            idx = np.arange(g * self.n, (g + 1) * self.n)
+            for i in self.rng.permutation(self.n - 1)[: self.n_swaps]:
+                a = idx[self.rank[idx] == i][0]
+                c = idx[self.rank[idx] == i + 1][0]
+                log_r = (self.ladder[i] - self.ladder[i + 1]) * (lnpi[c] - lnpi[a])
+                self.swaps_tried[i] += 1
+                if np.log(self.rng.uniform()) < log_r:                 # NaN compares false: no swap
+                    self.rank[a], self.rank[c] = i + 1, i
+                    self.swaps_accepted[i] += 1
+        self.backend.set_temperatures(self.ladder[self.rank])
+
+    def run(self, n_iter: int, collect_ages: bool = False):
+        """n_iter iterations with a swap phase every swap_period iterations.  collect_ages: returns the absolute node ages
+        tH * h_v of the cold chains after every swap phase, [n_phases, groups, n_nodes]."""
+        out = []
+        done = 0
+        while done < n_iter:
+            k = min(self.period, n_iter - done)
+            self.backend.run(k)
+            done += k
+            if k == self.period:
+                self.swap()
+            if collect_ages:
+                s = self.backend.state()
+                c = self.cold()
+                out.append(np.asarray(s.time_height)[c, None] * np.asarray(s.heights)[c])
+        return np.array(out) if collect_ages else None

@@ -125,7 +125,7 @@ def lib(native: bool = False):
     _mp = C.POINTER(_OrmModel)
     L.orm_run.restype = C.c_int
     L.orm_run.argtypes = ([_mp, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64, _ip, C.c_int64, C.c_int32, C.c_uint64,
-                           C.c_uint64, C.c_int64, _dp, _ip, _ip, _dp, _dp, _dp, _dp, C.POINTER(C.c_int8)])
+                           C.c_uint64, C.c_int64, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, C.POINTER(C.c_int8)])
     L.orm_tune.restype = None; L.orm_tune.argtypes = [_mp, C.c_int64, _dp, _ip, _ip]
     L.orm_propose_once.restype = C.c_int
     L.orm_propose_once.argtypes = [_mp, C.c_int, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
@@ -388,6 +388,7 @@ class MhChains:
         self.seed, self.step, self.chain0 = int(seed), 0, int(chain0)
         P, n = model.n_prop, model.n_nodes
         self.tune = np.ones((self.B, P))
+        self.beta = np.ones(self.B)            # reciprocal temperatures (MC3); set_temperatures() of the device driver
         self.acc = np.zeros((self.B, P), np.int32)
         self.tried = np.zeros((self.B, P), np.int32)
         self.post = np.zeros((self.B, 3))
@@ -404,7 +405,7 @@ class MhChains:
         ip = lambda a: a.ctypes.data_as(_ip)
         rc = lib().orm_run(C.byref(self.m.c), self.B, dp(self.birth), dp(self.death), dp(self.tH), dp(self.H), dp(self.rMu),
                            dp(self.rVar), dp(self.R), self.H.shape[1], ip(sched), n_iter, S, self.seed, self.step, self.chain0,
-                           dp(self.tune), ip(self.acc), ip(self.tried), dp(self.post),
+                           dp(self.beta), dp(self.tune), ip(self.acc), ip(self.tried), dp(self.post),
                            dp(self.age_sum) if accumulate else None, dp(self.age_sq) if accumulate else None, dp(ta),
                            tk.ctypes.data_as(C.POINTER(C.c_int8)) if trace else None)
         if rc:

@@ -474,10 +474,11 @@ static void posterior(const orm_model *M, const orm_state *x, double *lp, double
  *   age_sum, age_sq        [batch][n_nodes] or NULL: += tH * H[v] (and its square) after every iteration
  *   trace_alpha            [n_iter * S][batch] or NULL: ln acceptance ratio of every step
  *   trace_accept           [n_iter * S][batch] or NULL
+ *   beta                   [batch] reciprocal temperatures of MC3's heated chains, or NULL (all 1)
  */
 int orm_run(const orm_model *M, int64_t batch, double *birth, double *death, double *tH, double *H, double *rMu,
             double *rVar, double *R, int64_t ld, const int32_t *sched, int64_t n_iter, int32_t S, uint64_t seed,
-            uint64_t step0, int64_t chain0, double *tune, int32_t *acc, int32_t *tried, double *post, double *age_sum, double *age_sq,
+            uint64_t step0, int64_t chain0, const double *beta, double *tune, int32_t *acc, int32_t *tried, double *post, double *age_sum, double *age_sq,
             double *trace_alpha, int8_t *trace_accept)
 {
     const int n = M->n_nodes, P = M->n_prop;
@@ -503,7 +504,7 @@ int orm_run(const orm_model *M, int64_t batch, double *birth, double *death, dou
                 double lnq, lnj, lp1, ll1, lj1, ua[2];
                 propose(M, size, p, tune[b * P + p], &x, &y, &g, &lnq, &lnj);
                 posterior(M, &y, &lp1, &ll1, &lj1);
-                double la = (lp1 + ll1) - (lp + ll) + lnq + lnj;
+                double la = (beta ? beta[b] : 1.0) * ((lp1 + ll1) - (lp + ll)) + lnq + lnj;   /* MC3: posterior^beta */
                 if (M->jac_root[p]) la += lj1 - lj;
                 rng_block(&g, 0xFFFFFFFFu, ua);
                 const int ok = (la >= 0) || (ua[0] < exp(la));   /* NaN compares false => reject */

@@ -304,3 +304,46 @@ def test_device_sampler_recovers_known_marginals(gpu):
     t, acc, tried = smp.tuning()
     rate = acc.sum(axis=0) / np.maximum(1, tried.sum(axis=0))
     assert np.all((rate > 0.05) & (rate < 0.95)), rate     # bounded slides on a three-leaf tree accept often
+
+
+def test_heated_chains_and_mc3(gpu, golden):
+    """`--mc3` of the reference (app/Main.hs:476-478): heated chains accept with (prior x likelihood)^beta -- step-level parity
+    with the CPU twin under non-trivial temperatures -- and the swap phase on top (mcmc_date_amd.sampler.MC3): the cold
+    chains of 16 groups of 4 reproduce the node ages of plain Metropolis-Hastings chains within 2 %."""
+    fx = golden["12-leaves-variable-rate"]
+    topo, ps, smp, twin = setup(fx, B=8, seed=31)
+    beta = np.array([1.0, 0.9, 0.7, 0.5, 1.0, 0.97, 0.97 ** 2, 0.97 ** 3])
+    smp.set_temperatures(beta)
+    twin.beta[:] = beta
+    sched = M.cycle_schedule(ps, 3, np.random.default_rng(1))
+    tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
+    ta, tk = smp.run_schedule(sched, trace=True)
+    ra, rk = twin.run(sched, trace=True)
+    fin = np.isfinite(ra)
+    assert np.array_equal(np.isfinite(ta), fin) and alpha_close(ta[fin], ra[fin], tol) and np.array_equal(tk, rk)
+    compare_states(smp, twin)
+    with pytest.raises(M.McdError):
+        smp.set_temperatures(np.array([1.0, 0.9, 0.7, 0.5, 1.0, 0.97, 0.0, 1.2]))
+    # MC3 proper
+    B = 64
+    _, _, plain, _ = setup(fx, B=B, seed=41)
+    _, _, heated, _ = setup(fx, B=B, seed=42)
+    short = dict(fast=[10, 10, 20, 40, 80], slow=[100, 200, 300, 400])
+    plain.burn_in(**short)
+    plain.run(3000, accumulate=True)
+    ages_plain = plain.node_age_summary()[0]
+    heated.burn_in(**short)
+    mc3 = M.MC3(heated, n_chains=4, swap_period=2, n_swaps=3, seed=5)
+    assert len(mc3.cold()) == 16
+    mc3.run(400)
+    ages = mc3.run(3000, collect_ages=True)
+    assert ages.shape == (1500, 16, topo.n_nodes) and len(mc3.cold()) == 16
+    rate = mc3.swaps_accepted / np.maximum(1, mc3.swaps_tried)
+    assert np.all((rate > 0.05) & (rate <= 1.0)), rate
+    inner = ~topo.leaves
+    rel = np.abs(ages.mean(axis=(0, 1))[inner] - ages_plain[inner]) / ages_plain[inner]
+    assert rel.max() <= 0.02, (rel, rate)
+    with pytest.raises(ValueError):
+        M.MC3(heated, n_chains=5)
+    with pytest.raises(ValueError):
+        M.MC3(heated, n_chains=4, n_swaps=4)
