@@ -7,15 +7,21 @@
 //   getBranches / sumFirstTwo                                       app/Tools.hs:36-48
 //   heightTreeToLengthTree                                          lib/Mcmc/Tree/Types.hs:224-233
 //   I (state record)                                                app/State.hs:70-91
+//   priorFunction ht md cb cs bs                                    app/Probability.hs:127-150
+//   initWith, weightNBranches, proposals (the Metropolis-Hastings cycle)   app/Definitions.hs:96-130, 145-278
+//   the lock-step many-chain driver over that cycle (mhg of package `mcmc`, app/Main.hs:460-479)
 //
 // The reference is Haskell; its toolchain is absent from this image, so the host layer above the
 // C ABI is written in C++ (compiled code, like the reference) -- haskell/McmcDate/Gpu.hs holds the
 // source-level FFI shim a maintainer would add to the reference itself.  Structural faults throw
 // std::runtime_error (the reference calls `error`); numeric NaN/Inf flow through the returned value.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -150,6 +156,9 @@ public:
         return ll;
     }
 
+    const mcd_tree_t* treeHandle() const { return tree_.get(); }
+    const Topology& topology() const { return topo_; }
+
 private:
     Topology topo_;
     std::unique_ptr<mcd_mvn_t, detail::MvnDeleter> mvn_;
@@ -162,5 +171,245 @@ inline std::function<double(const I&)> likelihoodFunction(const LikelihoodData& 
     auto lik = std::make_shared<Likelihood>(lhd, topo, device);
     return [lik](const I& x) { return (*lik)(x); };
 }
+
+// ---- priorFunction -- app/Probability.hs:127-150 ----------------------------------------------------------------------
+enum class RelaxedMolecularClockModel { UncorrelatedGamma = 0, UncorrelatedLogNormal = 1, UncorrelatedWhiteNoise = 2, AutocorrelatedLogNormal = 3 };
+// node = pre-order index; lower / upper: absolute ages, hasLower / hasUpper false = Zero / Infinity (Calibration.hs:108-121)
+struct Calibration { std::string name; int node; bool hasLower; double lower, lowerP; bool hasUpper; double upper, upperP; };
+struct Constraint { std::string name; int young, old; double p; };
+struct Brace { std::string name; std::vector<int> nodes; double sd; };
+
+namespace detail {
+struct PriorDeleter { void operator()(mcd_prior_t* p) const { mcd_prior_destroy(p); } };
+struct MhDeleter { void operator()(mcd_mh_t* p) const { mcd_mh_destroy(p); } };
+}  // namespace detail
+
+class PriorFunction {
+public:
+    PriorFunction(double ht, RelaxedMolecularClockModel md, const std::vector<Calibration>& cb, const std::vector<Constraint>& cs,
+                  const std::vector<Brace>& bs, const Topology& topo, int device = 0)
+        : topo_(topo)
+    {
+        std::vector<int32_t> cn, chl, chh, cy, co, bp{0}, bn;
+        Vec cl, clp, ch, chp, cp, bsd;
+        for (auto& c : cb) {
+            cn.push_back(c.node); chl.push_back(c.hasLower); cl.push_back(c.hasLower ? c.lower : 0.0); clp.push_back(c.hasLower ? c.lowerP : 0.0);
+            chh.push_back(c.hasUpper); ch.push_back(c.hasUpper ? c.upper : 0.0); chp.push_back(c.hasUpper ? c.upperP : 0.0);
+        }
+        for (auto& k : cs) { cy.push_back(k.young); co.push_back(k.old); cp.push_back(k.p); }
+        for (auto& b : bs) {
+            for (int v : b.nodes) bn.push_back(v);
+            bp.push_back((int32_t)bn.size());
+            bsd.push_back(b.sd);
+        }
+        mcd_prior_t* p = nullptr;
+        detail::check(mcd_prior_create(&p, topo.nNodes(), topo.parent.data(), ht, (int)md, (int)cb.size(), cn.data(), chl.data(), cl.data(),
+                                       clp.data(), chh.data(), ch.data(), chp.data(), (int)cs.size(), cy.data(), co.data(), cp.data(),
+                                       (int)bs.size(), bp.data(), bn.data(), bsd.data(), device));
+        prior_.reset(p);
+    }
+    // PriorFunction I: log prior of one state
+    double operator()(const I& x) const
+    {
+        double lp = 0.0;
+        detail::check(mcd_prior_logprior_batch(prior_.get(), &x.timeBirthRate, &x.timeDeathRate, &x.timeHeight, x.timeTree.data(), &x.rateMean,
+                                               &x.rateVariance, x.rateTree.data(), topo_.nNodes(), 1, 0, nullptr, &lp, nullptr));
+        return lp;
+    }
+    const mcd_prior_t* handle() const { return prior_.get(); }
+
+private:
+    Topology topo_;
+    std::unique_ptr<mcd_prior_t, detail::PriorDeleter> prior_;
+};
+
+// ---- initWith -- app/Definitions.hs:96-123 -----------------------------------------------------------------------------
+inline I initWith(const Topology& t, const Vec& lengths)
+{
+    const int n = t.nNodes();
+    Vec ln(lengths);
+    double sum = 0.0;
+    for (int v = 1; v < n; ++v) sum += ln[v];
+    const double avg = sum / (n - 1);
+    for (int v = 1; v < n; ++v)
+        if (ln[v] == 0.0) ln[v] = avg;
+    ln[0] = 0.0;
+    std::vector<char> leaf(n, 1);
+    for (int v = 1; v < n; ++v) leaf[t.parent[v]] = 0;
+    Vec dist(n, 0.0);
+    double height = 0.0;
+    for (int v = 1; v < n; ++v) dist[v] = dist[t.parent[v]] + ln[v];
+    for (int v = 0; v < n; ++v)
+        if (leaf[v]) height = std::max(height, dist[v]);
+    I x;
+    x.timeTree.assign(n, 0.0);
+    x.rateTree.assign(n, 1.0);
+    for (int v = 0; v < n; ++v) x.timeTree[v] = leaf[v] ? 0.0 : (height - dist[v]) / height;
+    x.timeTree[0] = 1.0;
+    x.rateTree[0] = 0.0;
+    return x;
+}
+
+// ---- proposals -- app/Definitions.hs:127-278 ----------------------------------------------------------------------------
+struct Proposal {
+    std::string name;
+    int kind = 0, node = 0;
+    double p0 = 1.0, p1 = 0.0;
+    int n1 = 0, n2 = 0;
+    bool jacRoot = false;   // liftProposalWith jacobianRootBranch
+    int dim = 1, weight = 1;
+};
+
+inline int weightNBranches(int n) { return (int)std::floor(std::log((double)n) / std::log(1.3)); }   // :127-130
+
+// The cycle of `proposals bs calibrationsAvailable x Nothing` in the reference's order (kinds: MCD_PROP_*).
+inline std::vector<Proposal> proposals(const Topology& topo, const std::vector<Brace>& braces, bool calibrationsAvailable,
+                                       bool exactJacobians = false)
+{
+    const int n = topo.nNodes();
+    std::vector<int> size(n, 1), inner(n, 0), levels(n, 1), plen(n, 0), nch(n, 0);
+    std::vector<char> leaf(n, 1);
+    for (int v = 1; v < n; ++v) { leaf[topo.parent[v]] = 0; plen[v] = plen[topo.parent[v]] + 1; nch[topo.parent[v]]++; }
+    for (int v = 0; v < n; ++v) inner[v] = leaf[v] ? 0 : 1;
+    for (int v = n - 1; v > 0; --v) {
+        const int p = topo.parent[v];
+        size[p] += size[v];
+        inner[p] += inner[v];
+        levels[p] = std::max(levels[p], levels[v] + 1);
+    }
+    const int w = weightNBranches(n);
+    auto [l, r] = topo.rootChildren();
+    std::vector<Proposal> ps;
+    auto add = [&](std::string name, int kind, int node, double p0, double p1, int n1, int n2, bool jac, int dim, int weight) {
+        ps.push_back(Proposal{std::move(name), kind, node, p0, p1, n1, n2, jac, dim, weight});
+    };
+    auto subW = [&](int v) { return std::min(3 + levels[v] - 2, 8); };
+    add("Time birth rate", MCD_PROP_SCALE_SCALAR, 0, 10.0, 0, 0, 0, false, 1, w);
+    add("Time death rate", MCD_PROP_SCALE_SCALAR, 1, 10.0, 0, 0, 0, false, 1, w);
+    add("Rate mean", MCD_PROP_SCALE_SCALAR, 3, 10.0, 0, 0, 0, false, 1, w);
+    add("Rate variance", MCD_PROP_SCALE_SCALAR, 4, 10.0, 0, 0, 0, false, 1, w);
+    const int nInner = inner[0];
+    if (nInner - 1 < 1) throw std::runtime_error("scaleRatesAndTreeContrarilyPFunction: no internal nodes to scale");
+    add("Rates and time tree", MCD_PROP_SCALE_RATES_TREE_CONTRA, 0, 0.1, 0, nInner - 1, 0, true, nInner - 1 + 2, w);
+    auto group = [&](bool atRoot) { return [&, atRoot](int v) { return atRoot ? plen[v] == 1 : plen[v] > 1; }; };
+    auto timePs = [&](bool atRoot, const std::string& tag) {
+        auto hn = group(atRoot);
+        for (int v = 0; v < n; ++v)
+            if (!leaf[v] && hn(v)) add(tag + " Time tree node " + std::to_string(v), MCD_PROP_SLIDE_NODE, v, 0.01, 0, 0, 0, atRoot, 1, 5);
+        for (int v = 0; v < n; ++v)
+            if (!leaf[v] && hn(v)) add(tag + " Time tree node " + std::to_string(v), MCD_PROP_SCALE_SUBTREE_TIME, v, 0.01, 0, inner[v], 0, atRoot, inner[v], subW(v));
+    };
+    if (!leaf[l] && !leaf[r]) add("[R] Time tree", MCD_PROP_PULLEY, 0, 0.01, 0, inner[l], inner[r], true, inner[l] + inner[r], 6);
+    timePs(true, "[R]");
+    timePs(false, "[O]");
+    for (size_t i = 0; i < braces.size(); ++i)
+        add("[B] Time tree " + braces[i].name, MCD_PROP_SLIDE_BRACE, (int)i, 0.01, 0, 0, 0, false, (int)braces[i].nodes.size(), 5);
+    add("[R] Rate mean, Rate tree", MCD_PROP_SCALE_NORM_TREE, 3, 100.0, 0, 0, 0, true, n, w);
+    add("[R] Rate variance, Rate tree", MCD_PROP_SCALE_VAR_TREE, 0, 100.0, exactJacobians ? 1.0 : 0.0, 0, 0, true, n, w);
+    add("[R] Rate variance, Rate tree (autocorrelated)", MCD_PROP_SCALE_VAR_TREE_AUTO, 0, 100.0, 0, 0, 0, true, n, w);
+    auto ratePs = [&](bool atRoot, const std::string& tag) {
+        auto hn = group(atRoot);
+        for (int v = 0; v < n; ++v)
+            if (hn(v)) add(tag + " Rate tree branch " + std::to_string(v), MCD_PROP_SCALE_BRANCH_RATE, v, 100.0, 0, 0, 0, atRoot, 1, 3);
+        for (int v = 0; v < n; ++v)
+            if (!leaf[v] && hn(v)) add(tag + " Rate tree node " + std::to_string(v), MCD_PROP_SCALE_SUBTREE_RATE, v, 100.0, 0, size[v], 0, atRoot, size[v], subW(v));
+    };
+    ratePs(true, "[R]");
+    ratePs(false, "[O]");
+    auto contraPs = [&](bool atRoot, const std::string& tag) {
+        auto hn = group(atRoot);
+        for (int v = 0; v < n; ++v)
+            if (!leaf[v] && hn(v)) add(tag + " Trees node " + std::to_string(v), MCD_PROP_SLIDE_NODE_CONTRA, v, 0.1, 0, 0, 0, atRoot, 1 + 1 + nch[v], subW(v));
+        for (int v = 0; v < n; ++v)
+            if (!leaf[v] && hn(v)) add(tag + " Trees node " + std::to_string(v), MCD_PROP_SCALE_SUBTREE_CONTRA, v, 0.1, 0, inner[v], size[v], atRoot, inner[v] + size[v], subW(v));
+    };
+    contraPs(true, "[C] [R]");
+    contraPs(false, "[C] [O]");
+    for (size_t i = 0; i < braces.size(); ++i) {
+        int daughters = 0;
+        for (int x : braces[i].nodes) daughters += nch[x];
+        add("[C] [B] Trees " + braces[i].name, MCD_PROP_SLIDE_BRACE_CONTRA, (int)i, 0.1, 0, 0, 0, false, 2 * (int)braces[i].nodes.size() + daughters, 5);
+    }
+    if (calibrationsAvailable) {
+        add("Time height", MCD_PROP_SCALE_SCALAR, 2, 3000.0, 0, 0, 0, false, 1, w);
+        add("Time height, rate mean", MCD_PROP_SCALE_CONTRARILY, 0, 10.0, 0.1, 0, 0, false, 2, w);
+        add("[R] Time height, Rate tree", MCD_PROP_SCALE_NORM_TREE, 2, 100.0, 0, 0, 0, true, n, w);
+        add("[R] Trees", MCD_PROP_SLIDE_ROOT_CONTRA, 0, 10.0, 0, exactJacobians ? nInner - 1 : nInner, 0, true, 1 + nInner + 2, w);
+    }
+    return ps;
+}
+
+// One iteration of `mcmc`'s default cycle order: every proposal `weight` times, freshly shuffled.
+template <class Rng>
+inline std::vector<int32_t> cycleSchedule(const std::vector<Proposal>& ps, int nIter, Rng& rng)
+{
+    std::vector<int32_t> base;
+    for (size_t i = 0; i < ps.size(); ++i) base.insert(base.end(), ps[i].weight, (int32_t)i);
+    std::vector<int32_t> out;
+    for (int it = 0; it < nIter; ++it) {
+        std::shuffle(base.begin(), base.end(), rng);
+        out.insert(out.end(), base.begin(), base.end());
+    }
+    return out;
+}
+
+// B chains in lock step on one GPU (mhg of package `mcmc`, one state per call, becomes many chains per call).
+class Sampler {
+public:
+    Sampler(const Likelihood& lik, const PriorFunction& prior, std::vector<Proposal> table, int64_t batch, uint64_t seed)
+        : topo_(lik.topology()), table_(std::move(table)), batch_(batch)
+    {
+        std::vector<int32_t> kind, node, n1, n2, jac, dim;
+        Vec p0, p1;
+        for (auto& p : table_) {
+            kind.push_back(p.kind); node.push_back(p.node); n1.push_back(p.n1); n2.push_back(p.n2); jac.push_back(p.jacRoot); dim.push_back(p.dim);
+            p0.push_back(p.p0); p1.push_back(p.p1);
+        }
+        mcd_mh_t* m = nullptr;
+        detail::check(mcd_mh_create(&m, lik.treeHandle(), prior.handle(), (int)table_.size(), kind.data(), node.data(), n1.data(), n2.data(),
+                                    jac.data(), dim.data(), p0.data(), p1.data(), batch, seed));
+        mh_.reset(m);
+        stepsPerIteration_ = 0;
+        for (auto& p : table_) stepsPerIteration_ += p.weight;
+    }
+    void setInitialState(const I& x)   // every chain starts from the same state, like the reference's single chain
+    {
+        const int nn = topo_.nNodes();
+        Vec b(batch_, x.timeBirthRate), d(batch_, x.timeDeathRate), t(batch_, x.timeHeight), m(batch_, x.rateMean), v(batch_, x.rateVariance), H, R;
+        for (int64_t c = 0; c < batch_; ++c) { H.insert(H.end(), x.timeTree.begin(), x.timeTree.end()); R.insert(R.end(), x.rateTree.begin(), x.rateTree.end()); }
+        detail::check(mcd_mh_set_state(mh_.get(), b.data(), d.data(), t.data(), H.data(), m.data(), v.data(), R.data(), nn));
+    }
+    void run(const std::vector<int32_t>& schedule, bool accumulate = false)
+    {
+        detail::check(mcd_mh_run(mh_.get(), schedule.data(), (int64_t)schedule.size() / stepsPerIteration_, stepsPerIteration_, accumulate, nullptr, nullptr));
+    }
+    void autoTune() { detail::check(mcd_mh_tune(mh_.get())); }
+    I state(int64_t chain) const
+    {
+        const int nn = topo_.nNodes();
+        Vec b(batch_), d(batch_), t(batch_), m(batch_), v(batch_), H((size_t)batch_ * nn), R((size_t)batch_ * nn);
+        detail::check(mcd_mh_get_state(mh_.get(), b.data(), d.data(), t.data(), H.data(), m.data(), v.data(), R.data(), nn));
+        I x;
+        x.timeBirthRate = b[chain]; x.timeDeathRate = d[chain]; x.timeHeight = t[chain]; x.rateMean = m[chain]; x.rateVariance = v[chain];
+        x.timeTree.assign(H.begin() + chain * nn, H.begin() + (chain + 1) * nn);
+        x.rateTree.assign(R.begin() + chain * nn, R.begin() + (chain + 1) * nn);
+        return x;
+    }
+    // [batch][3]: ln prior, ln likelihood, ln jacobianRootBranch of the current states
+    Vec posterior() const
+    {
+        Vec post((size_t)batch_ * 3);
+        detail::check(mcd_mh_get_posterior(mh_.get(), post.data()));
+        return post;
+    }
+    int stepsPerIteration() const { return stepsPerIteration_; }
+
+private:
+    Topology topo_;
+    std::vector<Proposal> table_;
+    int64_t batch_;
+    int stepsPerIteration_ = 0;
+    std::unique_ptr<mcd_mh_t, detail::MhDeleter> mh_;
+};
 
 }  // namespace mcmcdate

@@ -6,11 +6,86 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <string>
 
 #include "../../mcmc-date_amd/host/mcmcdate.hpp"
 
+// Second mode (tests/test_gpu_mh.py::test_cpp_sampler_mirror): `test_host_mirror --sampler fixture.txt`.
+// Fixture: n_nodes, parent[], mu[], sigma_inv[], logdet, ht, clock model, calibrations, constraints, braces, mean branch
+// lengths, batch, seed, n_sched, schedule[].  Builds priorFunction, the proposal cycle and the sampler in C++, starts all
+// chains from initWith, runs the given schedule and prints the proposal table summary, the log prior of the initial state
+// and the [batch][3] posterior after the run; the Python test repeats the same run through the Python mirror and expects
+// identical numbers.
+static int sampler_mode(const char* path)
+{
+    using namespace mcmcdate;
+    std::ifstream f(path);
+    int nn;
+    f >> nn;
+    Topology topo;
+    topo.parent.resize(nn);
+    for (auto& p : topo.parent) f >> p;
+    const int n = nn - 2;
+    Full full;
+    full.mu.resize(n);
+    full.sigmaInv.resize((size_t)n * n);
+    for (auto& v : full.mu) f >> v;
+    for (auto& v : full.sigmaInv) f >> v;
+    f >> full.logDetSigma;
+    double ht;
+    int model, ncal, ncon, nbr;
+    f >> ht >> model >> ncal;
+    std::vector<Calibration> cb(ncal);
+    for (auto& c : cb) { int hl, hh; f >> c.node >> hl >> c.lower >> c.lowerP >> hh >> c.upper >> c.upperP; c.hasLower = hl; c.hasUpper = hh; c.name = "c"; }
+    f >> ncon;
+    std::vector<Constraint> cs(ncon);
+    for (auto& k : cs) { f >> k.young >> k.old >> k.p; k.name = "k"; }
+    f >> nbr;
+    std::vector<Brace> bs(nbr);
+    for (auto& b : bs) { int m; f >> m >> b.sd; b.nodes.resize(m); for (auto& v : b.nodes) f >> v; b.name = "b"; }
+    Vec lengths(nn);
+    for (auto& v : lengths) f >> v;
+    long long batch;
+    unsigned long long seed;
+    size_t nsched;
+    f >> batch >> seed >> nsched;
+    std::vector<int32_t> sched(nsched);
+    for (auto& s : sched) f >> s;
+    if (!f) { std::fprintf(stderr, "bad fixture\n"); return 2; }
+    Likelihood lik(LikelihoodData{full}, topo);
+    PriorFunction prior(ht, (RelaxedMolecularClockModel)model, cb, cs, bs, topo);
+    auto ps = proposals(topo, bs, ncal > 0);
+    int wsum = 0;
+    long long kindsum = 0, nodesum = 0, dimsum = 0;
+    for (auto& p : ps) { wsum += p.weight; kindsum += p.kind; nodesum += p.node; dimsum += p.dim; }
+    std::printf("table %zu %d %lld %lld %lld %d\n", ps.size(), wsum, kindsum, nodesum, dimsum, weightNBranches(nn));
+    I x0 = initWith(topo, lengths);
+    if (ncal > 0) x0.timeHeight = ht;
+    std::printf("prior0 %.17g lik0 %.17g\n", prior(x0), lik(x0));
+    Sampler smp(lik, prior, ps, batch, seed);
+    smp.setInitialState(x0);
+    smp.run(sched);
+    const Vec post = smp.posterior();
+    for (long long b = 0; b < batch; ++b) std::printf("post %lld %.17g %.17g %.17g\n", b, post[b * 3], post[b * 3 + 1], post[b * 3 + 2]);
+    const I last = smp.state(batch - 1);
+    std::printf("state %.17g %.17g %.17g\n", last.timeHeight, last.timeTree[1], last.rateTree[nn - 1]);
+    std::mt19937_64 rng(1);
+    const auto cyc = cycleSchedule(ps, 2, rng);
+    if ((int)cyc.size() != 2 * smp.stepsPerIteration()) return 1;
+    std::puts("ok");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 3 && std::string(argv[1]) == "--sampler") {
+        try {
+            return sampler_mode(argv[2]);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "exception: %s\n", e.what());
+            return 3;
+        }
+    }
     if (argc < 2) { std::fprintf(stderr, "usage: test_host_mirror fixture.txt\n"); return 2; }
     std::ifstream f(argv[1]);
     int nn;

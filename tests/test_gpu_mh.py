@@ -347,3 +347,51 @@ def test_heated_chains_and_mc3(gpu, golden):
         M.MC3(heated, n_chains=5)
     with pytest.raises(ValueError):
         M.MC3(heated, n_chains=4, n_swaps=4)
+
+
+def test_cpp_sampler_mirror(gpu, golden, tmp_path):
+    """The C++ host mirror (mcmc-date_amd/host/mcmcdate.hpp: priorFunction, initWith, proposals, Sampler) against the Python
+    mirror: same proposal table, same initial prior / likelihood, and after the same schedule with the same seed the same
+    posterior triples and states, bit for bit (both sit on the same C ABI)."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_host_mirror")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    fx = golden["24-leaves-braces"]
+    B, seed = 4, 17
+    topo, ps, smp, _ = setup(fx, B=B, seed=seed)
+    sched = M.cycle_schedule(ps, 2, np.random.default_rng(3))
+    r = lambda v: repr(float(v))
+    p = tmp_path / "sampler.txt"
+    with open(p, "w") as f:
+        f.write(f"{len(fx['parent'])}\n" + " ".join(map(str, fx["parent"])) + "\n")
+        f.write(" ".join(r(v) for v in fx["mu"]) + "\n" + " ".join(r(v) for v in fx["sigma_inv"].ravel()) + "\n" + r(fx["logdet"]) + "\n")
+        f.write(f"{r(fx['prior_ht'])} 0 {len(fx['cal'])}\n")
+        for c in fx["cal"]:
+            f.write(f"{int(c[0])} {int(c[1])} {r(c[2])} {r(c[3])} {int(c[4])} {r(c[5])} {r(c[6])}\n")
+        f.write(f"{len(fx['con'])}\n")
+        for c in fx["con"]:
+            f.write(f"{int(c[0])} {int(c[1])} {r(c[2])}\n")
+        f.write(f"{len(fx['brace_sd'])}\n")
+        for i, sd in enumerate(fx["brace_sd"]):
+            nodes = fx["brace_nodes"][fx["brace_ptr"][i]:fx["brace_ptr"][i + 1]]
+            f.write(f"{len(nodes)} {r(sd)} " + " ".join(str(int(v)) for v in nodes) + "\n")
+        f.write(" ".join(r(v) for v in fx["mean_lengths"]) + "\n")
+        f.write(f"{B} {seed} {sched.size}\n" + " ".join(str(int(v)) for v in sched.ravel()) + "\n")
+    out = subprocess.run([exe, "--sampler", str(p)], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    tab = [int(v) for v in lines[0].split()[1:]]
+    assert tab == [len(ps), sum(q.weight for q in ps), sum(q.kind for q in ps), sum(q.node for q in ps), sum(q.dim for q in ps),
+                   M.weight_n_branches(topo.n_nodes)]
+    post0 = smp.posterior()
+    p0 = [float(v) for v in (lines[1].split()[1], lines[1].split()[3])]
+    assert p0[0] == post0[0, 0] and p0[1] == post0[0, 1]
+    smp.run_schedule(sched)
+    post = smp.posterior()
+    got = np.array([[float(v) for v in l.split()[2:]] for l in lines if l.startswith("post ")])
+    assert np.array_equal(got, post)
+    s = smp.state()
+    st = [float(v) for v in [l for l in lines if l.startswith("state ")][0].split()[1:]]
+    assert st == [s.time_height[B - 1], s.heights[B - 1, 1], s.rates[B - 1, topo.n_nodes - 1]]
