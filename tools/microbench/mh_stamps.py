@@ -1,3 +1,6 @@
+"""Phase stamps of the Metropolis-Hastings chain kernel (cycles per step: loop head, propose, prior, likelihood, accept).
+Build the stamped library first:  make -C mcmc-date_amd/csrc stamp_mh   (writes tools/microbench/libmhstamp.so),
+then on the GPU box:  python tools/microbench/mh_stamps.py [chains]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MCD_LIB_PATH"] = os.path.join(ROOT, "tools", "microbench", "libmhstamp.so")
