@@ -90,6 +90,8 @@ def lib(native: bool = False):
     L.orc_tree_grad_full.argtypes = [C.c_int, _ip, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_logpdf_full_batch.restype = None
     L.orc_logpdf_full_batch.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, C.c_int64, C.c_int64, _dp]
+    L.orc_logpdf_full_batch_mt.restype = None
+    L.orc_logpdf_full_batch_mt.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, C.c_int64, C.c_int64, _dp]
     L.orc_logpdf_chol_batch.restype = None
     L.orc_logpdf_chol_batch.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int64, C.c_int64, _dp]
     L.orc_grad_full_batch.restype = None
@@ -165,11 +167,12 @@ def logpdf_full_ld(mu, sigma_inv, logdet, x) -> float:
     return float(lib().orc_logpdf_full_ld(len(mu), pm, pp, float(logdet), px))
 
 
-def logpdf_full_batch(mu, sigma_inv, logdet, X, native=False) -> np.ndarray:
-    """X: [batch, n] chain-major."""
+def logpdf_full_batch(mu, sigma_inv, logdet, X, native=False, all_cores=False) -> np.ndarray:
+    """X: [batch, n] chain-major.  all_cores: chains split over the host's cores (OpenMP; OMP_NUM_THREADS)."""
     mu, pm = _d(mu); P, pp = _d(sigma_inv); X, px = _d(X)
     out = np.empty(X.shape[0]); po = out.ctypes.data_as(_dp)
-    lib(native).orc_logpdf_full_batch(len(mu), pm, pp, float(logdet), px, X.shape[1], X.shape[0], po)
+    f = lib(native).orc_logpdf_full_batch_mt if all_cores else lib(native).orc_logpdf_full_batch
+    f(len(mu), pm, pp, float(logdet), px, X.shape[1], X.shape[0], po)
     return out
 
 

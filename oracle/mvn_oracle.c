@@ -369,6 +369,14 @@ void orc_logpdf_full_batch(int n, const double *mu, const double *sigma_inv, dou
     for (int64_t b = 0; b < batch; ++b) ll[b] = orc_logpdf_full(n, mu, sigma_inv, logdet_sigma, X + b * ld);
 }
 
+/* the same, chains split statically over the host's cores (bench.py cpu_baseline, all-core figure) */
+void orc_logpdf_full_batch_mt(int n, const double *mu, const double *sigma_inv, double logdet_sigma,
+                              const double *X, int64_t ld, int64_t batch, double *ll)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < batch; ++b) ll[b] = orc_logpdf_full(n, mu, sigma_inv, logdet_sigma, X + b * ld);
+}
+
 void orc_logpdf_chol_batch(int n, const double *mu, const double *L, const double *X, int64_t ld,
                            int64_t batch, double *ll)
 {
