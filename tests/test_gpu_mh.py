@@ -122,17 +122,18 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(fused.age_sums()[:2], phased.age_sums()[:2]))
 
 
-def test_large_tree_uses_the_per_phase_path(gpu):
-    """A synthetic 70-leaf tree (139 nodes, N = 137, three row blocks): lanes stride over the nodes and the likelihood
-    runs through the streaming kernel; parity with the CPU twin as for the small trees."""
+@pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150)])
+def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
+    """Synthetic trees beyond 64 nodes (70 leaves: 139 nodes, N = 137, three row blocks; 128 leaves: 255 nodes, N = 253,
+    the size of BASELINE.json's config 3, with 64 chains): lanes stride over the nodes and the likelihood runs through
+    the streaming kernel, two launches per step; parity with the CPU twin as for the small trees."""
     from mcmc_date_amd import synthetic as S
 
-    topo = S.random_topology(70, seed=3)
+    topo = S.random_topology(n_leaves, seed=3)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=3)
     sigma_inv = np.linalg.inv(sigma)
     logdet = float(np.linalg.slogdet(sigma)[1])
-    B = 6
     s0 = S.random_states(topo, B, seed=4)
     s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
     ps, _ = M.proposals(topo, [], calibrations_available=True)
@@ -143,7 +144,7 @@ def test_large_tree_uses_the_per_phase_path(gpu):
     spec = O.PriorSpec(topo.parent, 1.0, "UncorrelatedGamma", [], [], [])
     twin = O.MhChains(O.MhModel(topo.parent, mu, sigma_inv, logdet, spec, M.table_arrays(ps)), s0.time_birth_rate, s0.time_death_rate,
                       s0.time_height, s0.heights, s0.rate_mean, s0.rate_variance, s0.rates, seed=13)
-    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :400]
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :n_steps]
     tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
     ta, tk = smp.run_schedule(sched, trace=True)
     ra, rk = twin.run(sched, trace=True)
