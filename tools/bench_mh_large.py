@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Lock-step Metropolis-Hastings on a synthetic large tree (two launches per step): microseconds per lock step.
+Usage: python tools/bench_mh_large.py [n_leaves=128] [chains=512] [steps=2000]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import mcmc_date_amd as M
+    from mcmc_date_amd import synthetic as S
+
+    n_leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+    topo = S.random_topology(n_leaves, seed=3)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=3)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    s0 = S.random_states(topo, B, seed=4)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    smp = M.Sampler(lik, pf, ps, B, seed=13)
+    smp.set_state(s0)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))
+    reps = max(1, steps // sched.shape[1] + 1)
+    sched = np.tile(sched, (1, reps))[:, :steps]
+    smp.run_schedule(sched[:, :200])
+    t0 = time.perf_counter()
+    smp.run_schedule(sched)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "MH lock step, large tree", "n_nodes": topo.n_nodes, "chains": B, "steps": steps,
+                      "us_per_lockstep": 1e6 * dt / steps, "steps_per_s": B * steps / dt, "proposals_per_iteration": int(sum(p.weight for p in ps))}))
+
+
+if __name__ == "__main__":
+    main()
