@@ -27,16 +27,17 @@
 
 namespace mcd {
 
-// One launch between two likelihood launches: ACCEPT step `idx_acc` (its proposed state, ln prior, ln likelihood and
-// ln jacobianRootBranch are in H1/R1/sc1/post1) and PROPOSE step `idx_prop` together with the ln prior of its proposed
-// state.  Either half is skipped with a negative index (first / last launch of a run).  One wave per chain; the current
+// One launch between two likelihood launches: ACCEPT the pending step (proposal p_acc; its proposed state, ln prior, ln
+// likelihood and ln jacobianRootBranch are in H1/R1/sc1/post1) and PROPOSE the next one (proposal p_prop, its table row
+// passed by value) together with the ln prior of its proposed state.  Either half is skipped with a negative proposal
+// id (first / last launch of a run).  One wave per chain; the current
 // and the proposed heights and rates are staged in LDS (one region per wave), so no lane ever reads through global memory
 // what another lane of its wave has just written.
 //   accept:  post = (ln prior, ln likelihood, ln jacobianRootBranch), [3][batch]; counters; optional trace; running sums
 //            of the absolute node ages tH * h_v when the step closes an iteration (`accumulate_now`)
 //   propose: writes sc1, H1, R1, lnqj (ln q-ratio * Jacobian without the root-branch factor), post1[0] = ln prior
-__global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, const int32_t* __restrict__ sched, int64_t idx_acc,
-                                                 int64_t idx_prop, uint64_t step_acc, uint64_t seed, int accumulate_now,
+__global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc, int jac_root_acc, int p_prop, PropRow row_prop,
+                                                 uint64_t step_acc, uint64_t seed, int accumulate_now,
                                                  double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
 {
     extern __shared__ double sh[];
@@ -51,12 +52,12 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, const int3
     double* Hs = Rc + n;
     double* Rs = Hs + n;
     bool ok = false;
-    if (idx_acc >= 0) {
-        const int p = sched[idx_acc];
+    if (p_acc >= 0) {
+        const int p = p_acc;
         const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
         const double lp1 = M.post1[b], ll1 = M.post1[B + b], lj1 = M.post1[2 * B + b];
         double la = M.beta[b] * ((lp1 + ll1) - (lp + ll)) + M.lnqj[b];     // heated chains of MC3: posterior^beta; beta = 1 is exact
-        if (M.jac_root[p]) la += lj1 - lj;
+        if (jac_root_acc) la += lj1 - lj;
         double ua, ub;
         philox_block(mh_rng(seed, M.chain0 + b, step_acc), 0xFFFFFFFFu, ua, ub);
         ok = (la >= 0) || (ua < exp(la));
@@ -100,12 +101,11 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, const int3
             M.age_sq[b * n + w] += a * a;
         }
     }
-    if (idx_prop < 0) return;
+    if (p_prop < 0) return;
     __builtin_amdgcn_wave_barrier();
-    const int p = sched[idx_prop];
-    const double t = M.tune[b * M.n_prop + p];
-    const StepDraws dr = mh_step_draws(M, p, t, mh_rng(seed, M.chain0 + b, step_acc + 1));
-    const double lnqj = mh_propose_wave(M, p, t, dr, lane, sc, Hc, Rc, Hs, Rs);
+    const double t = M.tune[b * M.n_prop + p_prop];
+    const StepDraws dr = mh_step_draws(row_prop, t, mh_rng(seed, M.chain0 + b, step_acc + 1));
+    const double lnqj = mh_propose_wave(M, row_prop, t, dr, lane, sc, Hc, Rc, Hs, Rs);
     __builtin_amdgcn_wave_barrier();
     const double lp1 = prior_eval_wave(P, lane, sc[0], sc[1], sc[2], sc[3], sc[4], Hs, Rs, nullptr);
     for (int w = lane; w < n; w += 64) {
@@ -143,15 +143,16 @@ __global__ __launch_bounds__(256) void k_mh_tune(MhDev M)
     M.tried[i] = 0;
 }
 
-hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t idx_acc, int64_t idx_prop, uint64_t step_acc,
+hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, uint64_t step_acc,
                           uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
 {
     const size_t per_wave = sizeof(double) * 4 * (size_t)M.n_nodes;
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;
     if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_mh_step, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, sched, idx_acc, idx_prop,
-                       step_acc, seed, accumulate_now, trace_alpha, trace_accept);
+    const PropRow row{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
+    hipLaunchKernelGGL(k_mh_step, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, p_acc, jac_root_acc, p_prop,
+                       row, step_acc, seed, accumulate_now, trace_alpha, trace_accept);
     return hipGetLastError();
 }
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st)

@@ -90,9 +90,11 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
 #endif
     __builtin_amdgcn_wave_barrier();
     int p = sched[0];
+    PropRow row = mh_load_row(M, p);
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                 // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
         const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : 0;
+        const PropRow row_next = mh_load_row(M, p_next);            // the next step's row travels while this step computes
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: the random draws that depend only on the proposal row and its
             // tuning parameter (gamma multipliers with their ratio and logarithm, the uniforms of the truncated normals
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
             const int64_t mine = gs + lane;
             if (mine < n_steps) {
                 const int pl = sched[mine];
-                pre = mh_step_draws(M, pl, tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
+                pre = mh_step_draws(mh_load_row(M, pl), tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
             }
         }
         const int sl = (int)(gs & 63);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
         MH_TICK(0)
-        const double lnqj = mh_propose_wave(M, p, tune[p], dr, lane, sc1, Hc, Rc, Hp, Rp);
+        const double lnqj = mh_propose_wave(M, row, tune[p], dr, lane, sc1, Hc, Rc, Hp, Rp);
         __builtin_amdgcn_wave_barrier();
         MH_TICK(1)
         const bool dH = __builtin_amdgcn_ballot_w64(Hp[lane] != Hc[lane]) != 0;     // NaN != NaN: re-evaluated
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
         }
         MH_TICK(3)
         double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
-        if (M.jac_root[p]) la += lj1 - lj;
+        if (row.jac_root) la += lj1 - lj;
         const bool ok = (la >= 0) || (dr.Uacc < exp(la));
         if (ok) {
             Hc[lane] = Hp[lane];
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
             age_q += a * a;
         }
         p = p_next;
+        row = row_next;
         MH_TICK(4)
     }
 #ifdef MCD_MH_STAMP

@@ -46,6 +46,7 @@ struct mcd_mh {
     int64_t n_samples = 0;
     bool have_state = false;
     bool chain_kernel = false;   // n_nodes <= 64: whole schedule in one launch
+    std::vector<mcd::MhRow> rows;   // host copy of the proposal table
     const double* d_Fp = nullptr;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
@@ -195,6 +196,7 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     }
     m->device = dev_t;
     m->seed = seed;
+    for (int i = 0; i < n_prop; ++i) m->rows.push_back(mcd::MhRow{kind[i], node[i], n1[i], n2[i], jac_root[i], p0[i], p1[i]});
     MHIP_TRY(hipSetDevice(m->device));
     MHIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     mcd::MhDev& D = m->dev;
@@ -344,12 +346,14 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // two launches per step: [accept step s-1 + propose step s + ln prior] and [likelihood + root-branch Jacobian]
         const int64_t total = (int64_t)steps;
         if ((size_t)D.n_nodes * 32 > 64 * 1024) return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_run: more than 2048 nodes");
-        MHIP_TRY(mcd::launch_mh_step(D, *m->prior, m->d_sched, -1, 0, m->step - 1, m->seed, 0, nullptr, nullptr, m->stream));
+        const mcd::MhRow none{0, 0, 0, 0, 0, 1.0, 0.0};
+        MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], m->step - 1, m->seed, 0, nullptr, nullptr, m->stream));
         for (int64_t gs = 0; gs < total; ++gs) {
             MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
                                              D.post1 + D.batch, D.post1 + 2 * D.batch, m->stream));
             const bool closes = ((gs + 1) % S) == 0;
-            MHIP_TRY(mcd::launch_mh_step(D, *m->prior, m->d_sched, gs, (gs + 1 < total) ? gs + 1 : -1, m->step, m->seed,
+            const int pa = schedule[gs], pn = (gs + 1 < total) ? schedule[gs + 1] : -1;
+            MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, m->step, m->seed,
                                          (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
                                          trace ? m->d_trace_accept + gs * B : nullptr, m->stream));
             m->step += 1;

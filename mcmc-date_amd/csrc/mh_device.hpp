@@ -134,6 +134,18 @@ __device__ __forceinline__ Rng mh_rng(uint64_t seed, int64_t chain, uint64_t ste
     return Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)chain, (uint32_t)step, (uint32_t)(step >> 32)};
 }
 
+// One row of the proposal table, by value (kernel argument or prefetched registers) so that a step does not start with
+// a chain of dependent loads: schedule -> row -> node tables -> state.
+struct PropRow {
+    int kind, node, n1, n2, jac_root;
+    double p0, p1;
+};
+
+__device__ __forceinline__ PropRow mh_load_row(const MhDev& M, int p)
+{
+    return PropRow{M.kind[p], M.node[p], M.n1[p], M.n2[p], M.jac_root[p], M.p0[p], M.p1[p]};
+}
+
 // The STATE-INDEPENDENT random part of one step: what can be drawn knowing only the proposal row and its tuning
 // parameter.  Gamma-multiplier proposals: the multiplier u, ln (q(1/u) / q(u)) and ln u; truncated-normal proposals:
 // the uniform that goes through the quantile; every step: the acceptance uniform.  The whole-schedule kernel computes
@@ -151,14 +163,14 @@ __device__ __forceinline__ bool mh_is_gamma_kind(int kind)
            kind == MCD_PROP_SCALE_CONTRARILY;
 }
 
-__device__ inline StepDraws mh_step_draws(const MhDev& M, int p, double t, const Rng& g)
+__device__ inline StepDraws mh_step_draws(const PropRow& row, double t, const Rng& g)
 {
     StepDraws d{1.0, 0.0, 0.0, 0.5, 0.5};
     double ub;
-    const int kind = M.kind[p];
+    const int kind = row.kind;
     if (mh_is_gamma_kind(kind)) {
-        const double p0 = M.p0[p];
-        const double k = p0 / t, th = (kind == MCD_PROP_SCALE_CONTRARILY) ? M.p1[p] * t : t / p0;
+        const double p0 = row.p0;
+        const double k = p0 / t, th = (kind == MCD_PROP_SCALE_CONTRARILY) ? row.p1 * t : t / p0;
         d.u = gamma_sample(g, k, th);
         d.lnq = gamma_ratio(k, th, d.u);
         d.logu = log(d.u);
@@ -169,14 +181,14 @@ __device__ inline StepDraws mh_step_draws(const MhDev& M, int p, double t, const
     return d;
 }
 
-// Apply proposal row p with tuning parameter t to the state (sc, H, R) of one chain; all 64 lanes active.
+// Apply the proposal `row` with tuning parameter t to the state (sc, H, R) of one chain; all 64 lanes active.
 // Writes the proposed heights / rates to H1 / R1 (global memory or LDS), updates sc in place and returns
 // ln (q-ratio * Jacobian) without the root-branch factor (NaN = invalid proposal => reject).
-__device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double t, const StepDraws& dr, int lane, double (&sc)[5],
+__device__ __forceinline__ double mh_propose_wave(const MhDev& M, const PropRow& row, double t, const StepDraws& dr, int lane, double (&sc)[5],
                                                   const double* H, const double* R, double* H1, double* R1)
 {
-    const int n = M.n_nodes, kind = M.kind[p], v = M.node[p];
-    const double p0 = M.p0[p];
+    const int n = M.n_nodes, kind = row.kind, v = row.node;
+    const double p0 = row.p0;
     double lnq = 0.0, lnj = 0.0;
     // per-node transforms: H1[w] = (w in [hlo, hhi)) ? H[w] * hmul : H[w], with point overrides; R1[w] = R[w] * rmul + radd in [rlo, rhi)
     int hlo = 0, hhi = 0, hlo2 = 0, hhi2 = 0, rlo = 0, rhi = 0;
@@ -223,7 +235,7 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             hmul = xi;
             pt1 = v;
             pv1 = h1;
-            lnj = (double)(M.n1[p] - 1) * log(xi);
+            lnj = (double)(row.n1 - 1) * log(xi);
             break;
         }
         case MCD_PROP_PULLEY: {
@@ -241,7 +253,7 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             const double hL1 = hL - u, hR1 = hR + u, xiL = hL1 / hL, xiR = hR1 / hR;
             hlo = l + 1; hhi = l + M.size[l]; hmul = xiL; pt1 = l; pv1 = hL1;
             hlo2 = r + 1; hhi2 = r + M.size[r]; hmul2 = xiR; pt2 = r; pv2 = hR1;
-            lnj = (double)(M.n1[p] - 1) * log(xiL) + (double)(M.n2[p] - 1) * log(xiR);
+            lnj = (double)(row.n1 - 1) * log(xiL) + (double)(row.n2 - 1) * log(xiR);
             break;
         }
         case MCD_PROP_SCALE_BRANCH_RATE: {
@@ -255,7 +267,7 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             const double u = dr.u;
             rlo = v; rhi = v + M.size[v]; rmul = u;
             lnq = dr.lnq;
-            lnj = (double)(M.n1[p] - 2) * dr.logu;
+            lnj = (double)(row.n1 - 2) * dr.logu;
             break;
         }
         case MCD_PROP_SCALE_NORM_TREE: {
@@ -281,7 +293,7 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             lnq = dr.lnq;
             // reference: product of the diagonal of the Jacobian matrix, (u - u/n + 1/n)^n (Unconstrained.hs:321-326);
             // p1 = 1 selects the determinant u^(n-1) instead (the mean-preserving map has eigenvalues u (n-1 times) and 1)
-            lnj = (M.p1[p] == 1.0) ? (double)(nb - 1) * dr.logu : (double)nb * log(u - n1 * u + n1);
+            lnj = (row.p1 == 1.0) ? (double)(nb - 1) * dr.logu : (double)nb * log(u - n1 * u + n1);
             break;
         }
         case MCD_PROP_SCALE_VAR_TREE_AUTO: {
@@ -337,7 +349,7 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             rlo = v + 1; rhi = v + M.size[v]; rmul = xiR;
             rp3 = v;
             rm3 = xiStem;
-            lnj = (double)(M.n1[p] - M.n2[p]) * log(xiT) + log(xiStem);
+            lnj = (double)(row.n1 - row.n2) * log(xiT) + log(xiStem);
             break;
         }
         case MCD_PROP_SLIDE_ROOT_CONTRA: {   // Contrary.hs:191-223
@@ -356,7 +368,7 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             hlo = 1; hhi = n; hmul = u; h_divide = true;
             rp1 = l; rm1 = xil; rp2 = r; rm2 = xir;
             sc[2] = ht1;
-            lnj = (double)(-M.n1[p]) * log(u) + log(xil) + log(xir);
+            lnj = (double)(-row.n1) * log(u) + log(xil) + log(xir);
             break;
         }
         case MCD_PROP_SCALE_RATES_TREE_CONTRA: {   // Contrary.hs:420-446 on (timeBirthRate, rateMean, timeTree)
@@ -370,7 +382,7 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, int p, double 
             hlo = 1; hhi = n; hmul = xi;
             sc[0] = sc[0] / xi;
             sc[3] = sc[3] / xi;
-            lnj = (double)(M.n1[p] - 1 - 2) * log(xi);
+            lnj = (double)(row.n1 - 1 - 2) * log(xi);
             break;
         }
         case MCD_PROP_SLIDE_BRACE:

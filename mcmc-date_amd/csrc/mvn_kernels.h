@@ -108,8 +108,13 @@ hipError_t launch_hmc_kick(const HmcDev& D, double kick, int use_pos_grad, hipSt
 hipError_t launch_hmc_scatter(const HmcDev& D, hipStream_t st);               // state arrays <- D.q
 hipError_t launch_hmc_drift(const HmcDev& D, hipStream_t st);                 // q += eps Minv p, scattered into the state
 hipError_t launch_hmc_collect(const HmcDev& D, hipStream_t st);               // q, grad, value from the state and the gradient kernels
-// accept step idx_acc (< 0: none) and propose step idx_prop (< 0: none) with the ln prior of its proposed state
-hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, const int32_t* sched, int64_t idx_acc, int64_t idx_prop, uint64_t step_acc,
+// one row of the proposal table on the host (k_mh.hip turns it into a kernel argument)
+struct MhRow {
+    int kind, node, n1, n2, jac_root;
+    double p0, p1;
+};
+// accept the pending step of proposal p_acc (< 0: none) and propose proposal p_prop (< 0: none) with the ln prior of its proposed state
+hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& row_prop, uint64_t step_acc,
                           uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
 // whole schedule in one launch (k_mh_chain.hip); needs n_nodes <= 64 and mh_chain_lds_bytes(...) <= 64 KB
