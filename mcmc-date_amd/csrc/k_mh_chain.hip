@@ -9,9 +9,9 @@
 // lanes = nodes for the state and the prior, lanes = rows of the factor for the solve: z_j is broadcast with
 // v_readlane and column j of the factor is one conflict-free ds_read_b64 (address j * 64 + lane).
 //
-// The arithmetic is the one of the per-phase kernels (k_mh.hip, k_prior.hip, k_tree_logpdf.hip at R = 1): same
+// The arithmetic is the one of the two-launch path of larger trees (k_mh.hip with prior_device.hpp, k_tree_logpdf.hip at R = 1): same
 // proposal code, same prior code, the same fma order in the column sweep and the same reduction tree, so a chain
-// advanced by this kernel is bit-identical to the same chain advanced by one launch per phase
+// advanced by this kernel is bit-identical to the same chain advanced by that path
 // (tests/test_gpu_mh.py::test_chain_kernel_equals_per_phase_kernels).
 //
 // Reference: the loop this replaces is `mhg`'s iteration of `mcmc` [external] driven from app/Main.hs:460-479 with

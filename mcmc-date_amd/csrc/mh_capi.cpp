@@ -225,7 +225,7 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
         (rc = dev_alloc(m.get(), &D.age_sq, BN, true)))
         return rc;
     // trees of at most 64 nodes: the whole schedule runs in one launch with the factor staged in LDS (k_mh_chain.hip).
-    // MCD_MH_PER_PHASE=1 (diagnostic) keeps the one-launch-per-phase path that larger trees use.
+    // MCD_MH_PER_PHASE=1 (diagnostic) keeps the two-launches-per-step path that larger trees use.
     const char* per_phase = getenv("MCD_MH_PER_PHASE");
     const int nd = m->mvn->n;
     if (n <= 64 && !(per_phase && per_phase[0] == '1') && mcd::mh_chain_lds_bytes(nd, n_prop, 4) <= 64 * 1024) {

@@ -149,7 +149,7 @@ __device__ __forceinline__ PropRow mh_load_row(const MhDev& M, int p)
 // The STATE-INDEPENDENT random part of one step: what can be drawn knowing only the proposal row and its tuning
 // parameter.  Gamma-multiplier proposals: the multiplier u, ln (q(1/u) / q(u)) and ln u; truncated-normal proposals:
 // the uniform that goes through the quantile; every step: the acceptance uniform.  The whole-schedule kernel computes
-// these for 64 consecutive steps at once, one step per lane (k_mh_chain.hip); the per-phase kernel per step.
+// these for 64 consecutive steps at once, one step per lane (k_mh_chain.hip); k_mh_step per step.
 struct StepDraws {
     double u, lnq, logu;   // gamma kinds
     double U;              // truncated-normal kinds: first double of block 0
