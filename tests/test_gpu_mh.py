@@ -103,7 +103,7 @@ def test_lockstep_parity_other_clock_models(gpu, golden, model):
 
 
 def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
-    """Trees of at most 64 nodes run the whole schedule in one launch (k_mh_chain.hip); larger trees use one launch
+    """Trees of at most 64 nodes run the whole schedule in one launch (k_mh_chain.hip); larger trees use two
     launches per step (k_mh.hip + k_tree_logpdf.hip).  Same arithmetic in the same order: bit-identical chains."""
     fx = golden["25-leaves-bastien"]
     topo, ps, fused, _ = setup(fx, B=12, seed=5)
