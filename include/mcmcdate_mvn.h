@@ -243,6 +243,8 @@ typedef struct mcd_mh mcd_mh_t;
  * app/Definitions.hs:145-278), dim = PDimension (selects the optimal acceptance rate of the auto tuner), p0, p1.
  * All chains start with tuning parameter 1.  Random numbers are Philox4x32-10 keyed by `seed`, counter =
  * (draw, chain, step): results do not depend on batch size, launch geometry or GPU count.
+ * Unlike the likelihood and prior handles, a driver handle (mcd_mh_t, mcd_hmc_t) carries the chains' state: use it from
+ * one thread at a time; different handles may be driven concurrently from different threads.
  */
 int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
                   const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
