@@ -395,3 +395,37 @@ def test_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden):
     t0 = time.perf_counter()
     lf2.leapfrog(np.zeros((B, lf2.dim)), 1e-3, inv_mass_w, 200)
     print("leapfrog: %.1f us per step for %d chains" % (1e6 * (time.perf_counter() - t0) / 200, B))
+
+
+def test_hmc_handle_errors(gpu, golden):
+    """Structural faults of the leapfrog entry points come back as error codes with messages (never a crash)."""
+    import ctypes as C
+
+    fx = golden["06-leaves-constant-rate"]
+    topo = M.Topology(fx["parent"])
+    pf = M.PriorFunction(float(fx["prior_ht"]), "UncorrelatedGamma", [], [], [], topo)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    lf = M.Leapfrog(lik, pf, False, 3)
+    assert lf.dim == 2 + (topo.n_nodes - int(topo.leaves.sum()) - 1) + 2 + (topo.n_nodes - 1)      # no tH without calibrations
+    with pytest.raises(M.McdError, match="set_state"):
+        lf.position()
+    with pytest.raises(M.McdError, match="set_state"):
+        lf.leapfrog(np.zeros((3, lf.dim)), 0.01, 1.0, 1)
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    lf.set_state(M.StateBatch.from_states([x0] * 3))
+    q, v, g = lf.position()
+    assert np.all(np.isfinite(v)) and np.all(np.isfinite(g))            # birth = death = 1: the near-critical start has a gradient
+    with pytest.raises(M.McdError, match="positive"):
+        lf.leapfrog(np.zeros((3, lf.dim)), 0.01, np.zeros(lf.dim), 1)
+    with pytest.raises(ValueError):
+        lf.leapfrog(np.zeros((2, lf.dim)), 0.01, 1.0, 1)
+    # a step that leaves the support: NaN value, the caller rejects
+    p = np.zeros((3, lf.dim))
+    p[:, -1] = -1e6                                                       # drives the birth rate far below zero
+    lf.leapfrog(p, 1e-3, 1.0, 1)
+    _, v2, _ = lf.position()
+    assert not np.any(np.isfinite(v2))
+    other = M.Topology(np.array([-1, 0, 1, 1, 0], np.int32))
+    pf_other = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], other)
+    with pytest.raises(M.McdError):
+        M.Leapfrog(lik, pf_other, False, 3)
