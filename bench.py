@@ -270,7 +270,7 @@ def main():
         achieved = alg_b / per_launch_s / 1e9
         flops = algorithmic_flops_per_eval(n) * B / per_launch_s / 1e12
         out = {
-            "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec x chains) at N=256 nodes",
+            "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes",   # BASELINE.json:metric, verbatim
             "value": evals / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
