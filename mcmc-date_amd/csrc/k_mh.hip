@@ -37,7 +37,7 @@ namespace mcd {
 //            of the absolute node ages tH * h_v when the step closes an iteration (`accumulate_now`)
 //   propose: writes sc1, H1, R1, lnqj (ln q-ratio * Jacobian without the root-branch factor), post1[0] = ln prior
 __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc, int jac_root_acc, int p_prop, PropRow row_prop,
-                                                 uint64_t step_acc, uint64_t seed, int accumulate_now,
+                                                 int draw_slot, uint64_t step_acc, uint64_t seed, int accumulate_now,
                                                  double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
 {
     extern __shared__ double sh[];
@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
                 if (lane == i) mine = sc[i];
             M.sc[lane * B + b] = mine;
         }
-        if (lane < 3) M.post[lane * B + b] = M.post1[lane * B + b];
+        if (lane < 3) {
+            M.post[lane * B + b] = M.post1[lane * B + b];
+            M.pcomp[b * 3 + lane] = M.pcomp1[b * 3 + lane];
+        }
     }
     if (accumulate_now) {
         for (int w = lane; w < n; w += 64) {
@@ -104,10 +107,33 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
     if (p_prop < 0) return;
     __builtin_amdgcn_wave_barrier();
     const double t = M.tune[b * M.n_prop + p_prop];
-    const StepDraws dr = mh_step_draws(row_prop, t, mh_rng(seed, M.chain0 + b, step_acc + 1));
+    // the state-independent draws of this step were computed by k_mh_draws, one thread per (step, chain)
+    const double* dw = M.draws + ((size_t)draw_slot * B + b) * 5;
+    const StepDraws dr{dw[0], dw[1], dw[2], dw[3], dw[4]};
+    (void)seed;
+    double sc0[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sc0[i] = sc[i];
     const double lnqj = mh_propose_wave(M, row_prop, t, dr, lane, sc, Hc, Rc, Hs, Rs);
     __builtin_amdgcn_wave_barrier();
-    const double lp1 = prior_eval_wave(P, lane, sc[0], sc[1], sc[2], sc[3], sc[4], Hs, Rs, nullptr);
+    // re-evaluate only the blocks of the ln prior whose inputs the proposal moved (as k_mh_chain.hip does)
+    bool dH = false, dR = false;
+    for (int w0 = 0; w0 < n; w0 += 64) {
+        const int w = w0 + lane;
+        const bool in = w < n;
+        dH = dH || (__builtin_amdgcn_ballot_w64(in && Hs[in ? w : 0] != Hc[in ? w : 0]) != 0);
+        dR = dR || (__builtin_amdgcn_ballot_w64(in && Rs[in ? w : 0] != Rc[in ? w : 0]) != 0);
+    }
+    const double c0p = (dH || sc[2] != sc0[2]) ? prior_nodes_wave(P, lane, sc[2], Hs) : M.pcomp[b * 3 + 0];
+    const double c1p = (dH || sc[0] != sc0[0] || sc[1] != sc0[1]) ? prior_bd_wave(P, lane, sc[0], sc[1], Hs) : M.pcomp[b * 3 + 1];
+    const double c2p = (dR || sc[3] != sc0[3] || sc[4] != sc0[4] || (dH && P.clock_model >= 2)) ? prior_clock_wave(P, lane, sc[3], sc[4], Hs, Rs)
+                                                                                             : M.pcomp[b * 3 + 2];
+    const double lp1 = c0p + c1p + c2p;
+    if (lane == 0) {
+        M.pcomp1[b * 3 + 0] = c0p;
+        M.pcomp1[b * 3 + 1] = c1p;
+        M.pcomp1[b * 3 + 2] = c2p;
+    }
     for (int w = lane; w < n; w += 64) {
         M.H1[b * M.ld + w] = Hs[w];
         M.R1[b * M.ld + w] = Rs[w];
@@ -123,6 +149,25 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
         M.lnqj[b] = lnqj;
         M.post1[b] = lp1;
     }
+}
+
+// The state-independent draws (gamma multipliers with ratio and logarithm, the uniforms) of up to 64 consecutive steps: one
+// THREAD per (step, chain) instead of one wave per chain, so the transcendental work is not repeated on 64 lanes.
+__global__ __launch_bounds__(256) void k_mh_draws(MhDev M, const int32_t* __restrict__ sched, int64_t idx0, int count, uint64_t step0,
+                                                  uint64_t seed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)count * M.batch) return;
+    const int j = (int)(i / M.batch);
+    const int64_t b = i - (int64_t)j * M.batch;
+    const int p = sched[idx0 + j];
+    const StepDraws d = mh_step_draws(mh_load_row(M, p), M.tune[b * M.n_prop + p], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)j));
+    double* o = M.draws + ((size_t)j * M.batch + b) * 5;
+    o[0] = d.u;
+    o[1] = d.lnq;
+    o[2] = d.logu;
+    o[3] = d.U;
+    o[4] = d.Uacc;
 }
 
 // mcmc's auto tuning [external]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3); counters reset.
@@ -143,8 +188,14 @@ __global__ __launch_bounds__(256) void k_mh_tune(MhDev M)
     M.tried[i] = 0;
 }
 
-hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, uint64_t step_acc,
-                          uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
+hipError_t launch_mh_draws(const MhDev& M, const int32_t* sched, int64_t idx0, int count, uint64_t step0, uint64_t seed, hipStream_t st)
+{
+    const int64_t n = (int64_t)count * M.batch;
+    hipLaunchKernelGGL(k_mh_draws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, sched, idx0, count, step0, seed);
+    return hipGetLastError();
+}
+hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, int draw_slot,
+                          uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
 {
     const size_t per_wave = sizeof(double) * 4 * (size_t)M.n_nodes;
     int wpb = 4;
@@ -152,7 +203,7 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
     if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
     const PropRow row{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
     hipLaunchKernelGGL(k_mh_step, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, p_acc, jac_root_acc, p_prop,
-                       row, step_acc, seed, accumulate_now, trace_alpha, trace_accept);
+                       row, draw_slot, step_acc, seed, accumulate_now, trace_alpha, trace_accept);
     return hipGetLastError();
 }
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st)

@@ -94,7 +94,7 @@ int eval_posterior(mcd_mh* m, const double* sc, const double* H, const double* R
 {
     const mcd::MhDev& D = m->dev;
     const int64_t B = D.batch;
-    MHIP_TRY(mcd::launch_prior(*m->prior, sc + 0 * B, sc + 1 * B, sc + 2 * B, H, sc + 3 * B, sc + 4 * B, R, D.ld, B, post, nullptr,
+    MHIP_TRY(mcd::launch_prior(*m->prior, sc + 0 * B, sc + 1 * B, sc + 2 * B, H, sc + 3 * B, sc + 4 * B, R, D.ld, B, post, D.pcomp,
                                m->stream));
     MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, H, R, D.ld, sc + 2 * B, sc + 3 * B, B, post + B, post + 2 * B, m->stream));
     return MCD_OK;
@@ -222,7 +222,8 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
         (rc = dev_alloc(m.get(), &D.post1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.lnqj, B, true)) || (rc = dev_alloc(m.get(), &D.beta, B, false)) ||
         (rc = dev_alloc(m.get(), &D.tune, BP, false)) || (rc = dev_alloc(m.get(), &D.acc, BP, true)) ||
         (rc = dev_alloc(m.get(), &D.tried, BP, true)) || (rc = dev_alloc(m.get(), &D.age_sum, BN, true)) ||
-        (rc = dev_alloc(m.get(), &D.age_sq, BN, true)))
+        (rc = dev_alloc(m.get(), &D.age_sq, BN, true)) || (rc = dev_alloc(m.get(), &D.pcomp, 3 * B, true)) ||
+        (rc = dev_alloc(m.get(), &D.pcomp1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.draws, 64 * 5 * B, true)))
         return rc;
     // trees of at most 64 nodes: the whole schedule runs in one launch with the factor staged in LDS (k_mh_chain.hip).
     // MCD_MH_PER_PHASE=1 (diagnostic) keeps the two-launches-per-step path that larger trees use.
@@ -347,14 +348,27 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         const int64_t total = (int64_t)steps;
         if ((size_t)D.n_nodes * 32 > 64 * 1024) return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_run: more than 2048 nodes");
         const mcd::MhRow none{0, 0, 0, 0, 0, 1.0, 0.0};
-        MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], m->step - 1, m->seed, 0, nullptr, nullptr, m->stream));
+        // the draws of schedule positions [64 k, 64 k + 64) are computed when position 64 k is about to be proposed
+        const uint64_t step_base = m->step;                      // the step number of schedule position 0
+        auto draws_for = [&](int64_t idx) -> int {
+            if ((idx & 63) == 0) {
+                const int count = (int)((total - idx < 64) ? total - idx : 64);
+                const hipError_t e = mcd::launch_mh_draws(D, m->d_sched, idx, count, step_base + (uint64_t)idx, m->seed, m->stream);
+                if (e != hipSuccess) return mfail(MCD_ERR_HIP, "launch_mh_draws: %s", hipGetErrorString(e));
+            }
+            return MCD_OK;
+        };
+        if (int rc = draws_for(0)) return rc;
+        MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr, m->stream));
         for (int64_t gs = 0; gs < total; ++gs) {
             MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
                                              D.post1 + D.batch, D.post1 + 2 * D.batch, m->stream));
             const bool closes = ((gs + 1) % S) == 0;
             const int pa = schedule[gs], pn = (gs + 1 < total) ? schedule[gs + 1] : -1;
-            MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, m->step, m->seed,
-                                         (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
+            if (pn >= 0)
+                if (int rc = draws_for(gs + 1)) return rc;
+            MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, (int)((gs + 1) & 63), m->step,
+                                         m->seed, (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
                                          trace ? m->d_trace_accept + gs * B : nullptr, m->stream));
             m->step += 1;
             if (accumulate && closes) m->n_samples += 1;

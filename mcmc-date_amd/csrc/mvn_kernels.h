@@ -69,6 +69,10 @@ struct MhDev {
     double* tune;              // [batch][n_prop]
     int32_t *acc, *tried;      // [batch][n_prop]
     double *age_sum, *age_sq;  // [batch][n_nodes]
+    // two-launch path (trees with more than 64 nodes): the three blocks of the ln prior of the current / proposed state,
+    // [batch][3], and the state-independent draws of a block of 64 steps, [64][batch][5] (k_mh_draws)
+    double *pcomp, *pcomp1;
+    double* draws;
 };
 
 // Workspace of the device leapfrog (k_hmc.hip); all pointers are device memory.
@@ -114,9 +118,11 @@ struct MhRow {
     double p0, p1;
 };
 // accept the pending step of proposal p_acc (< 0: none) and propose proposal p_prop (< 0: none) with the ln prior of its proposed state
-hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& row_prop, uint64_t step_acc,
-                          uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st);
+hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& row_prop, int draw_slot,
+                          uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
+// state-independent draws of the steps [idx0, idx0 + count) of the schedule (count <= 64), one thread per (step, chain)
+hipError_t launch_mh_draws(const MhDev& M, const int32_t* sched, int64_t idx0, int count, uint64_t step0, uint64_t seed, hipStream_t st);
 // whole schedule in one launch (k_mh_chain.hip); needs n_nodes <= 64 and mh_chain_lds_bytes(...) <= 64 KB
 size_t mh_chain_lds_bytes(int n, int n_prop, int wpb);
 hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const double* Fp,
