@@ -44,6 +44,11 @@ struct Workspace {
     hipStream_t stream = nullptr;
     double* dbuf = nullptr;
     size_t cap = 0;  // doubles
+    // small calls (the reference's one-state-per-call pattern): a pinned, device-mapped host buffer the kernel reads and
+    // writes directly -- no staging copies, one launch + one synchronisation per call
+    double* hbuf = nullptr;      // host address
+    double* hbuf_dev = nullptr;  // the same memory as the device sees it
+    size_t hcap = 0;             // doubles
 };
 
 struct WorkspacePool {
@@ -77,6 +82,7 @@ struct WorkspacePool {
         std::lock_guard<std::mutex> g(mu);
         for (Workspace* w : idle) {
             if (w->dbuf) (void)hipFree(w->dbuf);
+            if (w->hbuf) (void)hipHostFree(w->hbuf);
             if (w->stream) (void)hipStreamDestroy(w->stream);
             delete w;
         }
@@ -94,6 +100,21 @@ int ensure(Workspace* w, size_t doubles)
     HIP_TRY(hipMalloc((void**)&w->dbuf, want * sizeof(double)));
     w->cap = want;
     return MCD_OK;
+}
+
+constexpr size_t kZeroCopyDoubles = 8192;   // calls moving at most 64 KiB use the mapped host buffer
+
+int ensure_mapped(Workspace* w, size_t doubles)
+{
+    if (w->hcap >= doubles) return MCD_OK;
+    if (w->hbuf) HIP_TRY(hipHostFree(w->hbuf));
+    w->hbuf = nullptr;
+    w->hbuf_dev = nullptr;
+    w->hcap = 0;
+    HIP_TRY(hipHostMalloc((void**)&w->hbuf, kZeroCopyDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostGetDevicePointer((void**)&w->hbuf_dev, w->hbuf, 0));
+    w->hcap = kZeroCopyDoubles;
+    return doubles <= w->hcap ? MCD_OK : MCD_ERR_INVALID_ARG;
 }
 
 struct WsGuard {
@@ -278,6 +299,15 @@ int mcd_mvn_logpdf_batch(const mcd_mvn_t* h, const double* X, int64_t ld, int64_
     WsGuard g{&h->pool, h->pool.acquire()};
     if (!g.w) return fail(MCD_ERR_HIP, "mcd_mvn_logpdf_batch: cannot create a HIP stream");
     const size_t nx = (size_t)batch * (size_t)h->n;
+    if (nx + (size_t)batch <= kZeroCopyDoubles) {
+        if (int rc = ensure_mapped(g.w, nx + (size_t)batch)) return rc;
+        double* hX = g.w->hbuf;
+        for (int64_t b = 0; b < batch; ++b) memcpy(hX + (size_t)b * h->n, X + (size_t)b * ld, sizeof(double) * (size_t)h->n);
+        HIP_TRY(mcd::launch_logpdf(h->dev, g.w->hbuf_dev, h->n, batch, g.w->hbuf_dev + nx, g.w->stream));
+        HIP_TRY(hipStreamSynchronize(g.w->stream));
+        memcpy(ll, hX + nx, sizeof(double) * (size_t)batch);
+        return MCD_OK;
+    }
     if (int rc = ensure(g.w, nx + (size_t)batch)) return rc;
     double* dX = g.w->dbuf;
     double* dll = dX + nx;
@@ -415,6 +445,25 @@ int mcd_tree_loglik_batch(const mcd_tree_t* t, const double* heights, const doub
     WsGuard g{&h->pool, h->pool.acquire()};
     if (!g.w) return fail(MCD_ERR_HIP, "mcd_tree_loglik_batch: cannot create a HIP stream");
     const size_t nn = (size_t)t->n_nodes, B = (size_t)batch;
+    if (2 * B * nn + 4 * B <= kZeroCopyDoubles) {
+        if (int rc = ensure_mapped(g.w, 2 * B * nn + 4 * B)) return rc;
+        double* hH = g.w->hbuf;
+        double* hR = hH + B * nn;
+        double* hS = hR + B * nn;            // tH | rMu | ll | log_jac
+        for (size_t b = 0; b < B; ++b) {
+            memcpy(hH + b * nn, heights + b * (size_t)ld_state, sizeof(double) * nn);
+            memcpy(hR + b * nn, rates + b * (size_t)ld_state, sizeof(double) * nn);
+        }
+        memcpy(hS, tH, sizeof(double) * B);
+        memcpy(hS + B, rMu, sizeof(double) * B);
+        double* d0 = g.w->hbuf_dev;
+        HIP_TRY(mcd::launch_tree_logpdf(h->dev, t->dev, d0, d0 + B * nn, (int64_t)nn, d0 + 2 * B * nn, d0 + 2 * B * nn + B, batch,
+                                        d0 + 2 * B * nn + 2 * B, log_jac ? d0 + 2 * B * nn + 3 * B : nullptr, g.w->stream));
+        HIP_TRY(hipStreamSynchronize(g.w->stream));
+        memcpy(ll, hS + 2 * B, sizeof(double) * B);
+        if (log_jac) memcpy(log_jac, hS + 3 * B, sizeof(double) * B);
+        return MCD_OK;
+    }
     if (int rc = ensure(g.w, 2 * B * nn + 4 * B)) return rc;
     double* dH = g.w->dbuf;
     double* dR = dH + B * nn;
