@@ -59,6 +59,19 @@ const char* mcd_version(void);
 const char* mcd_last_error(void);
 
 /*
+ * Which of the two forms of the log-density kernels a launch uses (process wide; results agree to rounding):
+ *   MCD_FORM_AUTO     (default) by dimension and batch size;
+ *   MCD_FORM_SWEEP    always the column sweep (one chain per wave -- the latency form);
+ *   MCD_FORM_MULTIPLY always the multiply form z = L^-1 (x - mu) on the fp64 matrix cores (the throughput form).
+ * The environment variable MCD_WIDE=0|1 sets the initial value to SWEEP | MULTIPLY.  Returns the previous value.
+ * The gradient entry points always use the column sweeps.
+ */
+#define MCD_FORM_AUTO 0
+#define MCD_FORM_SWEEP 1
+#define MCD_FORM_MULTIPLY 2
+int mcd_set_logpdf_form(int form);
+
+/*
  * Build the immutable likelihood operands on GPU `device_id`.
  * Replaces: getLikelihoodFunction / getData (app/Main.hs:333-347, 85-99) + the closure creation
  * likelihoodFunction (Full mu sigmaInv logDetSigma) (app/Probability.hs:277-278, 247-248).

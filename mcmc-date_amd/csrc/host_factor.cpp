@@ -97,4 +97,33 @@ void pack_factors(int n, int R, const std::vector<double>& L, std::vector<double
     }
 }
 
+void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt)
+{
+    // rows of W one after the other: W_i: = (e_i - sum_{k<i} L_ik W_k:) / L_ii, long double accumulation
+    std::vector<double> W((size_t)n * n, 0.0);
+    std::vector<long double> acc(n);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < i; ++j) acc[j] = 0.0L;
+        const double* Li = &L[(size_t)i * n];
+        for (int k = 0; k < i; ++k) {
+            const long double lik = Li[k];
+            const double* Wk = &W[(size_t)k * n];
+            for (int j = 0; j <= k; ++j) acc[j] -= lik * (long double)Wk[j];
+        }
+        const long double d = Li[i];
+        for (int j = 0; j < i; ++j) W[(size_t)i * n + j] = (double)(acc[j] / d);
+        W[(size_t)i * n + i] = (double)(1.0L / d);
+    }
+    const int NB = (n + 15) / 16;
+    Wt.assign((size_t)2 * NB * (NB + 1) * 64, 0.0);
+    for (int ib = 0; ib < NB; ++ib)
+        for (int kt = 0; kt < 4 * (ib + 1); ++kt) {
+            double* t = &Wt[((size_t)2 * ib * (ib + 1) + kt) * 64];
+            for (int l = 0; l < 64; ++l) {
+                const int row = 16 * ib + (l & 15), colk = 4 * kt + (l >> 4);
+                if (row < n && colk <= row) t[l] = W[(size_t)row * n + colk];
+            }
+        }
+}
+
 }  // namespace mcd

@@ -16,4 +16,10 @@ size_t packed_index(int R, int row, int col);
 void pack_factors(int n, int R, const std::vector<double>& L, std::vector<double>& mu_pad, const double* mu,
                   std::vector<double>& invdiag, std::vector<double>& Ft, std::vector<double>& Ut);
 
+// W = L^-1 (row-major lower triangular) as the operand tiles k_wide.hip streams: row block ib (16 rows) holds the
+// k tiles kt = 0 .. 4 (ib + 1) - 1 (4 columns each) at tile index 2 ib (ib + 1) + kt; a tile is 64 doubles in lane
+// order, lane l = W[16 ib + (l & 15)][4 kt + (l >> 4)] (the A operand of v_mfma_f64_16x16x4_f64); zeros above the
+// diagonal and beyond n.
+void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt);
+
 }  // namespace mcd

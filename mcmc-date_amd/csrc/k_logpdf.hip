@@ -1,6 +1,8 @@
 // k_logpdf.hip -- batched log-density, raw x (gfx950).  Device code: mvn_device.hpp.
 #include "mvn_device.hpp"
 #include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
 
 namespace mcd {
 
@@ -86,6 +88,27 @@ int sweep_chunk_columns(int R)
     return 2 * ((R == 1) ? 32 : (R == 2) ? 16 : (R <= 4) ? 8 : 4);
 }
 
+int wide_chain_tiles(int64_t batch)
+{
+    static const int force = getenv("MCD_WIDE_CT") ? atoi(getenv("MCD_WIDE_CT")) : 0;
+    if (force == 1 || force == 2 || force == 4) return force;
+    if (batch <= 256 * 16) return 1;
+    if (batch <= 256 * 64) return 2;
+    return 4;
+}
+
+static std::atomic<int> g_form{getenv("MCD_WIDE") ? (atoi(getenv("MCD_WIDE")) ? 2 : 1) : 0};   // MCD_FORM_*
+
+int set_logpdf_form(int form) { return g_form.exchange(form); }
+
+bool use_wide(const MvnDev& M, int64_t batch)
+{
+    const int form = g_form.load(std::memory_order_relaxed);
+    if (M.Wt == nullptr || form == 1) return false;
+    if (form == 2) return true;
+    return M.n >= 128 && batch >= 1024;
+}
+
 int padded_blocks(int n)
 {
     const int r = (n + 63) / 64;
@@ -103,6 +126,7 @@ hipError_t launch_logpdf_g3(const MvnDev& M, const double* X, int64_t ldx, int64
 hipError_t launch_logpdf(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (use_wide(M, batch)) return launch_logpdf_wide(M, X, ldx, batch, ll, st);
     if (M.R == 6 || M.R == 8) return launch_logpdf_g1(M, X, ldx, batch, ll, st);
     if (M.R == 12) return launch_logpdf_g2(M, X, ldx, batch, ll, st);
     if (M.R == 16) return launch_logpdf_g3(M, X, ldx, batch, ll, st);

@@ -1,0 +1,282 @@
+// k_wide.hip -- log-density of many chains at once, multiply form on the fp64 matrix cores (gfx950).
+//
+// The column sweep of mvn_device.hpp (one chain per wave, the factor broadcast lane by lane) is the latency form: it
+// wins while every chain can have a SIMD to itself.  With thousands of chains the same quantity
+//     ll = c - 1/2 (logdet Sigma + |W (x - mu)|^2),  W = L^-1          (app/Probability.hs:166-173, Sigma^-1 = W^T W)
+// is a triangular matrix-matrix product Z = W R with one column of R per chain, and only the column sums of Z^2 are
+// wanted.  Here a workgroup owns CT tiles of 16 chains; its 8 waves own row blocks of 16 rows of W and accumulate
+// Z tiles with v_mfma_f64_16x16x4_f64:
+//   * W is streamed from global memory as 16 x 4 tiles stored in lane order (host_factor.cpp: pack_w_tiles), each tile
+//     one coalesced 512-byte load, prefetched WD_P tiles ahead, used for CT MFMAs;
+//   * R = x - mu (or the tree distances of the state minus mu) is staged once per 256-column chunk in LDS, chain-major
+//     with a row stride of 258 doubles so that the 4 x 16 B-operand read is bank-conflict free;
+//   * rows are taken in super blocks of 256 (16 row blocks, two per wave: slots w and 15 - w, equal work on the
+//     diagonal chunk); a super block walks the chunks 0 .. s, so the accumulators never outgrow 2 CT tiles per wave and
+//     N is not bounded by the register file;
+//   * the result layout of the f64 MFMA keeps a chain on lane & 15 in all four result registers, so the column sums of
+//     squares need no transposition: registers, two lane exchanges, then the 8 waves in a fixed order through LDS.
+#include "mvn_kernels.h"
+#include <type_traits>
+
+namespace mcd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int WD_WAVES = 8;
+constexpr int WD_SB = 256;          // rows per super block = columns per staged chunk
+constexpr int WD_LD = WD_SB + 2;    // LDS row stride in doubles: 516 dwords = 4 (mod 64 banks)
+constexpr int WD_P = 8;             // W tiles in flight per row block
+
+struct WideSrc {
+    const double* X;                // raw x: [batch][ldx]                                       (TREE = false)
+    int64_t ldx;
+    TreeDev T;                      // tree state: heights / rates [batch][lds], tH, rMu [batch]   (TREE = true)
+    const double *H, *Rt;
+    int64_t lds;
+    const double *tH, *rMu;
+    double* logjac;
+};
+
+// One 256-column chunk of R into LDS.  512 threads = two chain rows per pass, so a thread keeps its column: the
+// per-column operands (mu, the slot's node and its parent) are read once, and the CT * 8 passes over the chains are
+// unrolled so that all their loads are in flight together.
+template <int CT, bool TREE>
+__device__ __forceinline__ void wide_stage(double* rs, const double* scs, const MvnDev& M, const WideSrc& A, int64_t b0, int64_t batch,
+                                           int kc0, int tid)
+{
+    const int j = tid & (WD_SB - 1), k = kc0 + j, ch0 = tid >> 8;
+    const bool live = k < M.n;
+    const double m = live ? M.mu[k] : 0.0;
+    if constexpr (!TREE) {
+        constexpr int G = 8;                                   // chain rows in flight per thread
+#pragma unroll 1
+        for (int g = 0; g < CT * 8; g += G) {
+            double v[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int64_t b = b0 + ch0 + 2 * (g + i);
+                v[i] = (live && b < batch) ? A.X[b * A.ldx + k] : m;        // padded columns and chains: exact zeros
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) rs[(ch0 + 2 * (g + i)) * WD_LD + j] = v[i] - m;   // dxs = xs - mu  (app/Probability.hs:171)
+        }
+    } else {
+        // distances from the tree state -- app/Probability.hs:201-207 (as load_tree in mvn_device.hpp); scs[] holds
+        // tH * rMu of the workgroup's chains.  Slot 0 (the two root branches, sumFirstTwo) is left to wide_stage_root.
+        constexpr int G = 8;
+        const int a = live ? A.T.slot_node[k] : 0;
+        const int pa = live ? A.T.parent[a] : 0;             // (the root's parent entry is -1: never index with it)
+#pragma unroll 1
+        for (int g = 0; g < CT * 8; g += G) {
+            double hp[G], ha[G], ra[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int64_t b = (b0 + ch0 + 2 * (g + i) < batch) ? b0 + ch0 + 2 * (g + i) : batch - 1;
+                const double* h = A.H + b * A.lds;
+                hp[i] = h[pa];
+                ha[i] = h[a];
+                ra[i] = A.Rt[b * A.lds + a];
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int ch = ch0 + 2 * (g + i);
+                const double d = ((hp[i] - ha[i]) * ra[i]) * scs[ch];
+                if (k != 0) rs[ch * WD_LD + j] = (live && b0 + ch < batch) ? d - m : 0.0;
+            }
+        }
+    }
+}
+
+// slot 0 of the distances: the branches of the two children of the root added up (app/Tools.hs:36-48), one chain per
+// thread; also the root-branch Jacobian.
+template <int CT>
+__device__ __forceinline__ void wide_stage_root(double* rs, const double* scs, const MvnDev& M, const WideSrc& A, int64_t b0,
+                                                int64_t batch, bool first, int tid)
+{
+    if (tid >= CT * 16) return;
+    const int64_t b = (b0 + tid < batch) ? b0 + tid : batch - 1;
+    const double* h = A.H + b * A.lds;
+    const double* r = A.Rt + b * A.lds;
+    const int a = A.T.slot_node[0], pa = A.T.parent[a], rr = A.T.root_right;
+    double d = (h[pa] - h[a]) * r[a];
+    d = d + (h[0] - h[rr]) * r[rr];
+    d = d * scs[tid];
+    const bool in = b0 + tid < batch;
+    if (first && in && A.logjac != nullptr) A.logjac[b] = log(1.0 / d);      // app/Probability.hs:394, 409
+    rs[tid * WD_LD] = in ? d - M.mu[0] : 0.0;
+}
+
+template <int CT, bool TREE>
+__global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int64_t batch, double* __restrict__ ll)
+{
+    extern __shared__ double smem[];
+    double* rs = smem;                                   // [CT * 16][WD_LD]
+    double* part = smem + CT * 16 * WD_LD;               // [WD_WAVES][CT * 16]
+    double* scs = part + WD_WAVES * CT * 16;             // [CT * 16] tH * rMu per chain (tree state)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b0 = (int64_t)blockIdx.x * (CT * 16);
+    const int NB = (M.n + 15) >> 4, NS = (NB + 15) >> 4;
+    const int col = lane & 15, kq = lane >> 4;
+    const double* __restrict__ Wt = M.Wt;
+
+    double ssq[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) ssq[ct] = 0.0;
+    if constexpr (TREE) {
+        if (tid < CT * 16) {
+            const int64_t b = (b0 + tid < batch) ? b0 + tid : batch - 1;
+            scs[tid] = A.tH[b] * A.rMu[b];               // :205-207  (tH * rMu)
+        }
+    }
+
+    for (int s = 0; s < NS; ++s) {
+        const int nb = (NB - 16 * s < 16) ? NB - 16 * s : 16;
+        const int shift = 16 - nb;                        // a partial super block fills the upper slots
+        const int bA = wave - shift, bB = 15 - wave - shift;
+        const int64_t ibA = 16 * s + bA, ibB = 16 * s + bB;
+        d4 accA[CT], accB[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) accA[ct] = accB[ct] = d4{0.0, 0.0, 0.0, 0.0};
+
+        for (int c = 0; c <= s; ++c) {
+            const int ntA = bA >= 0 ? (c < s ? WD_SB / 4 : 4 * (bA + 1)) : 0;
+            const int ntB = bB >= 0 ? (c < s ? WD_SB / 4 : 4 * (bB + 1)) : 0;      // ntB >= ntA, both multiples of 4
+            const double* wA = Wt + ((bA >= 0 ? 2 * ibA * (ibA + 1) : 0) + (WD_SB / 4) * c) * 64 + lane;
+            const double* wB = Wt + ((bB >= 0 ? 2 * ibB * (ibB + 1) : 0) + (WD_SB / 4) * c) * 64 + lane;
+            // The ring slots are always refilled (index clamped to the last tile of the block, a valid address even for
+            // a wave without a block), so the loads carry no branch and the wait counts stay exact.  The first WD_P
+            // tiles are requested before the chunk is staged: their latency overlaps the staging loads.
+            const int lastA = ntA > 0 ? ntA - 1 : 0, lastB = ntB > 0 ? ntB - 1 : 0;
+            double ra[WD_P], rb[WD_P];
+#pragma unroll
+            for (int p = 0; p < WD_P; ++p) {
+                ra[p] = wA[(p < lastA ? p : lastA) * 64];
+                rb[p] = wB[(p < lastB ? p : lastB) * 64];
+            }
+            __syncthreads();
+            wide_stage<CT, TREE>(rs, scs, M, A, b0, batch, c * WD_SB, tid);
+            if constexpr (TREE) {
+                if (c == 0) wide_stage_root<CT>(rs, scs, M, A, b0, batch, s == 0, tid);
+            }
+            __syncthreads();
+            // four k tiles (slots h .. h + 3 of the ring) against both row blocks or the longer one only -- no branch
+            // inside, so the LDS reads of later tiles are scheduled under the MFMAs of earlier ones
+            auto quad = [&](int kt0, auto hsel, auto both, bool refill) {
+                constexpr int h = decltype(hsel)::value;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int kt = kt0 + p, nx = kt + WD_P;
+                    const double a = ra[h + p], b = rb[h + p];
+                    if (refill) {
+                        ra[h + p] = wA[(nx < lastA ? nx : lastA) * 64];
+                        rb[h + p] = wB[(nx < lastB ? nx : lastB) * 64];
+                    }
+                    double r[CT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) r[ct] = rs[(ct * 16 + col) * WD_LD + kt * 4 + kq];
+                    if constexpr (decltype(both)::value) {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, r[ct], accA[ct], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) accB[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, r[ct], accB[ct], 0, 0, 0);
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I4 = std::integral_constant<int, 4>;
+            int kt0 = 0;
+            for (; kt0 + WD_P <= ntB; kt0 += WD_P) {
+                if (kt0 + 8 <= ntA) {
+                    quad(kt0, I0{}, std::true_type{}, true);
+                    quad(kt0 + 4, I4{}, std::true_type{}, true);
+                } else if (kt0 >= ntA) {
+                    quad(kt0, I0{}, std::false_type{}, true);
+                    quad(kt0 + 4, I4{}, std::false_type{}, true);
+                } else {
+                    quad(kt0, I0{}, std::true_type{}, true);
+                    quad(kt0 + 4, I4{}, std::false_type{}, true);
+                }
+            }
+            if (kt0 < ntB) {                              // a half group is left; nothing more to request
+                if (kt0 < ntA)
+                    quad(kt0, I0{}, std::true_type{}, false);
+                else
+                    quad(kt0, I0{}, std::false_type{}, false);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ssq[ct] = fma(accA[ct][q], accA[ct][q], ssq[ct]);
+                ssq[ct] = fma(accB[ct][q], accB[ct][q], ssq[ct]);
+            }
+        }
+    }
+
+    // column sums: the four lane groups of a wave, then the waves in a fixed order
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        double v = ssq[ct];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) part[wave * (CT * 16) + ct * 16 + lane] = v;
+    }
+    __syncthreads();
+    if (tid < CT * 16 && b0 + tid < batch) {
+        double q = 0.0;
+#pragma unroll
+        for (int w = 0; w < WD_WAVES; ++w) q += part[w * (CT * 16) + tid];
+        ll[b0 + tid] = M.c + (-0.5) * (M.logdet + q);      // app/Probability.hs:169
+    }
+}
+
+template <int CT, bool TREE>
+static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, hipStream_t st)
+{
+    constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16) * sizeof(double);
+    static hipError_t attr = hipFuncSetAttribute((const void*)k_wide<CT, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (attr != hipSuccess) return attr;
+    const unsigned grid = (unsigned)((batch + CT * 16 - 1) / (CT * 16));
+    hipLaunchKernelGGL((k_wide<CT, TREE>), dim3(grid), dim3(64 * WD_WAVES), bytes, st, M, A, batch, ll);
+    return hipGetLastError();
+}
+
+template <bool TREE>
+static hipError_t launch_wide(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, hipStream_t st)
+{
+    // chains per workgroup: as few as keep >= 256 workgroups in flight, so that all CUs take part
+    const int ct = wide_chain_tiles(batch);
+    if (ct == 1) return launch_ct<1, TREE>(M, A, batch, ll, st);
+    if (ct == 2) return launch_ct<2, TREE>(M, A, batch, ll, st);
+    return launch_ct<4, TREE>(M, A, batch, ll, st);
+}
+
+hipError_t launch_logpdf_wide(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    if (M.Wt == nullptr) return hipErrorInvalidValue;
+    WideSrc A{};
+    A.X = X;
+    A.ldx = ldx;
+    return launch_wide<false>(M, A, batch, ll, st);
+}
+
+hipError_t launch_tree_logpdf_wide(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                   const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    if (M.Wt == nullptr) return hipErrorInvalidValue;
+    WideSrc A{};
+    A.T = T;
+    A.H = H;
+    A.Rt = Rt;
+    A.lds = lds;
+    A.tH = tH;
+    A.rMu = rMu;
+    A.logjac = logjac;
+    return launch_wide<true>(M, A, batch, ll, st);
+}
+
+}  // namespace mcd

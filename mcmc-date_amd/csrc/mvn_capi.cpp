@@ -132,7 +132,7 @@ struct mcd_mvn {
     int n = 0, R = 0, device = 0;
     double logdet = 0.0;
     mcd::MvnDev dev{};
-    double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr;
+    double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr, *d_Wt = nullptr;
     std::vector<double> L;  // host copy of the factor (row-major lower)
     mutable WorkspacePool pool;
 
@@ -144,6 +144,7 @@ struct mcd_mvn {
         if (d_invdiag) (void)hipFree(d_invdiag);
         if (d_Ft) (void)hipFree(d_Ft);
         if (d_Ut) (void)hipFree(d_Ut);
+        if (d_Wt) (void)hipFree(d_Wt);
     }
 };
 
@@ -267,11 +268,24 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
     h->dev.invdiag = h->d_invdiag;
     h->dev.Ft = h->d_Ft;
     h->dev.Ut = h->d_Ut;
+    {   // multiply form for large batches (k_wide.hip): W = L^-1 as MFMA operand tiles
+        std::vector<double> Wt;
+        mcd::pack_w_tiles(n, h->L, Wt);
+        HIP_TRY(hipMalloc((void**)&h->d_Wt, Wt.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(h->d_Wt, Wt.data(), Wt.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->dev.Wt = h->d_Wt;
+    }
     *out = h.release();
     return MCD_OK;
 }
 
 void mcd_mvn_destroy(mcd_mvn_t* h) { delete h; }
+
+int mcd_set_logpdf_form(int form)
+{
+    if (form < MCD_FORM_AUTO || form > MCD_FORM_MULTIPLY) return mcd_set_last_error_(MCD_ERR_INVALID_ARG, "mcd_set_logpdf_form: unknown form");
+    return mcd::set_logpdf_form(form);
+}
 
 int mcd_mvn_dim(const mcd_mvn_t* h) { return h ? h->n : fail(MCD_ERR_INVALID_ARG, "mcd_mvn_dim: NULL handle"); }
 int mcd_mvn_device(const mcd_mvn_t* h) { return h ? h->device : fail(MCD_ERR_INVALID_ARG, "mcd_mvn_device: NULL handle"); }

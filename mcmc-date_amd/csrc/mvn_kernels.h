@@ -17,6 +17,7 @@ struct MvnDev {
     const double* invdiag;  // [NP], 1 / L_ii, one padded
     const double* Ft;       // forward factor  L[i][j]/L[i][i], pair-interleaved column layout, NP*NP
     const double* Ut;       // backward factor L[i][r]/L[r][r], same layout, NP*NP
+    const double* Wt;       // W = L^-1 as 16 x 4 MFMA operand tiles (host_factor.h: pack_w_tiles), for k_wide.hip
 };
 
 // Topology tables of the time/rate trees (pre-order node ids, root = 0).
@@ -90,6 +91,14 @@ struct HmcDev {
 int padded_blocks(int n);          // supported R for dimension n, or -1
 int sweep_chunk_columns(int R);    // columns per register buffer (ncols granularity)
 
+// Many chains per launch: multiply form on the fp64 matrix cores (k_wide.hip).  launch_logpdf / launch_tree_logpdf
+// route to these when use_wide() says so; MCD_WIDE=0 / 1 forces the choice, MCD_WIDE_CT=1|2|4 the chains per workgroup / 16.
+hipError_t launch_logpdf_wide(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
+hipError_t launch_tree_logpdf_wide(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                   const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st);
+int wide_chain_tiles(int64_t batch);
+bool use_wide(const MvnDev& M, int64_t batch);
+int set_logpdf_form(int form);
 hipError_t launch_logpdf(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
 hipError_t launch_grad(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
                        hipStream_t st);

@@ -132,6 +132,21 @@ def _check_cuda(t, device: int, name: str):
 # ----------------------------------------------------------------------------------------------
 # the likelihood object (owns the C handle)
 # ----------------------------------------------------------------------------------------------
+FORMS = {"auto": 0, "sweep": 1, "multiply": 2}    # MCD_FORM_* (include/mcmcdate_mvn.h)
+
+
+def set_logpdf_form(form: str) -> str:
+    """Choose the form of the log-density kernels for this process: "auto" (by dimension and batch size), "sweep" (one
+    chain per wave, the latency form) or "multiply" (z = L^-1 (x - mu) on the fp64 matrix cores, the throughput form).
+    Returns the previous setting.  The two forms agree to rounding, not bit for bit."""
+    if form not in FORMS:
+        raise ValueError(f"set_logpdf_form: expected one of {sorted(FORMS)}, got {form!r}")
+    prev = _capi.lib().mcd_set_logpdf_form(FORMS[form])
+    if prev < 0:
+        _capi.check(prev)
+    return {v: k for k, v in FORMS.items()}[prev]
+
+
 class MvnLikelihood:
     """`likelihoodFunction lhd` with its operands staged once on one GPU.
 

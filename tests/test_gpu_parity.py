@@ -192,7 +192,11 @@ def test_every_launch_geometry(gpu, n):
     lik = M.MvnLikelihood.from_covariance(mu, sigma)
     X = S.sample_chains(mu, sigma, 5000, seed=n)
     ref = O.logpdf_full_batch(mu, P, logdet, X[:40])
-    outs = [lik.logpdf(X[:B])[:40] for B in (40, 600, 5000)]
+    M.set_logpdf_form("sweep")                       # (large batches would otherwise take the multiply form)
+    try:
+        outs = [lik.logpdf(X[:B])[:40] for B in (40, 600, 5000)]
+    finally:
+        M.set_logpdf_form("auto")
     for o in outs:
         assert np.max(rel_err(o, ref)) <= 1e-9
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
@@ -240,6 +244,117 @@ def test_tree_large_batch_two_chains_per_wave(gpu):
     assert np.array_equal(ll[-260:], ll_s) and np.array_equal(lj[-260:], lj_s)
     ref, refj = O.tree_loglik_full_batch(topo.parent, st.heights[-40:], st.rates[-40:], st.time_height[-40:], st.rate_mean[-40:], mu, P, logdet)
     assert np.max(np.abs(ll[-40:] - ref) / np.abs(ref)) <= 1e-11 and np.max(rel_err(lj[-40:], refj)) <= 1e-12
+
+
+# ------------------------------------------------------------------------------------------
+# multiply form (k_wide.hip): z = L^-1 (x - mu) on the fp64 matrix cores, used for large batches
+# ------------------------------------------------------------------------------------------
+@pytest.fixture
+def multiply_form(gpu):
+    prev = M.set_logpdf_form("multiply")
+    yield
+    M.set_logpdf_form(prev)
+
+
+@pytest.mark.parametrize("n,batch", [(1, 3), (2, 1), (9, 5), (15, 16), (16, 17), (17, 100), (63, 7), (64, 64), (65, 33), (129, 17), (200, 64),
+                                     (255, 1500), (256, 512), (257, 9), (272, 40), (500, 21), (513, 70), (768, 12), (1024, 16)])
+def test_multiply_form_logpdf(gpu, multiply_form, n, batch):
+    """Every shape of the tiling: N below one row block, partial and several super blocks (N > 256 walks the chunks
+    0 .. s), ragged chain tiles, padded leading dimension.  Same bound as the column sweep."""
+    import torch
+
+    mu, sigma = S.random_spd_problem(n, seed=n)
+    X = S.sample_chains(mu, sigma, batch, seed=n)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    kappa = np.linalg.cond(sigma)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    ref = O.logpdf_full_batch(mu, P, logdet, X)
+    q = -2.0 * (ref + 0.9189385332046727 * n) - logdet
+    tol = 64 * n * EPS * kappa * np.maximum(1.0, q)
+    ll = lik.logpdf(X)
+    assert np.all(np.abs(ll - ref) <= tol), (np.max(np.abs(ll - ref)), tol.min())
+    ld = n + 3
+    Xd = torch.full((batch, ld), np.nan, dtype=torch.float64, device=gpu)       # the padding must never be read
+    Xd[:, :n] = torch.as_tensor(X, device=gpu)
+    out = torch.empty(batch, dtype=torch.float64, device=gpu)
+    M._capi.check(M._capi.lib().mcd_mvn_logpdf_batch(lik._h, Xd.data_ptr(), ld, batch, 1, None, out.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ll)
+    # a chain's value does not depend on its neighbours or on the batch it travels in
+    assert lik.logpdf1(X[batch - 1]) == ll[batch - 1]
+    M.set_logpdf_form("sweep")
+    sw = lik.logpdf(X)
+    M.set_logpdf_form("multiply")
+    assert np.all(np.abs(sw - ll) <= tol)
+
+
+@pytest.mark.parametrize("ct", [4100, 17000])
+def test_multiply_form_chain_tiles(gpu, multiply_form, ct):
+    """16, 32 and 64 chains per workgroup (chosen by batch size) give each chain the same bits."""
+    n = 130
+    mu, sigma = S.random_spd_problem(n, seed=3)
+    X = S.sample_chains(mu, sigma, ct, seed=3)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    big = lik.logpdf(X)
+    small = lik.logpdf(X[:200])
+    assert np.array_equal(big[:200], small)
+    tail = lik.logpdf(X[-77:])
+    assert np.array_equal(big[-77:], tail)
+    ref = O.logpdf_full_batch(mu, np.linalg.inv(sigma), np.linalg.slogdet(sigma)[1], X[-50:])
+    assert np.max(rel_err(big[-50:], ref)) <= 1e-9
+
+
+@pytest.mark.parametrize("leaves,batch", [(3, 5), (12, 40), (50, 333), (129, 96), (140, 50), (400, 20)])
+def test_multiply_form_tree(gpu, multiply_form, leaves, batch):
+    """Tree states through the multiply form: oracle values, and the root-branch Jacobian bit for bit as the sweep's."""
+    topo = S.random_topology(leaves, seed=leaves)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=leaves)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    st = S.random_states(topo, batch, seed=leaves)
+    tl = M.MvnLikelihood(M.Full(mu, P, logdet)).bind_tree(topo)
+    ll, lj = tl.loglik(st)
+    ref, refj = O.tree_loglik_full_batch(topo.parent, st.heights, st.rates, st.time_height, st.rate_mean, mu, P, logdet)
+    assert np.max(np.abs(ll - ref) / np.abs(ref)) <= 1e-11
+    assert np.max(rel_err(lj, refj)) <= 1e-12
+    ll_d, lj_d = tl.loglik(st.to(gpu))
+    assert np.array_equal(ll_d.cpu().numpy(), ll) and np.array_equal(lj_d.cpu().numpy(), lj)
+    ll_n, none = tl.loglik(st, want_jacobian=False)
+    assert none is None and np.array_equal(ll_n, ll)
+    M.set_logpdf_form("sweep")
+    ll_s, lj_s = tl.loglik(st)
+    M.set_logpdf_form("multiply")
+    assert np.array_equal(lj_s, lj)
+    assert np.max(np.abs(ll_s - ll) / np.abs(ll)) <= 1e-12
+
+
+def test_form_selection(gpu):
+    """auto = sweep for a sampler's usual batch, multiply for thousands of chains of a large tree; unknown values are
+    refused; non-finite inputs flow through the multiply form as through the sweep."""
+    n = 160
+    mu, sigma = S.random_spd_problem(n, seed=11)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    X = S.sample_chains(mu, sigma, 3000, seed=11)
+    assert M.set_logpdf_form("auto") == "auto"
+    auto_small, auto_big = lik.logpdf(X[:256]), lik.logpdf(X)
+    M.set_logpdf_form("sweep")
+    sw_small, sw_big = lik.logpdf(X[:256]), lik.logpdf(X)
+    assert M.set_logpdf_form("multiply") == "sweep"
+    mu_big = lik.logpdf(X)
+    Xn = X[:40].copy()
+    Xn[3, 7] = np.nan
+    Xn[5, 0] = np.inf
+    bad = lik.logpdf(Xn)
+    assert M.set_logpdf_form("auto") == "multiply"
+    assert np.array_equal(auto_small, sw_small) and np.array_equal(auto_big, mu_big)
+    assert not np.array_equal(auto_big, sw_big) and np.max(rel_err(auto_big, sw_big)) <= 1e-12
+    assert np.isnan(bad[3]) and (np.isnan(bad[5]) or bad[5] == -np.inf) and np.all(np.isfinite(np.delete(bad, [3, 5])))
+    with pytest.raises(ValueError):
+        M.set_logpdf_form("fast")
+    assert M._capi.lib().mcd_set_logpdf_form(7) == M._capi.MCD_ERR_INVALID_ARG
+    assert M.set_logpdf_form("auto") == "auto"
 
 
 # ------------------------------------------------------------------------------------------
