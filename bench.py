@@ -90,14 +90,16 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--n", type=int, default=256, help="MVN dimension")
     ap.add_argument("--chains", type=int, default=512, help="chains per GPU")
     ap.add_argument("--swap-period", type=int, default=0, help="all-gather ll every P steps (0 = off)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
     ap.add_argument("--graph-chunk", type=int, default=100, help="steps captured per hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--form", default="auto", choices=["auto", "sweep", "multiply"],
+                    help="log-density kernel form (mcd_set_logpdf_form); auto = multiply for N >= 96 and >= 2048 chains, N >= 32 and >= 8192")
     ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior"])
     args = ap.parse_args()
 
@@ -139,6 +141,8 @@ def main():
     X = torch.as_tensor(X_host, device=dev)
     ll = torch.empty(B, dtype=torch.float64, device=dev)
     lib = M._capi.lib()
+    if args.form != "auto":
+        M.set_logpdf_form(args.form)
 
     if args.kind == "logpdf":
         def step():
@@ -240,6 +244,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    form = args.form
+    if form == "auto":
+        form = "multiply" if (args.kind in ("logpdf", "tree", "posterior") and ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192))) else "sweep"
+    if args.kind not in ("logpdf", "tree", "posterior"):
+        form = "sweep"                                   # gradients and the prior have one form
     run(W)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -289,11 +298,17 @@ def main():
                                        else f"chains sharded x{world} + ll all-gather every {args.swap_period} steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic() if (n == 256 and B == 512 and args.kind == "logpdf") else None,
+                         "traffic": measured_traffic() if (n == 256 and B == 512 and args.kind == "logpdf" and form == "sweep") else None,
                          "kernel_us_per_launch": per_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_b,
                          "fp64_tflops": flops, "fp64_frac": flops / FP64_PEAK_TFLOPS},
         }
+        out["config"]["form"] = form
+        if form == "multiply":
+            # k_wide.hip: a triangular matrix product on the fp64 matrix cores -- priced against the dense fp64 MFMA peak
+            # (v_mfma_f64_16x16x4_f64: 64 cycles per 16x16x4 tile product and SIMD = the vector fp64 rate, 78.6 TFLOP/s)
+            out["roofline"].update({"bound": "mfma", "achieved": flops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": flops / FP64_PEAK_TFLOPS, "hbm_gbs": achieved})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, mu, sigma, X_host)
         print(json.dumps(out))

@@ -69,6 +69,11 @@ foreign import ccall unsafe "mcd_tree_loglik_batch"
 foreign import ccall unsafe "mcd_last_error"
   c_last_error :: IO CString
 
+-- | 0 = by dimension and batch size (default), 1 = column sweep, 2 = multiply form on the fp64 matrix cores; returns
+-- the previous value.  Pin 1 when runs with different chain counts have to agree bit for bit.
+foreign import ccall unsafe "mcd_set_logpdf_form"
+  c_set_logpdf_form :: CInt -> IO CInt
+
 check :: String -> CInt -> IO ()
 check _ 0 = pure ()
 check ctx _ = c_last_error >>= peekCString >>= \m -> error (ctx <> ": " <> m)

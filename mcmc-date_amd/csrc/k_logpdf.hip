@@ -106,7 +106,9 @@ bool use_wide(const MvnDev& M, int64_t batch)
     const int form = g_form.load(std::memory_order_relaxed);
     if (M.Wt == nullptr || form == 1) return false;
     if (form == 2) return true;
-    return M.n >= 128 && batch >= 1024;
+    // measured crossovers (tools/bench_forms.py, profiles/r01_form_crossover.jsonl): at 1024 chains the sweep still wins
+    // or ties for every N, at 2048 the multiply form wins from N = 127 up; small N only pays at 8192 chains
+    return (M.n >= 96 && batch >= 2048) || (M.n >= 32 && batch >= 8192);
 }
 
 int padded_blocks(int n)

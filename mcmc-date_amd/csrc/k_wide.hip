@@ -27,6 +27,15 @@ constexpr int WD_SB = 256;          // rows per super block = columns per staged
 constexpr int WD_LD = WD_SB + 2;    // LDS row stride in doubles: 516 dwords = 4 (mod 64 banks)
 constexpr int WD_P = 8;             // W tiles in flight per row block
 
+// diagnostic build (make stamp_wide): s_memtime phase stamps of every wave of workgroup 0, read back with
+// mcd_wide_debug_stamps (tools/microbench/wide_stamps.py)
+#ifdef MCD_WIDE_STAMP
+__device__ unsigned long long g_wide_dbg[WD_WAVES * 8];
+#define WD_T(i) do { if (blockIdx.x == 0 && lane == 0) g_wide_dbg[wave * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WD_T(i) do { } while (0)
+#endif
+
 struct WideSrc {
     const double* X;                // raw x: [batch][ldx]                                       (TREE = false)
     int64_t ldx;
@@ -63,7 +72,7 @@ __device__ __forceinline__ void wide_stage(double* rs, const double* scs, const 
     } else {
         // distances from the tree state -- app/Probability.hs:201-207 (as load_tree in mvn_device.hpp); scs[] holds
         // tH * rMu of the workgroup's chains.  Slot 0 (the two root branches, sumFirstTwo) is left to wide_stage_root.
-        constexpr int G = 8;
+        constexpr int G = CT == 4 ? 16 : 8;
         const int a = live ? A.T.slot_node[k] : 0;
         const int pa = live ? A.T.parent[a] : 0;             // (the root's parent entry is -1: never index with it)
 #pragma unroll 1
@@ -123,6 +132,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int
     double ssq[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) ssq[ct] = 0.0;
+    WD_T(0);
     if constexpr (TREE) {
         if (tid < CT * 16) {
             const int64_t b = (b0 + tid < batch) ? b0 + tid : batch - 1;
@@ -154,12 +164,15 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int
                 ra[p] = wA[(p < lastA ? p : lastA) * 64];
                 rb[p] = wB[(p < lastB ? p : lastB) * 64];
             }
+            WD_T(1);
             __syncthreads();
             wide_stage<CT, TREE>(rs, scs, M, A, b0, batch, c * WD_SB, tid);
+            WD_T(2);
             if constexpr (TREE) {
                 if (c == 0) wide_stage_root<CT>(rs, scs, M, A, b0, batch, s == 0, tid);
             }
             __syncthreads();
+            WD_T(3);
             // four k tiles (slots h .. h + 3 of the ring) against both row blocks or the longer one only -- no branch
             // inside, so the LDS reads of later tiles are scheduled under the MFMAs of earlier ones
             auto quad = [&](int kt0, auto hsel, auto both, bool refill) {
@@ -215,6 +228,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int
         }
     }
 
+    WD_T(4);
     // column sums: the four lane groups of a wave, then the waves in a fixed order
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -230,6 +244,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int
         for (int w = 0; w < WD_WAVES; ++w) q += part[w * (CT * 16) + tid];
         ll[b0 + tid] = M.c + (-0.5) * (M.logdet + q);      // app/Probability.hs:169
     }
+    WD_T(5);
 }
 
 template <int CT, bool TREE>
@@ -280,3 +295,10 @@ hipError_t launch_tree_logpdf_wide(const MvnDev& M, const TreeDev& T, const doub
 }
 
 }  // namespace mcd
+
+#ifdef MCD_WIDE_STAMP
+extern "C" int mcd_wide_debug_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_wide_dbg), sizeof(unsigned long long) * mcd::WD_WAVES * 8);
+}
+#endif

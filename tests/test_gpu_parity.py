@@ -174,8 +174,12 @@ def test_large_batch_two_chains_per_wave(gpu):
     mu, sigma = S.random_spd_problem(n, seed=5)
     X = S.sample_chains(mu, sigma, batch, seed=5)
     lik = M.MvnLikelihood.from_covariance(mu, sigma)
-    ll = lik.logpdf(torch.as_tensor(X, device=gpu)).cpu().numpy()
-    small = lik.logpdf(X[:300])
+    M.set_logpdf_form("sweep")
+    try:
+        ll = lik.logpdf(torch.as_tensor(X, device=gpu)).cpu().numpy()
+        small = lik.logpdf(X[:300])
+    finally:
+        M.set_logpdf_form("auto")
     assert np.array_equal(ll[:300], small)
     ref = O.logpdf_full_batch(mu, np.linalg.inv(sigma), np.linalg.slogdet(sigma)[1], X[-50:])
     assert np.max(rel_err(ll[-50:], ref)) <= 1e-9
@@ -239,8 +243,12 @@ def test_tree_large_batch_two_chains_per_wave(gpu):
     batch = 4096 + 1500 + 3
     st = S.random_states(topo, batch, seed=9)
     tl = M.MvnLikelihood(M.Full(mu, P, logdet)).bind_tree(topo)
-    ll, lj = tl.loglik(st)
-    ll_s, lj_s = tl.loglik(st.slice(batch - 260, batch))
+    M.set_logpdf_form("sweep")
+    try:
+        ll, lj = tl.loglik(st)
+        ll_s, lj_s = tl.loglik(st.slice(batch - 260, batch))
+    finally:
+        M.set_logpdf_form("auto")
     assert np.array_equal(ll[-260:], ll_s) and np.array_equal(lj[-260:], lj_s)
     ref, refj = O.tree_loglik_full_batch(topo.parent, st.heights[-40:], st.rates[-40:], st.time_height[-40:], st.rate_mean[-40:], mu, P, logdet)
     assert np.max(np.abs(ll[-40:] - ref) / np.abs(ref)) <= 1e-11 and np.max(rel_err(lj[-40:], refj)) <= 1e-12
@@ -388,6 +396,40 @@ def test_properties_full_size(gpu):
     assert np.max(np.abs(G2 - 2.0 * G1)) <= 1e-9 * np.abs(G1).max()
     _, G0 = lik.grad(mu[None, :])
     assert np.all(G0 == 0.0)
+
+
+def test_properties_full_size_many_chains(gpu):
+    """BASELINE's N = 256 at 8192 chains (the automatic choice is the multiply form there): the quadratic form of
+    x = mu + L z is |z|^2, the maximum sits at mu exactly, the density is symmetric around mu, runs repeat bit for bit,
+    and a chain's value is the same in a batch of 8192 (32 chains per workgroup) and of 2100 (16 per workgroup)."""
+    import torch
+
+    n, batch = 256, 8192
+    mu, sigma = S.random_spd_problem(n, seed=256)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    L = lik.cholesky_factor()
+    rng = np.random.default_rng(2)
+    Z = rng.standard_normal((batch, n))
+    X = mu + Z @ L.T
+    X[17] = mu
+    Xd = torch.as_tensor(X, device=gpu)
+    ll = lik.logpdf(Xd).cpu().numpy()
+    c = -0.9189385332046727 * n
+    q = -2.0 * (ll - c) - lik.logdet_sigma
+    q_expected = np.sum(Z * Z, axis=1)
+    keep = np.arange(batch) != 17
+    assert np.max(np.abs(q[keep] - q_expected[keep]) / q_expected[keep]) <= 1e-10
+    assert ll[17] == c - 0.5 * lik.logdet_sigma and np.all(ll <= ll[17])
+    ll_ref = lik.logpdf(torch.as_tensor(2 * mu[None, :] - X, device=gpu)).cpu().numpy()
+    assert np.max(np.abs(ll_ref - ll) / np.abs(ll)) <= 1e-12
+    assert np.array_equal(lik.logpdf(Xd).cpu().numpy(), ll)
+    assert np.array_equal(lik.logpdf(X[:2100]), ll[:2100])
+    M.set_logpdf_form("sweep")
+    try:
+        sw = lik.logpdf(Xd).cpu().numpy()
+    finally:
+        M.set_logpdf_form("auto")
+    assert not np.array_equal(sw, ll) and np.max(np.abs(sw - ll) / np.abs(ll)) <= 1e-13
 
 
 # ------------------------------------------------------------------------------------------
