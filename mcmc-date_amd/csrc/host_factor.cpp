@@ -97,7 +97,7 @@ void pack_factors(int n, int R, const std::vector<double>& L, std::vector<double
     }
 }
 
-void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt)
+void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt, std::vector<double>& Wtb)
 {
     // rows of W one after the other: W_i: = (e_i - sum_{k<i} L_ik W_k:) / L_ii, long double accumulation
     std::vector<double> W((size_t)n * n, 0.0);
@@ -121,6 +121,15 @@ void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt)
             double* t = &Wt[((size_t)2 * ib * (ib + 1) + kt) * 64];
             for (int l = 0; l < 64; ++l) {
                 const int row = 16 * ib + (l & 15), colk = 4 * kt + (l >> 4);
+                if (row < n && colk <= row) t[l] = W[(size_t)row * n + colk];
+            }
+        }
+    Wtb.assign((size_t)2 * NB * (NB + 1) * 64, 0.0);      // sum over ib of 4 (NB - ib) tiles = 2 NB (NB + 1)
+    for (int ib = 0; ib < NB; ++ib)
+        for (int kt = 4 * ib; kt < 4 * NB; ++kt) {
+            double* t = &Wtb[((size_t)4 * (ib * NB - ib * (ib - 1) / 2) + (kt - 4 * ib)) * 64];
+            for (int l = 0; l < 64; ++l) {
+                const int row = 4 * kt + (l >> 4), colk = 16 * ib + (l & 15);     // element (row, colk) of W
                 if (row < n && colk <= row) t[l] = W[(size_t)row * n + colk];
             }
         }

@@ -20,6 +20,8 @@ void pack_factors(int n, int R, const std::vector<double>& L, std::vector<double
 // k tiles kt = 0 .. 4 (ib + 1) - 1 (4 columns each) at tile index 2 ib (ib + 1) + kt; a tile is 64 doubles in lane
 // order, lane l = W[16 ib + (l & 15)][4 kt + (l >> 4)] (the A operand of v_mfma_f64_16x16x4_f64); zeros above the
 // diagonal and beyond n.
-void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt);
+// Wtb: the same for the transposed product y = W^T z (k_wide_grad.hip): row block ib holds the k tiles kt = 4 ib ..
+// 4 NB - 1 at tile index 4 (ib NB - ib (ib - 1) / 2) + (kt - 4 ib), lane l = W[4 kt + (l >> 4)][16 ib + (l & 15)].
+void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt, std::vector<double>& Wtb);
 
 }  // namespace mcd

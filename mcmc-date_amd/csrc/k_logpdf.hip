@@ -111,6 +111,12 @@ bool use_wide(const MvnDev& M, int64_t batch)
     return (M.n >= 96 && batch >= 2048) || (M.n >= 32 && batch >= 8192);
 }
 
+bool use_wide_grad(const MvnDev& M, int64_t batch)
+{
+    // the multiply-form gradient keeps z and y in one LDS chunk: N <= 256
+    return M.Wtb != nullptr && M.n <= 256 && use_wide(M, batch);
+}
+
 int padded_blocks(int n)
 {
     const int r = (n + 63) / 64;

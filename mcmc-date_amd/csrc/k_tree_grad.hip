@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_tree_grad(MvnDev M, TreeDev 
         const double g = -d[k][0];
         gd = fma(g, dist[k][0], gd);
         if (a >= 0) {
-            const int pa = T.parent[a];
+            const int pa = T.slot_parent[row];
             const double sg = s * g;
             gR[b * lds + a] = sg * (h[pa] - h[a]);
             e[a] = sg * r[a];
@@ -138,6 +138,7 @@ hipError_t launch_tree_grad(const MvnDev& M, const TreeDev& T, const double* H, 
                             double* gtH, double* grMu, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (use_wide_grad(M, batch) && T.n_nodes <= 258) return launch_tree_grad_wide(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
     if (M.R == 6 || M.R == 8) return launch_tree_grad_g1(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
     if (M.R == 12) return launch_tree_grad_g2(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
     if (M.R == 16) return launch_tree_grad_g3(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);

@@ -15,105 +15,9 @@
 //     N is not bounded by the register file;
 //   * the result layout of the f64 MFMA keeps a chain on lane & 15 in all four result registers, so the column sums of
 //     squares need no transposition: registers, two lane exchanges, then the 8 waves in a fixed order through LDS.
-#include "mvn_kernels.h"
-#include <type_traits>
+#include "wide_device.hpp"
 
 namespace mcd {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-constexpr int WD_WAVES = 8;
-constexpr int WD_SB = 256;          // rows per super block = columns per staged chunk
-constexpr int WD_LD = WD_SB + 2;    // LDS row stride in doubles: 516 dwords = 4 (mod 64 banks)
-constexpr int WD_P = 8;             // W tiles in flight per row block
-
-// diagnostic build (make stamp_wide): s_memtime phase stamps of every wave of workgroup 0, read back with
-// mcd_wide_debug_stamps (tools/microbench/wide_stamps.py)
-#ifdef MCD_WIDE_STAMP
-__device__ unsigned long long g_wide_dbg[WD_WAVES * 8];
-#define WD_T(i) do { if (blockIdx.x == 0 && lane == 0) g_wide_dbg[wave * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define WD_T(i) do { } while (0)
-#endif
-
-struct WideSrc {
-    const double* X;                // raw x: [batch][ldx]                                       (TREE = false)
-    int64_t ldx;
-    TreeDev T;                      // tree state: heights / rates [batch][lds], tH, rMu [batch]   (TREE = true)
-    const double *H, *Rt;
-    int64_t lds;
-    const double *tH, *rMu;
-    double* logjac;
-};
-
-// One 256-column chunk of R into LDS.  512 threads = two chain rows per pass, so a thread keeps its column: the
-// per-column operands (mu, the slot's node and its parent) are read once, and the CT * 8 passes over the chains are
-// unrolled so that all their loads are in flight together.
-template <int CT, bool TREE>
-__device__ __forceinline__ void wide_stage(double* rs, const double* scs, const MvnDev& M, const WideSrc& A, int64_t b0, int64_t batch,
-                                           int kc0, int tid)
-{
-    const int j = tid & (WD_SB - 1), k = kc0 + j, ch0 = tid >> 8;
-    const bool live = k < M.n;
-    const double m = live ? M.mu[k] : 0.0;
-    if constexpr (!TREE) {
-        constexpr int G = 8;                                   // chain rows in flight per thread
-#pragma unroll 1
-        for (int g = 0; g < CT * 8; g += G) {
-            double v[G];
-#pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const int64_t b = b0 + ch0 + 2 * (g + i);
-                v[i] = (live && b < batch) ? A.X[b * A.ldx + k] : m;        // padded columns and chains: exact zeros
-            }
-#pragma unroll
-            for (int i = 0; i < G; ++i) rs[(ch0 + 2 * (g + i)) * WD_LD + j] = v[i] - m;   // dxs = xs - mu  (app/Probability.hs:171)
-        }
-    } else {
-        // distances from the tree state -- app/Probability.hs:201-207 (as load_tree in mvn_device.hpp); scs[] holds
-        // tH * rMu of the workgroup's chains.  Slot 0 (the two root branches, sumFirstTwo) is left to wide_stage_root.
-        constexpr int G = CT == 4 ? 16 : 8;
-        const int a = live ? A.T.slot_node[k] : 0;
-        const int pa = live ? A.T.parent[a] : 0;             // (the root's parent entry is -1: never index with it)
-#pragma unroll 1
-        for (int g = 0; g < CT * 8; g += G) {
-            double hp[G], ha[G], ra[G];
-#pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const int64_t b = (b0 + ch0 + 2 * (g + i) < batch) ? b0 + ch0 + 2 * (g + i) : batch - 1;
-                const double* h = A.H + b * A.lds;
-                hp[i] = h[pa];
-                ha[i] = h[a];
-                ra[i] = A.Rt[b * A.lds + a];
-            }
-#pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const int ch = ch0 + 2 * (g + i);
-                const double d = ((hp[i] - ha[i]) * ra[i]) * scs[ch];
-                if (k != 0) rs[ch * WD_LD + j] = (live && b0 + ch < batch) ? d - m : 0.0;
-            }
-        }
-    }
-}
-
-// slot 0 of the distances: the branches of the two children of the root added up (app/Tools.hs:36-48), one chain per
-// thread; also the root-branch Jacobian.
-template <int CT>
-__device__ __forceinline__ void wide_stage_root(double* rs, const double* scs, const MvnDev& M, const WideSrc& A, int64_t b0,
-                                                int64_t batch, bool first, int tid)
-{
-    if (tid >= CT * 16) return;
-    const int64_t b = (b0 + tid < batch) ? b0 + tid : batch - 1;
-    const double* h = A.H + b * A.lds;
-    const double* r = A.Rt + b * A.lds;
-    const int a = A.T.slot_node[0], pa = A.T.parent[a], rr = A.T.root_right;
-    double d = (h[pa] - h[a]) * r[a];
-    d = d + (h[0] - h[rr]) * r[rr];
-    d = d * scs[tid];
-    const bool in = b0 + tid < batch;
-    if (first && in && A.logjac != nullptr) A.logjac[b] = log(1.0 / d);      // app/Probability.hs:394, 409
-    rs[tid * WD_LD] = in ? d - M.mu[0] : 0.0;
-}
 
 template <int CT, bool TREE>
 __global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int64_t batch, double* __restrict__ ll)

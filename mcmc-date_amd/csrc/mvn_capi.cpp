@@ -132,7 +132,7 @@ struct mcd_mvn {
     int n = 0, R = 0, device = 0;
     double logdet = 0.0;
     mcd::MvnDev dev{};
-    double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr, *d_Wt = nullptr;
+    double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr, *d_Wt = nullptr, *d_Wtb = nullptr;
     std::vector<double> L;  // host copy of the factor (row-major lower)
     mutable WorkspacePool pool;
 
@@ -145,6 +145,7 @@ struct mcd_mvn {
         if (d_Ft) (void)hipFree(d_Ft);
         if (d_Ut) (void)hipFree(d_Ut);
         if (d_Wt) (void)hipFree(d_Wt);
+        if (d_Wtb) (void)hipFree(d_Wtb);
     }
 };
 
@@ -269,11 +270,14 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
     h->dev.Ft = h->d_Ft;
     h->dev.Ut = h->d_Ut;
     {   // multiply form for large batches (k_wide.hip): W = L^-1 as MFMA operand tiles
-        std::vector<double> Wt;
-        mcd::pack_w_tiles(n, h->L, Wt);
+        std::vector<double> Wt, Wtb;
+        mcd::pack_w_tiles(n, h->L, Wt, Wtb);
         HIP_TRY(hipMalloc((void**)&h->d_Wt, Wt.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(h->d_Wt, Wt.data(), Wt.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&h->d_Wtb, Wtb.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(h->d_Wtb, Wtb.data(), Wtb.size() * sizeof(double), hipMemcpyHostToDevice));
         h->dev.Wt = h->d_Wt;
+        h->dev.Wtb = h->d_Wtb;
     }
     *out = h.release();
     return MCD_OK;
@@ -405,6 +409,8 @@ int mcd_tree_create(mcd_tree_t** out, const mcd_mvn_t* h, int n_nodes, const int
     int o = 1;
     for (int v = l + 1; v < r; ++v) slot[o++] = v;
     for (int v = r + 1; v < n_nodes; ++v) slot[o++] = v;
+    slot.resize(2 * (size_t)NP, 0);                        // second half: the parent of each slot's node
+    for (int i = 0; i < NP; ++i) slot[NP + i] = slot[i] >= 0 ? parent[slot[i]] : 0;
     std::vector<int32_t> cptr(n_nodes + 1, 0), cidx(n_nodes - 1);
     for (int v = 1; v < n_nodes; ++v) cptr[parent[v] + 1]++;
     for (int v = 0; v < n_nodes; ++v) cptr[v + 1] += cptr[v];
@@ -418,11 +424,11 @@ int mcd_tree_create(mcd_tree_t** out, const mcd_mvn_t* h, int n_nodes, const int
     t->parent.assign(parent, parent + n_nodes);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMalloc((void**)&t->d_parent, sizeof(int32_t) * n_nodes));
-    HIP_TRY(hipMalloc((void**)&t->d_slot, sizeof(int32_t) * NP));
+    HIP_TRY(hipMalloc((void**)&t->d_slot, sizeof(int32_t) * 2 * NP));
     HIP_TRY(hipMalloc((void**)&t->d_cptr, sizeof(int32_t) * (n_nodes + 1)));
     HIP_TRY(hipMalloc((void**)&t->d_cidx, sizeof(int32_t) * (n_nodes - 1)));
     HIP_TRY(hipMemcpy(t->d_parent, parent, sizeof(int32_t) * n_nodes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t->d_slot, slot.data(), sizeof(int32_t) * NP, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t->d_slot, slot.data(), sizeof(int32_t) * 2 * NP, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t->d_cptr, cptr.data(), sizeof(int32_t) * (n_nodes + 1), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t->d_cidx, cidx.data(), sizeof(int32_t) * (n_nodes - 1), hipMemcpyHostToDevice));
     t->dev.n_nodes = n_nodes;
@@ -430,6 +436,7 @@ int mcd_tree_create(mcd_tree_t** out, const mcd_mvn_t* h, int n_nodes, const int
     t->dev.root_right = r;
     t->dev.parent = t->d_parent;
     t->dev.slot_node = t->d_slot;
+    t->dev.slot_parent = t->d_slot + NP;
     t->dev.child_ptr = t->d_cptr;
     t->dev.child_idx = t->d_cidx;
     *out = t.release();

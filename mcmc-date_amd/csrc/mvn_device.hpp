@@ -543,7 +543,7 @@ __device__ __forceinline__ void load_tree(double (&d)[R][BT], double (&dist)[R][
         const double m = M.mu[row];
         const double iv = M.invdiag[row];
         const int a = T.slot_node[row];    // -1 for padded rows
-        const int pa = a >= 0 ? T.parent[a] : 0;
+        const int pa = T.slot_parent[row]; // 0 for padded rows
 #pragma unroll
         for (int c = 0; c < BT; ++c) {
             const int64_t b = (b0 + c < batch) ? b0 + c : batch - 1;

@@ -18,6 +18,7 @@ struct MvnDev {
     const double* Ft;       // forward factor  L[i][j]/L[i][i], pair-interleaved column layout, NP*NP
     const double* Ut;       // backward factor L[i][r]/L[r][r], same layout, NP*NP
     const double* Wt;       // W = L^-1 as 16 x 4 MFMA operand tiles (host_factor.h: pack_w_tiles), for k_wide.hip
+    const double* Wtb;      // the tiles of W^T for the gradient's second product (k_wide_grad.hip)
 };
 
 // Topology tables of the time/rate trees (pre-order node ids, root = 0).
@@ -27,6 +28,7 @@ struct TreeDev {
     int root_right;           // second child of the root (the first one is node 1)
     const int32_t* parent;    // [n_nodes]
     const int32_t* slot_node; // [NP] node whose branch feeds distance slot i (slot 0: node 1), -1 padded
+    const int32_t* slot_parent; // [NP] parent of that node (0 padded): saves a dependent load where only the branch is needed
     const int32_t* child_ptr; // [n_nodes + 1] CSR children
     const int32_t* child_idx; // [n_nodes - 1]
 };
@@ -96,6 +98,12 @@ int sweep_chunk_columns(int R);    // columns per register buffer (ncols granula
 hipError_t launch_logpdf_wide(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
 hipError_t launch_tree_logpdf_wide(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                    const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st);
+hipError_t launch_grad_wide(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
+                            hipStream_t st);
+hipError_t launch_tree_grad_wide(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                 const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu,
+                                 hipStream_t st);
+bool use_wide_grad(const MvnDev& M, int64_t batch);
 int wide_chain_tiles(int64_t batch);
 bool use_wide(const MvnDev& M, int64_t batch);
 int set_logpdf_form(int form);

@@ -338,6 +338,62 @@ def test_multiply_form_tree(gpu, multiply_form, leaves, batch):
     assert np.max(np.abs(ll_s - ll) / np.abs(ll)) <= 1e-12
 
 
+@pytest.mark.parametrize("n,batch", [(1, 3), (9, 5), (16, 17), (17, 100), (63, 7), (64, 64), (65, 33), (129, 17), (200, 64), (255, 1500), (256, 520)])
+def test_multiply_form_gradient(gpu, multiply_form, n, batch):
+    """ll and d ll / d x through the two triangular MFMA products (N <= 256), against the oracle and the sweeps."""
+    import torch
+
+    mu, sigma = S.random_spd_problem(n, seed=n)
+    X = S.sample_chains(mu, sigma, batch, seed=n + 1)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    kappa = np.linalg.cond(sigma)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    ll, G = lik.grad(X)
+    assert np.array_equal(ll, lik.logpdf(X))                 # same forward product, same bits
+    Gref = O.grad_full_batch(mu, P, X)
+    gtol = 64 * n * EPS * kappa * np.abs(Gref).max() * 4
+    assert np.max(np.abs(G - Gref)) <= gtol, (np.max(np.abs(G - Gref)), gtol)
+    ll_d, G_d = lik.grad(torch.as_tensor(X, device=gpu))
+    assert np.array_equal(ll_d.cpu().numpy(), ll) and np.array_equal(G_d.cpu().numpy(), G)
+    M.set_logpdf_form("sweep")
+    ll_s, G_s = lik.grad(X)
+    M.set_logpdf_form("multiply")
+    assert np.max(np.abs(G_s - G)) <= gtol and np.max(rel_err(ll_s, ll)) <= 1e-12
+    if n > 1:
+        _, G0 = lik.grad(mu[None, :])
+        assert np.all(G0 == 0.0)
+
+
+@pytest.mark.parametrize("leaves,batch", [(3, 5), (4, 33), (12, 40), (50, 333), (100, 70), (129, 96)])
+def test_multiply_form_tree_gradient(gpu, multiply_form, leaves, batch):
+    """Chain rule to heights, rates, tH, rMu on the LDS copy of g: oracle values per chain, sweep values for all."""
+    topo = S.random_topology(leaves, seed=leaves)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=leaves)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    st = S.random_states(topo, batch, seed=leaves + 3)
+    tl = M.MvnLikelihood(M.Full(mu, P, logdet)).bind_tree(topo)
+    out = tl.grad(st)
+    ll, _ = tl.loglik(st)
+    assert np.array_equal(out[0], ll)
+    for b in sorted({0, batch // 2, batch - 1}):
+        gH, gR, gt, gm = O.tree_grad_full(topo.parent, st.heights[b], st.rates[b], st.time_height[b], st.rate_mean[b], mu, P)
+        sc = max(np.abs(gH).max(), np.abs(gR).max())
+        assert np.max(np.abs(out[1][b] - gH)) <= 1e-9 * sc and np.max(np.abs(out[2][b] - gR)) <= 1e-9 * sc
+        assert abs(out[3][b] - gt) <= 1e-9 * abs(gt) and abs(out[4][b] - gm) <= 1e-9 * abs(gm)
+    out_d = tl.grad(st.to(gpu))
+    for a, b in zip(out, out_d):
+        assert np.array_equal(a, b.cpu().numpy())
+    M.set_logpdf_form("sweep")
+    sw = tl.grad(st)
+    M.set_logpdf_form("multiply")
+    sc = max(np.abs(sw[1]).max(), np.abs(sw[2]).max())
+    assert np.max(np.abs(sw[1] - out[1])) <= 1e-10 * sc and np.max(np.abs(sw[2] - out[2])) <= 1e-10 * sc
+    assert np.max(np.abs(sw[3] - out[3]) / np.abs(sw[3])) <= 1e-9 and np.max(np.abs(sw[4] - out[4]) / np.abs(sw[4])) <= 1e-9
+
+
 def test_form_selection(gpu):
     """auto = sweep for a sampler's usual batch, multiply for thousands of chains of a large tree; unknown values are
     refused; non-finite inputs flow through the multiply form as through the sweep."""

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[512, 2048, 8192, 32768])
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--tree", action="store_true")
+    ap.add_argument("--grad", action="store_true", help="time the gradient entry points (ll + gradient) instead of ll alone")
     ap.add_argument("--ct", type=int, default=0, help="informational: MCD_WIDE_CT must be set in the environment")
     a = ap.parse_args()
     L = M._capi.lib()
@@ -55,9 +56,28 @@ def main():
         lik = M.MvnLikelihood.from_covariance(mu, sigma)
         tl = lik.bind_tree(topo) if a.tree else None
         for B in a.batch:
-            if a.tree:
+            if a.tree and a.grad:
+                st = S.random_states(topo, B, seed=B).to(dev)
+                ll = torch.empty(B, dtype=torch.float64, device=dev)
+                gH, gR, gt, gm = torch.empty_like(st.heights), torch.empty_like(st.rates), torch.empty_like(ll), torch.empty_like(ll)
+                sp = M.likelihood._stream_ptr(0)
+
+                def run():
+                    M._capi.check(L.mcd_tree_grad_batch(tl._t, st.heights.data_ptr(), st.rates.data_ptr(), st.heights.stride(0), st.time_height.data_ptr(),
+                                                        st.rate_mean.data_ptr(), B, 1, sp, ll.data_ptr(), gH.data_ptr(), gR.data_ptr(), gt.data_ptr(), gm.data_ptr()))
+                    return gH
+            elif a.tree:
                 st = S.random_states(topo, B, seed=B).to(dev)
                 run = lambda: tl.loglik(st, want_jacobian=True)[0]
+            elif a.grad:
+                X = torch.as_tensor(S.sample_chains(mu, sigma, B, seed=B), device=dev)
+                ll = torch.empty(B, dtype=torch.float64, device=dev)
+                G = torch.empty_like(X)
+                sp = M.likelihood._stream_ptr(0)
+
+                def run():
+                    M._capi.check(L.mcd_mvn_grad_batch(lik._h, X.data_ptr(), X.stride(0), B, 1, sp, ll.data_ptr(), G.data_ptr(), G.stride(0)))
+                    return G
             else:
                 X = torch.as_tensor(S.sample_chains(mu, sigma, B, seed=B), device=dev)
                 out = torch.empty(B, dtype=torch.float64, device=dev)
@@ -69,9 +89,10 @@ def main():
                 vals[name] = run().cpu().numpy().copy()
                 res[name + "_us"] = round(time_launches(run, a.iters), 2)
             L.mcd_set_logpdf_form(0)
-            flops = n * (n + 1.0) * B
-            diff = float(np.max(np.abs(vals["sweep"] - vals["multiply"]) / np.maximum(1.0, np.abs(vals["sweep"]))))
-            print(json.dumps({"n": n, "batch": B, "tree": a.tree, **res, "multiply_frac_fp64_peak": round(flops / (res["multiply_us"] * 1e-6) / FP64_PEAK, 4),
+            flops = n * (n + 1.0) * B * (2 if a.grad else 1)
+            scale = np.abs(vals["sweep"]).max() if a.grad else np.maximum(1.0, np.abs(vals["sweep"]))
+            diff = float(np.max(np.abs(vals["sweep"] - vals["multiply"]) / scale))
+            print(json.dumps({"n": n, "batch": B, "tree": a.tree, "grad": a.grad, **res, "multiply_frac_fp64_peak": round(flops / (res["multiply_us"] * 1e-6) / FP64_PEAK, 4),
                               "sweep_frac_fp64_peak": round(flops / (res["sweep_us"] * 1e-6) / FP64_PEAK, 4), "max_rel_diff": diff,
                               "ct": os.environ.get("MCD_WIDE_CT", "auto")}), flush=True)
 
