@@ -244,11 +244,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    form = args.form
-    if form == "auto":
-        form = "multiply" if (args.kind in ("logpdf", "tree", "posterior") and ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192))) else "sweep"
-    if args.kind not in ("logpdf", "tree", "posterior"):
-        form = "sweep"                                   # gradients and the prior have one form
+    # which form the launch takes (mirror of use_wide / use_wide_grad in csrc/k_logpdf.hip)
+    has_grad = args.kind in ("grad", "tree_grad")
+    if args.kind == "prior" or (has_grad and n > 256):
+        form = "sweep"
+    elif args.form != "auto":
+        form = args.form
+    else:
+        form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
     run(W)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -277,7 +280,7 @@ def main():
         per_launch_s = (dev_ms * 1e-3) / K
         alg_b = algorithmic_bytes_per_eval(n, B) * B
         achieved = alg_b / per_launch_s / 1e9
-        flops = algorithmic_flops_per_eval(n) * B / per_launch_s / 1e12
+        flops = algorithmic_flops_per_eval(n) * (2.0 if has_grad else 1.0) * B / per_launch_s / 1e12
         out = {
             "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes",   # BASELINE.json:metric, verbatim
             "value": evals / elapsed,

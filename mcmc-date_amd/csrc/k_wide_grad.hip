@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
     double* rs = smem;                                   // [CT * 16][WD_LD]: residuals, then z, then g (then e by node)
     double* part = smem + CT * 16 * WD_LD;               // [WD_WAVES][CT * 16]
     double* scs = part + WD_WAVES * CT * 16;             // [CT * 16] tH * rMu per chain (tree state)
-    double* gpart = scs + CT * 16;                       // [CT * 16][4] partial g.d per chain and wave quarter (tree state)
+    double* gpart = scs + CT * 16;                       // [CT * 16][4] partial g.d per chain and wave quarter + [CT * 16] root branch (tree state)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b0 = (int64_t)blockIdx.x * (CT * 16);
@@ -124,33 +124,43 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
         const int c00 = v0 < n_nodes ? A.T.child_ptr[v0] : 0, c01 = v0 < n_nodes ? A.T.child_ptr[v0 + 1] : 0;
         const int c10 = v1 < n_nodes ? A.T.child_ptr[v1] : 0, c11 = v1 < n_nodes ? A.T.child_ptr[v1 + 1] : 0;
         const int k00 = c01 - c00 > 0 ? A.T.child_idx[c00] : 0, k01 = c01 - c00 > 1 ? A.T.child_idx[c00 + 1] : 0;
-        double ev[CT * 8], e2[CT * 8], gd[CT * 8];
+        double ev[CT * 8], gd[CT * 8];
+        auto chains8 = [&](auto half) {                    // eight chain rows at a time: their loads are in flight together
+            constexpr int h0 = decltype(half)::value * 8;
 #pragma unroll
-        for (int it = 0; it < CT * 8; ++it) {
-            const int ch = ch0 + 2 * it;
-            const int64_t b = (b0 + ch < batch) ? b0 + ch : batch - 1;
-            const bool in = live && b0 + ch < batch;
-            const double* h = A.H + b * A.lds;
-            const double* r = A.Rt + b * A.lds;
-            const double g = live ? rs[ch * WD_LD + j] : 0.0;
-            const double s = scs[ch];
-            const double t = live ? h[pa] - h[a] : 0.0;
-            const double ra = live ? r[a] : 0.0;
-            double dist = t * ra;
-            const double sg = s * g;
-            ev[it] = sg * ra;
-            e2[it] = 0.0;
-            if (in) O.gR[b * A.lds + a] = sg * t;                               // d ll / d r_v = s g t_v
-            if (j == 0) {                                                        // the second root branch shares slot 0
-                const double t2 = h[0] - h[rr];
-                dist = dist + t2 * r[rr];
-                e2[it] = sg * r[rr];
-                if (in) {
-                    O.gR[b * A.lds + rr] = sg * t2;
-                    O.gR[b * A.lds] = 0.0;                                       // stem rate: unused by the likelihood
-                }
+            for (int i = 0; i < 8; ++i) {
+                const int it = h0 + i, ch = ch0 + 2 * it;
+                const int64_t b = (b0 + ch < batch) ? b0 + ch : batch - 1;
+                const double* h = A.H + b * A.lds;
+                const double g = live ? rs[ch * WD_LD + j] : 0.0;
+                const double t = live ? h[pa] - h[a] : 0.0;
+                const double ra = live ? A.Rt[b * A.lds + a] : 0.0;
+                const double sg = scs[ch] * g;
+                ev[it] = sg * ra;
+                if (live && b0 + ch < batch) O.gR[b * A.lds + a] = sg * t;      // d ll / d r_v = s g t_v
+                gd[it] = g * ((t * ra) * scs[ch]);
             }
-            gd[it] = g * (dist * s);
+        };
+        chains8(std::integral_constant<int, 0>{});
+        if constexpr (CT == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            chains8(std::integral_constant<int, 1>{});
+        }
+        // the second root branch shares slot 0 (sumFirstTwo): one chain per thread
+        double e_rr = 0.0, gd_rr = 0.0;
+        if (tid < CT * 16) {
+            const int64_t b = (b0 + tid < batch) ? b0 + tid : batch - 1;
+            const double* h = A.H + b * A.lds;
+            const double r2 = A.Rt[b * A.lds + rr];
+            const double t2 = h[0] - h[rr];
+            const double g0 = rs[tid * WD_LD];
+            const double sg = scs[tid] * g0;
+            e_rr = sg * r2;
+            gd_rr = g0 * ((t2 * r2) * scs[tid]);
+            if (b0 + tid < batch) {
+                O.gR[b * A.lds + rr] = sg * t2;
+                O.gR[b * A.lds] = 0.0;                                           // stem rate: unused by the likelihood
+            }
         }
         // g . d: the 64 columns of this wave (all chain rows at once, so the exchanges overlap), then the four waves of a
         // chain row in a fixed order below
@@ -168,14 +178,15 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
         for (int it = 0; it < CT * 8; ++it) {
             const int ch = ch0 + 2 * it;
             if (live) rs[ch * WD_LD + a] = ev[it];        // e by node id (slots -> nodes is one-to-one onto 1 .. n_nodes - 1 \ {rr})
-            if (j == 0) {
-                rs[ch * WD_LD + rr] = e2[it];
-                rs[ch * WD_LD] = 0.0;                     // the root has no branch
-            }
+        }
+        if (tid < CT * 16) {
+            rs[tid * WD_LD + rr] = e_rr;
+            rs[tid * WD_LD] = 0.0;                        // the root has no branch
+            gpart[CT * 16 * 4 + tid] = gd_rr;
         }
         __syncthreads();
         if (tid < CT * 16 && b0 + tid < batch) {
-            const double gdot = ((gpart[tid * 4] + gpart[tid * 4 + 1]) + gpart[tid * 4 + 2]) + gpart[tid * 4 + 3];
+            const double gdot = (((gpart[tid * 4] + gpart[tid * 4 + 1]) + gpart[tid * 4 + 2]) + gpart[tid * 4 + 3]) + gpart[CT * 16 * 4 + tid];
             O.gtH[b0 + tid] = gdot / A.tH[b0 + tid];
             O.grMu[b0 + tid] = gdot / A.rMu[b0 + tid];
         }
@@ -211,7 +222,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
 template <int CT, bool TREE>
 static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, const WideGradOut& O, int64_t batch, hipStream_t st)
 {
-    constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16 + CT * 16 * 4) * sizeof(double);
+    constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16 + CT * 16 * 5) * sizeof(double);
     static hipError_t attr = hipFuncSetAttribute((const void*)k_wide_grad<CT, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (attr != hipSuccess) return attr;
     const unsigned grid = (unsigned)((batch + CT * 16 - 1) / (CT * 16));

@@ -122,11 +122,12 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(fused.age_sums()[:2], phased.age_sums()[:2]))
 
 
-@pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150)])
+@pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150), (70, 2100, 24)])
 def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
     """Synthetic trees beyond 64 nodes (70 leaves: 139 nodes, N = 137, three row blocks; 128 leaves: 255 nodes, N = 253,
     the size of BASELINE.json's config 3, with 64 chains): lanes stride over the nodes and the likelihood runs through
-    the streaming kernel, two launches per step; parity with the CPU twin as for the small trees."""
+    the streaming kernel, two launches per step; parity with the CPU twin as for the small trees.  With 2100 chains the
+    likelihood launch takes the multiply form on the matrix cores (k_wide.hip)."""
     from mcmc_date_amd import synthetic as S
 
     topo = S.random_topology(n_leaves, seed=3)

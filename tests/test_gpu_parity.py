@@ -411,7 +411,10 @@ def test_form_selection(gpu):
     Xn[3, 7] = np.nan
     Xn[5, 0] = np.inf
     bad = lik.logpdf(Xn)
+    _, G_mu = lik.grad(X)
     assert M.set_logpdf_form("auto") == "multiply"
+    _, G_auto = lik.grad(X)
+    assert np.array_equal(G_auto, G_mu)                      # gradients follow the same choice (N <= 256)
     assert np.array_equal(auto_small, sw_small) and np.array_equal(auto_big, mu_big)
     assert not np.array_equal(auto_big, sw_big) and np.max(rel_err(auto_big, sw_big)) <= 1e-12
     assert np.isnan(bad[3]) and (np.isnan(bad[5]) or bad[5] == -np.inf) and np.all(np.isfinite(np.delete(bad, [3, 5])))
