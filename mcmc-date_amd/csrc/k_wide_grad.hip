@@ -14,6 +14,7 @@
 // runs on the LDS copy: e[v] = s g[slot(v)] r_v is scattered into the same rows by node id, then every node gathers its
 // children.
 #include "wide_device.hpp"
+#include <atomic>
 
 namespace mcd {
 
@@ -223,8 +224,15 @@ template <int CT, bool TREE>
 static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, const WideGradOut& O, int64_t batch, hipStream_t st)
 {
     constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16 + CT * 16 * 5) * sizeof(double);
-    static hipError_t attr = hipFuncSetAttribute((const void*)k_wide_grad<CT, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (attr != hipSuccess) return attr;
+    // more than 64 KiB of dynamic LDS has to be allowed once per device (a process may hold handles on several GPUs)
+    static std::atomic<bool> allowed[64];
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!allowed[dev].load(std::memory_order_acquire)) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)k_wide_grad<CT, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)) return e;
+        allowed[dev].store(true, std::memory_order_release);
+    }
     const unsigned grid = (unsigned)((batch + CT * 16 - 1) / (CT * 16));
     hipLaunchKernelGGL((k_wide_grad<CT, TREE>), dim3(grid), dim3(64 * WD_WAVES), bytes, st, M, A, O, batch);
     return hipGetLastError();
