@@ -209,8 +209,10 @@ hipError_t launch_tree_logpdf_wide(const MvnDev& M, const TreeDev& T, const doub
 }  // namespace mcd
 
 #ifdef MCD_WIDE_STAMP
+#ifndef MCD_WIDE_STAMP_GRAD
 extern "C" int mcd_wide_debug_stamps(unsigned long long* out)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_wide_dbg), sizeof(unsigned long long) * mcd::WD_WAVES * 8);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_wide_dbg), sizeof(unsigned long long) * mcd::WD_WAVES * 16);
 }
+#endif
 #endif

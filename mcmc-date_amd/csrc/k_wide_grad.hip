@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
     const int shift = 16 - nb;
     const int bA = wave - shift, bB = 15 - wave - shift;  // this wave's row blocks (or < 0)
 
+    WD_T(0);
     if constexpr (TREE) {
         if (tid < CT * 16) {
             const int64_t b = (b0 + tid < batch) ? b0 + tid : batch - 1;
@@ -60,9 +61,15 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
         }
     }
     __syncthreads();
-    wide_stage<CT, TREE>(rs, scs, M, A, b0, batch, 0, tid);
-    if constexpr (TREE) wide_stage_root<CT>(rs, scs, M, A, b0, batch, false, tid);
+    double tk[CT * 8], rk[CT * 8];                        // tree state: branch duration and rate of (slot j, chain row it)
+    if constexpr (TREE) {
+        wide_stage_tree_keep<CT>(rs, scs, M, A, b0, batch, tid, tk, rk);
+        wide_stage_root<CT>(rs, scs, M, A, b0, batch, false, tid);
+    } else {
+        wide_stage<CT, false>(rs, scs, M, A, b0, batch, 0, tid);
+    }
     __syncthreads();
+    WD_T(1);
 
     // ---- forward: z = W r -------------------------------------------------------------------------------------------
     d4 accA[CT], accB[CT];
@@ -84,6 +91,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
         v += __shfl_xor(v, 32);
         if (lane < 16) part[wave * (CT * 16) + ct * 16 + lane] = v;
     }
+    WD_T(2);
     __syncthreads();                                      // every wave has read the residuals
     if (bA >= 0) store_tile_rows<CT>(rs, accA, bA, col, kq, 1.0);
     if (bB >= 0) store_tile_rows<CT>(rs, accB, bB, col, kq, 1.0);
@@ -94,16 +102,19 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
         O.ll[b0 + tid] = M.c + (-0.5) * (M.logdet + q);   // app/Probability.hs:169
     }
     __syncthreads();
+    WD_T(3);
 
     // ---- backward: y = W^T z; block b starts at tile 4 (b nb - b (b - 1) / 2) of the stream, k tiles 4 b .. 4 nb - 1 ----
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) accA[ct] = accB[ct] = d4{0.0, 0.0, 0.0, 0.0};
     if (bA >= 0) wide_tri_pass<CT>(M.Wtb + (int64_t)(4 * (bA * nb - bA * (bA - 1) / 2)) * 64 + lane, 4 * (nb - bA), 4 * bA, rs, col, kq, accA);
     if (bB >= 0) wide_tri_pass<CT>(M.Wtb + (int64_t)(4 * (bB * nb - bB * (bB - 1) / 2)) * 64 + lane, 4 * (nb - bB), 4 * bB, rs, col, kq, accB);
+    WD_T(4);
     __syncthreads();                                      // every wave has read z
     if (bA >= 0) store_tile_rows<CT>(rs, accA, bA, col, kq, -1.0);   // g = -y
     if (bB >= 0) store_tile_rows<CT>(rs, accB, bB, col, kq, -1.0);
     __syncthreads();
+    WD_T(5);
 
     // ---- outputs: thread = (column j, chain rows ch0, ch0 + 2, ...) as in wide_stage ----------------------------------
     const int j = tid & (WD_SB - 1), ch0 = tid >> 8;
@@ -118,7 +129,6 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
     } else {
         const int n_nodes = A.T.n_nodes;                  // = N + 2 <= WD_LD
         const int a = live ? A.T.slot_node[j] : 0;
-        const int pa = live ? A.T.slot_parent[j] : 0;
         const int rr = A.T.root_right;
         // children of the node(s) this thread gathers for below (requested now, used after two barriers)
         const int v0 = j, v1 = j + WD_SB;
@@ -126,26 +136,15 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
         const int c10 = v1 < n_nodes ? A.T.child_ptr[v1] : 0, c11 = v1 < n_nodes ? A.T.child_ptr[v1 + 1] : 0;
         const int k00 = c01 - c00 > 0 ? A.T.child_idx[c00] : 0, k01 = c01 - c00 > 1 ? A.T.child_idx[c00 + 1] : 0;
         double ev[CT * 8], gd[CT * 8];
-        auto chains8 = [&](auto half) {                    // eight chain rows at a time: their loads are in flight together
-            constexpr int h0 = decltype(half)::value * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int it = h0 + i, ch = ch0 + 2 * it;
-                const int64_t b = (b0 + ch < batch) ? b0 + ch : batch - 1;
-                const double* h = A.H + b * A.lds;
-                const double g = live ? rs[ch * WD_LD + j] : 0.0;
-                const double t = live ? h[pa] - h[a] : 0.0;
-                const double ra = live ? A.Rt[b * A.lds + a] : 0.0;
-                const double sg = scs[ch] * g;
-                ev[it] = sg * ra;
-                if (live && b0 + ch < batch) O.gR[b * A.lds + a] = sg * t;      // d ll / d r_v = s g t_v
-                gd[it] = g * ((t * ra) * scs[ch]);
-            }
-        };
-        chains8(std::integral_constant<int, 0>{});
-        if constexpr (CT == 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            chains8(std::integral_constant<int, 1>{});
+        for (int it = 0; it < CT * 8; ++it) {
+            const int ch = ch0 + 2 * it;
+            const int64_t b = b0 + ch;
+            const double g = live ? rs[ch * WD_LD + j] : 0.0;
+            const double sg = scs[ch] * g;
+            ev[it] = sg * rk[it];
+            if (live && b < batch) O.gR[b * A.lds + a] = sg * tk[it];          // d ll / d r_v = s g t_v
+            gd[it] = g * ((tk[it] * rk[it]) * scs[ch]);
         }
         // the second root branch shares slot 0 (sumFirstTwo): one chain per thread
         double e_rr = 0.0, gd_rr = 0.0;
@@ -163,6 +162,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
                 O.gR[b * A.lds] = 0.0;                                           // stem rate: unused by the likelihood
             }
         }
+        WD_T(6);
         // g . d: the 64 columns of this wave (all chain rows at once, so the exchanges overlap), then the four waves of a
         // chain row in a fixed order below
 #pragma unroll
@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
 #pragma unroll
             for (int it = 0; it < CT * 8; ++it) gpart[(ch0 + 2 * it) * 4 + (wave & 3)] = gd[it];
         }
+        WD_T(7);
         __syncthreads();                                  // every thread holds its g-derived values: the rows can be reused
 #pragma unroll
         for (int it = 0; it < CT * 8; ++it) {
@@ -191,6 +192,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
             O.gtH[b0 + tid] = gdot / A.tH[b0 + tid];
             O.grMu[b0 + tid] = gdot / A.rMu[b0 + tid];
         }
+        WD_T(8);
         // d ll / d h_v = sum_children e_c - e_v, one node per thread column (n_nodes <= 258: columns 0 .. 255 and a tail of 2)
         if (v0 < n_nodes) {
 #pragma unroll 4
@@ -218,6 +220,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
             }
         }
     }
+    WD_T(9);
 }
 
 template <int CT, bool TREE>
@@ -283,3 +286,10 @@ hipError_t launch_tree_grad_wide(const MvnDev& M, const TreeDev& T, const double
 }
 
 }  // namespace mcd
+
+#ifdef MCD_WIDE_STAMP_GRAD
+extern "C" int mcd_wide_debug_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_wide_dbg), sizeof(unsigned long long) * mcd::WD_WAVES * 16);
+}
+#endif

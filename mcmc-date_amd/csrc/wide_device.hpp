@@ -16,8 +16,8 @@ constexpr int WD_P = 8;             // W tiles in flight per row block
 // diagnostic build (make stamp_wide): s_memtime phase stamps of every wave of workgroup 0, read back with
 // mcd_wide_debug_stamps (tools/microbench/wide_stamps.py)
 #ifdef MCD_WIDE_STAMP
-__device__ unsigned long long g_wide_dbg[WD_WAVES * 8];
-#define WD_T(i) do { if (blockIdx.x == 0 && lane == 0) g_wide_dbg[wave * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_wide_dbg[WD_WAVES * 16];
+#define WD_T(i) do { if (blockIdx.x == 0 && lane == 0) g_wide_dbg[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WD_T(i) do { } while (0)
 #endif
@@ -79,6 +79,45 @@ __device__ __forceinline__ void wide_stage(double* rs, const double* scs, const 
                 if (k != 0) rs[ch * WD_LD + j] = (live && b0 + ch < batch) ? d - m : 0.0;
             }
         }
+    }
+}
+
+// The same for one chunk of a tree state, keeping each slot's branch duration t = h_parent - h_node and rate per chain
+// row in registers: the gradient's chain rule (k_wide_grad.hip) needs them again and would otherwise gather them twice.
+template <int CT>
+__device__ __forceinline__ void wide_stage_tree_keep(double* rs, const double* scs, const MvnDev& M, const WideSrc& A, int64_t b0,
+                                                     int64_t batch, int tid, double (&tk)[CT * 8], double (&rk)[CT * 8])
+{
+    const int j = tid & (WD_SB - 1), ch0 = tid >> 8;
+    const bool live = j < M.n;
+    const double m = live ? M.mu[j] : 0.0;
+    const int a = live ? A.T.slot_node[j] : 0;
+    const int pa = live ? A.T.slot_parent[j] : 0;
+    auto rows8 = [&](auto half) {
+        constexpr int h0 = decltype(half)::value * 8;
+        double hp[8], ha[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t b = (b0 + ch0 + 2 * (h0 + i) < batch) ? b0 + ch0 + 2 * (h0 + i) : batch - 1;
+            const double* h = A.H + b * A.lds;
+            hp[i] = h[pa];
+            ha[i] = h[a];
+            rk[h0 + i] = A.Rt[b * A.lds + a];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = ch0 + 2 * (h0 + i);
+            const bool in = live && b0 + ch < batch;
+            tk[h0 + i] = in ? hp[i] - ha[i] : 0.0;
+            rk[h0 + i] = in ? rk[h0 + i] : 0.0;
+            const double d = (tk[h0 + i] * rk[h0 + i]) * scs[ch];
+            if (j != 0) rs[ch * WD_LD + j] = in ? d - m : 0.0;
+        }
+    };
+    rows8(std::integral_constant<int, 0>{});
+    if constexpr (CT == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        rows8(std::integral_constant<int, 1>{});
     }
 }
 

@@ -24,9 +24,9 @@ reps = 50
 for _ in range(reps + 5):
     lik.logpdf_into(X, out)
     torch.cuda.synchronize()
-    st = np.zeros(64, dtype=np.uint64)
+    st = np.zeros(128, dtype=np.uint64)
     L.mcd_wide_debug_stamps(st.ctypes.data)
-    st = st.reshape(8, 8).astype(np.int64)
+    st = st.reshape(8, 16).astype(np.int64)
     if _ >= 5:
         acc += np.diff(st[:, :6], axis=1)
 acc /= reps
