@@ -166,10 +166,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
         // g . d: the 64 columns of this wave (all chain rows at once, so the exchanges overlap), then the four waves of a
         // chain row in a fixed order below
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-#pragma unroll
-            for (int it = 0; it < CT * 8; ++it) gd[it] += __shfl_xor(gd[it], m);
-        }
+        for (int it = 0; it < CT * 8; ++it) gd[it] = wd_wave_sum(gd[it]);
         if (lane == 0) {
 #pragma unroll
             for (int it = 0; it < CT * 8; ++it) gpart[(ch0 + 2 * it) * 4 + (wave & 3)] = gd[it];

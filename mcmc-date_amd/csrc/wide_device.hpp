@@ -22,6 +22,32 @@ __device__ unsigned long long g_wide_dbg[WD_WAVES * 16];
 #define WD_T(i) do { } while (0)
 #endif
 
+// Sum over the 64 lanes with DPP row operations + four readlanes, result wave-uniform, fixed order (as wave_sum in
+// mvn_device.hpp): about a tenth of the cost of six ds_bpermute exchanges.
+template <int CTRL>
+__device__ __forceinline__ double wd_dpp_mov64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wd_readlane64(double v, int srclane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wd_wave_sum(double v)
+{
+    v += wd_dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += wd_dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += wd_dpp_mov64<0x124>(v);  // row_ror:4
+    v += wd_dpp_mov64<0x128>(v);  // row_ror:8 -> every lane holds its 16-lane row sum
+    return (wd_readlane64(v, 0) + wd_readlane64(v, 16)) + (wd_readlane64(v, 32) + wd_readlane64(v, 48));
+}
+
 struct WideSrc {
     const double* X;                // raw x: [batch][ldx]                                       (TREE = false)
     int64_t ldx;
