@@ -90,7 +90,7 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=100000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--n", type=int, default=256, help="MVN dimension")
     ap.add_argument("--chains", type=int, default=512, help="chains per GPU")
@@ -198,7 +198,19 @@ def main():
                                                       gR.data_ptr(), gt.data_ptr(), gm.data_ptr()))
 
     gathered = torch.empty(world * B, dtype=torch.float64, device=ctl_dev) if (world > 1 and args.swap_period > 0) else None
-    use_graph = (not args.no_graph) and gathered is None
+    # which form the launch takes (mirror of use_wide / use_wide_grad in csrc/k_logpdf.hip)
+    has_grad = args.kind in ("grad", "tree_grad")
+    if args.kind == "prior" or (has_grad and n > 256):
+        form = "sweep"
+    elif args.form != "auto":
+        form = args.form
+    else:
+        form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
+    # hipGraph replay hides the per-launch dispatch cost of the few-microsecond sweep launches; the multiply form's launches
+    # are longer than an eager dispatch and are launched eagerly.  (On this pool about one run in twenty sees the host learn
+    # of the completion ~60 ms late -- graph or eager, blocking wait or polling, HSA_ENABLE_INTERRUPT=0 or not -- while the HIP
+    # events of the same run agree with the kernel trace; the default run is long enough that such an outlier costs < 10 %.)
+    use_graph = (not args.no_graph) and gathered is None and form == "sweep"
     K, W = args.steps, args.warmup
 
     # --- build the launch schedule -----------------------------------------------------------
@@ -217,6 +229,9 @@ def main():
                 for _ in range(sz):
                     step()
             gmap[sz] = g
+        for g in gmap.values():                          # the first replay uploads the graph: keep that out of the timed
+            g.replay()                                   # region whatever --warmup is
+        torch.cuda.synchronize()
 
         def run(k):
             full, rem = divmod(k, chunk)
@@ -244,21 +259,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # which form the launch takes (mirror of use_wide / use_wide_grad in csrc/k_logpdf.hip)
-    has_grad = args.kind in ("grad", "tree_grad")
-    if args.kind == "prior" or (has_grad and n > 256):
-        form = "sweep"
-    elif args.form != "auto":
-        form = args.form
-    else:
-        form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
-    run(W)
+    # warm-up = W untimed steps; the last of them go through the same sequence as the timed region (timing events,
+    # replay, polling) so that nothing in it runs for the first time under the clock
+    r = min(W, args.graph_chunk) if use_graph else min(W, 10)
+    run(W - r)
+    fence()
+    if r > 0:
+        re0, re1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        re0.record()
+        run(r)
+        re1.record()
+        while not re1.query():
+            pass
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     run(K)
     ev1.record()
+    while not ev1.query():                               # poll rather than block in the driver
+        pass
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

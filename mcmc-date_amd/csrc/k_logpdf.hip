@@ -92,9 +92,9 @@ int wide_chain_tiles(int64_t batch)
 {
     static const int force = getenv("MCD_WIDE_CT") ? atoi(getenv("MCD_WIDE_CT")) : 0;
     if (force == 1 || force == 2 || force == 4) return force;
-    if (batch <= 256 * 16) return 1;
-    if (batch <= 256 * 64) return 2;
-    return 4;
+    // 16 chains per workgroup while that leaves every CU at most one workgroup; 32 above (two workgroups then share a CU:
+    // one stages while the other multiplies).  64 (MCD_WIDE_CT=4) measured slower at every size: its LDS chunk fills the CU.
+    return batch <= 256 * 16 ? 1 : 2;
 }
 
 static std::atomic<int> g_form{getenv("MCD_WIDE") ? (atoi(getenv("MCD_WIDE")) ? 2 : 1) : 0};   // MCD_FORM_*

@@ -14,14 +14,16 @@
 //     diagonal chunk); a super block walks the chunks 0 .. s, so the accumulators never outgrow 2 CT tiles per wave and
 //     N is not bounded by the register file;
 //   * the result layout of the f64 MFMA keeps a chain on lane & 15 in all four result registers, so the column sums of
-//     squares need no transposition: registers, two lane exchanges, then the 8 waves in a fixed order through LDS.
+//     squares need no transposition: registers, two lane exchanges, then the 8 waves in a fixed order through LDS;
+//   * with 16 or 32 chains per workgroup the kernel stays within 128 VGPRs and 68 KiB of LDS, so two workgroups share
+//     a CU: while one stages its chunk (a cold trip to HBM) the other keeps the matrix pipe busy.
 #include "wide_device.hpp"
 #include <atomic>
 
 namespace mcd {
 
 template <int CT, bool TREE>
-__global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int64_t batch, double* __restrict__ ll)
+__global__ void __launch_bounds__(64 * WD_WAVES, CT <= 2 ? 4 : 2) k_wide(MvnDev M, WideSrc A, int64_t batch, double* __restrict__ ll)
 {
     extern __shared__ double smem[];
     double* rs = smem;                                   // [CT * 16][WD_LD]
@@ -56,19 +58,7 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int
 
         for (int c = 0; c <= s; ++c) {
             const int ntA = bA >= 0 ? (c < s ? WD_SB / 4 : 4 * (bA + 1)) : 0;
-            const int ntB = bB >= 0 ? (c < s ? WD_SB / 4 : 4 * (bB + 1)) : 0;      // ntB >= ntA, both multiples of 4
-            const double* wA = Wt + ((bA >= 0 ? 2 * ibA * (ibA + 1) : 0) + (WD_SB / 4) * c) * 64 + lane;
-            const double* wB = Wt + ((bB >= 0 ? 2 * ibB * (ibB + 1) : 0) + (WD_SB / 4) * c) * 64 + lane;
-            // The ring slots are always refilled (index clamped to the last tile of the block, a valid address even for
-            // a wave without a block), so the loads carry no branch and the wait counts stay exact.  The first WD_P
-            // tiles are requested before the chunk is staged: their latency overlaps the staging loads.
-            const int lastA = ntA > 0 ? ntA - 1 : 0, lastB = ntB > 0 ? ntB - 1 : 0;
-            double ra[WD_P], rb[WD_P];
-#pragma unroll
-            for (int p = 0; p < WD_P; ++p) {
-                ra[p] = wA[(p < lastA ? p : lastA) * 64];
-                rb[p] = wB[(p < lastB ? p : lastB) * 64];
-            }
+            const int ntB = bB >= 0 ? (c < s ? WD_SB / 4 : 4 * (bB + 1)) : 0;
             WD_T(1);
             __syncthreads();
             wide_stage<CT, TREE>(rs, scs, M, A, b0, batch, c * WD_SB, tid);
@@ -78,50 +68,10 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide(MvnDev M, WideSrc A, int
             }
             __syncthreads();
             WD_T(3);
-            // four k tiles (slots h .. h + 3 of the ring) against both row blocks or the longer one only -- no branch
-            // inside, so the LDS reads of later tiles are scheduled under the MFMAs of earlier ones
-            auto quad = [&](int kt0, auto hsel, auto both, bool refill) {
-                constexpr int h = decltype(hsel)::value;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int kt = kt0 + p, nx = kt + WD_P;
-                    const double a = ra[h + p], b = rb[h + p];
-                    if (refill) {
-                        ra[h + p] = wA[(nx < lastA ? nx : lastA) * 64];
-                        rb[h + p] = wB[(nx < lastB ? nx : lastB) * 64];
-                    }
-                    double r[CT];
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) r[ct] = rs[(ct * 16 + col) * WD_LD + kt * 4 + kq];
-                    if constexpr (decltype(both)::value) {
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) accA[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, r[ct], accA[ct], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) accB[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, r[ct], accB[ct], 0, 0, 0);
-                }
-            };
-            using I0 = std::integral_constant<int, 0>;
-            using I4 = std::integral_constant<int, 4>;
-            int kt0 = 0;
-            for (; kt0 + WD_P <= ntB; kt0 += WD_P) {
-                if (kt0 + 8 <= ntA) {
-                    quad(kt0, I0{}, std::true_type{}, true);
-                    quad(kt0 + 4, I4{}, std::true_type{}, true);
-                } else if (kt0 >= ntA) {
-                    quad(kt0, I0{}, std::false_type{}, true);
-                    quad(kt0 + 4, I4{}, std::false_type{}, true);
-                } else {
-                    quad(kt0, I0{}, std::true_type{}, true);
-                    quad(kt0 + 4, I4{}, std::false_type{}, true);
-                }
-            }
-            if (kt0 < ntB) {                              // a half group is left; nothing more to request
-                if (kt0 < ntA)
-                    quad(kt0, I0{}, std::true_type{}, false);
-                else
-                    quad(kt0, I0{}, std::false_type{}, false);
-            }
+            // one row block after the other (wide_device.hpp): few registers, so that two workgroups share a CU and one
+            // stages its chunk while the other keeps the matrix pipe busy
+            wide_tri_pass<CT>(Wt + ((bA >= 0 ? 2 * ibA * (ibA + 1) : 0) + (WD_SB / 4) * c) * 64 + lane, ntA, 0, rs, col, kq, accA);
+            wide_tri_pass<CT>(Wt + ((bB >= 0 ? 2 * ibB * (ibB + 1) : 0) + (WD_SB / 4) * c) * 64 + lane, ntB, 0, rs, col, kq, accB);
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -173,7 +123,6 @@ static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, int64_t batch, do
 template <bool TREE>
 static hipError_t launch_wide(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, hipStream_t st)
 {
-    // chains per workgroup: as few as keep >= 256 workgroups in flight, so that all CUs take part
     const int ct = wide_chain_tiles(batch);
     if (ct == 1) return launch_ct<1, TREE>(M, A, batch, ll, st);
     if (ct == 2) return launch_ct<2, TREE>(M, A, batch, ll, st);
