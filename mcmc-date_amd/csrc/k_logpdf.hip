@@ -113,8 +113,8 @@ bool use_wide(const MvnDev& M, int64_t batch)
 
 bool use_wide_grad(const MvnDev& M, int64_t batch)
 {
-    // the multiply-form gradient keeps z and y in one LDS chunk: N <= 256
-    return M.Wtb != nullptr && M.n <= 256 && use_wide(M, batch);
+    // N <= 256: z and y stay in one LDS chunk (k_wide_grad.hip); above they pass through the output buffer (k_wide_grad_mc.hip)
+    return M.Wtb != nullptr && use_wide(M, batch);
 }
 
 int padded_blocks(int n)

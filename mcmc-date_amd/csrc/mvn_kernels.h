@@ -103,6 +103,10 @@ hipError_t launch_grad_wide(const MvnDev& M, const double* X, int64_t ldx, int64
 hipError_t launch_tree_grad_wide(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                  const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu,
                                  hipStream_t st);
+hipError_t launch_grad_wide_mc(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, hipStream_t st);
+hipError_t launch_tree_grad_wide_mc(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                    const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu,
+                                    hipStream_t st);
 bool use_wide_grad(const MvnDev& M, int64_t batch);
 int wide_chain_tiles(int64_t batch);
 bool use_wide(const MvnDev& M, int64_t batch);

@@ -338,9 +338,11 @@ def test_multiply_form_tree(gpu, multiply_form, leaves, batch):
     assert np.max(np.abs(ll_s - ll) / np.abs(ll)) <= 1e-12
 
 
-@pytest.mark.parametrize("n,batch", [(1, 3), (9, 5), (16, 17), (17, 100), (63, 7), (64, 64), (65, 33), (129, 17), (200, 64), (255, 1500), (256, 520)])
+@pytest.mark.parametrize("n,batch", [(1, 3), (9, 5), (16, 17), (17, 100), (63, 7), (64, 64), (65, 33), (129, 17), (200, 64), (255, 1500), (256, 520),
+                                     (257, 9), (272, 40), (500, 21), (513, 70), (768, 4200), (1024, 16)])
 def test_multiply_form_gradient(gpu, multiply_form, n, batch):
-    """ll and d ll / d x through the two triangular MFMA products (N <= 256), against the oracle and the sweeps."""
+    """ll and d ll / d x through the two triangular MFMA products, against the oracle and the sweeps: N <= 256 with z and y
+    in one LDS chunk, above through the gradient buffer itself (several chunks, partial super blocks, ragged tiles)."""
     import torch
 
     mu, sigma = S.random_spd_problem(n, seed=n)
@@ -356,6 +358,14 @@ def test_multiply_form_gradient(gpu, multiply_form, n, batch):
     assert np.max(np.abs(G - Gref)) <= gtol, (np.max(np.abs(G - Gref)), gtol)
     ll_d, G_d = lik.grad(torch.as_tensor(X, device=gpu))
     assert np.array_equal(ll_d.cpu().numpy(), ll) and np.array_equal(G_d.cpu().numpy(), G)
+    # padded gradient rows: the padding is never written (the rows double as scratch for z above 256)
+    ldg = n + 5
+    Gp = torch.full((batch, ldg), -7.0, dtype=torch.float64, device=gpu)
+    llp = torch.empty(batch, dtype=torch.float64, device=gpu)
+    Xd = torch.as_tensor(X, device=gpu)
+    M._capi.check(M._capi.lib().mcd_mvn_grad_batch(lik._h, Xd.data_ptr(), n, batch, 1, None, llp.data_ptr(), Gp.data_ptr(), ldg))
+    torch.cuda.synchronize()
+    assert np.array_equal(Gp[:, :n].cpu().numpy(), G) and bool((Gp[:, n:] == -7.0).all())
     M.set_logpdf_form("sweep")
     ll_s, G_s = lik.grad(X)
     M.set_logpdf_form("multiply")
@@ -365,9 +375,10 @@ def test_multiply_form_gradient(gpu, multiply_form, n, batch):
         assert np.all(G0 == 0.0)
 
 
-@pytest.mark.parametrize("leaves,batch", [(3, 5), (4, 33), (12, 40), (50, 333), (100, 70), (129, 96)])
+@pytest.mark.parametrize("leaves,batch", [(3, 5), (4, 33), (12, 40), (50, 333), (100, 70), (129, 96), (130, 37), (140, 50), (300, 2100), (513, 20)])
 def test_multiply_form_tree_gradient(gpu, multiply_form, leaves, batch):
-    """Chain rule to heights, rates, tH, rMu on the LDS copy of g: oracle values per chain, sweep values for all."""
+    """Chain rule to heights, rates, tH, rMu on the LDS copy of g (N <= 256) or in sub-batches of chains with g parked in the
+    height-gradient rows (above): oracle values per chain, sweep values for all."""
     topo = S.random_topology(leaves, seed=leaves)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=leaves)
