@@ -200,7 +200,7 @@ def main():
     gathered = torch.empty(world * B, dtype=torch.float64, device=ctl_dev) if (world > 1 and args.swap_period > 0) else None
     # which form the launch takes (mirror of use_wide / use_wide_grad in csrc/k_logpdf.hip)
     has_grad = args.kind in ("grad", "tree_grad")
-    if args.kind == "prior" or (has_grad and n > 256):
+    if args.kind == "prior":
         form = "sweep"
     elif args.form != "auto":
         form = args.form
