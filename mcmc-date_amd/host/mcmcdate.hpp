@@ -96,6 +96,17 @@ struct MvnDeleter { void operator()(mcd_mvn_t* p) const { mcd_mvn_destroy(p); } 
 struct TreeDeleter { void operator()(mcd_tree_t* p) const { mcd_tree_destroy(p); } };
 }  // namespace detail
 
+// Kernel form of the log-density entry points: column sweep (latency form), matrix-core multiply (throughput form), or
+// by dimension and batch size (default).  No counterpart in the reference (one CPU code path); returns the previous form.
+enum class LogpdfForm : int { Auto = MCD_FORM_AUTO, Sweep = MCD_FORM_SWEEP, Multiply = MCD_FORM_MULTIPLY };
+inline LogpdfForm setLogpdfForm(LogpdfForm f)
+{
+    const int prev = mcd_set_logpdf_form((int)f);
+    if (prev < 0) detail::check(prev);
+    return (LogpdfForm)prev;
+}
+
+
 // The closure built by getLikelihoodFunction (app/Main.hs:333-347): operands staged once on a GPU.
 class Likelihood {
 public:

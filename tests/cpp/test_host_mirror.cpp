@@ -117,6 +117,11 @@ int main(int argc, char** argv)
         std::printf("ll=%.17g ref=%.17g lj=%.17g ref=%.17g d0=%.6g\n", ll, ll_ref, lj, lj_ref, d[0]);
         if (std::fabs(ll - ll_ref) > 1e-10 * std::fmax(1.0, std::fabs(ll_ref))) return 1;
         if (std::fabs(lj - lj_ref) > 1e-12 * std::fmax(1.0, std::fabs(lj_ref))) return 1;
+        // the same state through the matrix-core multiply form: same value to rounding, same Jacobian bits
+        if (mcmcdate::setLogpdfForm(mcmcdate::LogpdfForm::Multiply) != mcmcdate::LogpdfForm::Auto) return 1;
+        const double ll_m = fn(x), lj_m = lik.jacobianRootBranch(x);
+        if (mcmcdate::setLogpdfForm(mcmcdate::LogpdfForm::Auto) != mcmcdate::LogpdfForm::Multiply) return 1;
+        if (std::fabs(ll_m - ll_ref) > 1e-10 * std::fmax(1.0, std::fabs(ll_ref)) || lj_m != lj) return 1;
         // structural fault: trifurcating root -> exception with the reference's message
         mcmcdate::Topology bad;
         bad.parent = {-1, 0, 0, 0};
