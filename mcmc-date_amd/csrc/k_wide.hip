@@ -102,11 +102,13 @@ __global__ void __launch_bounds__(64 * WD_WAVES, CT <= 2 ? 4 : 2) k_wide(MvnDev 
     WD_T(5);
 }
 
+// More than 64 KiB of dynamic LDS has to be allowed once per kernel and device (a process may hold handles on several
+// GPUs).  mcd_mvn_create does it for every instantiation (prepare_wide), so that a first launch under stream capture needs no
+// attribute call; the launchers check again.
 template <int CT, bool TREE>
-static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, hipStream_t st)
+static hipError_t allow_lds()
 {
     constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16) * sizeof(double);
-    // more than 64 KiB of dynamic LDS has to be allowed once per device (a process may hold handles on several GPUs)
     static std::atomic<bool> allowed[64];
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;
@@ -115,6 +117,14 @@ static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, int64_t batch, do
         if (hipError_t e = hipFuncSetAttribute((const void*)k_wide<CT, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)) return e;
         allowed[dev].store(true, std::memory_order_release);
     }
+    return hipSuccess;
+}
+
+template <int CT, bool TREE>
+static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, hipStream_t st)
+{
+    constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16) * sizeof(double);
+    if (hipError_t e = allow_lds<CT, TREE>()) return e;
     const unsigned grid = (unsigned)((batch + CT * 16 - 1) / (CT * 16));
     hipLaunchKernelGGL((k_wide<CT, TREE>), dim3(grid), dim3(64 * WD_WAVES), bytes, st, M, A, batch, ll);
     return hipGetLastError();
@@ -153,6 +163,17 @@ hipError_t launch_tree_logpdf_wide(const MvnDev& M, const TreeDev& T, const doub
     A.rMu = rMu;
     A.logjac = logjac;
     return launch_wide<true>(M, A, batch, ll, st);
+}
+
+hipError_t prepare_wide()
+{
+    if (hipError_t e = allow_lds<1, false>()) return e;
+    if (hipError_t e = allow_lds<1, true>()) return e;
+    if (hipError_t e = allow_lds<2, false>()) return e;
+    if (hipError_t e = allow_lds<2, true>()) return e;
+    if (hipError_t e = allow_lds<4, false>()) return e;
+    if (hipError_t e = allow_lds<4, true>()) return e;
+    return hipSuccess;
 }
 
 }  // namespace mcd

@@ -220,11 +220,13 @@ __global__ void __launch_bounds__(64 * WD_WAVES) k_wide_grad(MvnDev M, WideSrc A
     WD_T(9);
 }
 
+// More than 64 KiB of dynamic LDS has to be allowed once per kernel and device (a process may hold handles on several
+// GPUs).  mcd_mvn_create does it for every instantiation (prepare_wide_grad), so that a first launch under stream capture needs no
+// attribute call; the launchers check again.
 template <int CT, bool TREE>
-static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, const WideGradOut& O, int64_t batch, hipStream_t st)
+static hipError_t allow_lds()
 {
     constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16 + CT * 16 * 5) * sizeof(double);
-    // more than 64 KiB of dynamic LDS has to be allowed once per device (a process may hold handles on several GPUs)
     static std::atomic<bool> allowed[64];
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;
@@ -233,6 +235,14 @@ static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, const WideGradOut
         if (hipError_t e = hipFuncSetAttribute((const void*)k_wide_grad<CT, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)) return e;
         allowed[dev].store(true, std::memory_order_release);
     }
+    return hipSuccess;
+}
+
+template <int CT, bool TREE>
+static hipError_t launch_ct(const MvnDev& M, const WideSrc& A, const WideGradOut& O, int64_t batch, hipStream_t st)
+{
+    constexpr size_t bytes = (size_t)(CT * 16 * WD_LD + WD_WAVES * CT * 16 + CT * 16 + CT * 16 * 5) * sizeof(double);
+    if (hipError_t e = allow_lds<CT, TREE>()) return e;
     const unsigned grid = (unsigned)((batch + CT * 16 - 1) / (CT * 16));
     hipLaunchKernelGGL((k_wide_grad<CT, TREE>), dim3(grid), dim3(64 * WD_WAVES), bytes, st, M, A, O, batch);
     return hipGetLastError();
@@ -280,6 +290,15 @@ hipError_t launch_tree_grad_wide(const MvnDev& M, const TreeDev& T, const double
     O.gtH = gtH;
     O.grMu = grMu;
     return launch_wide<true>(M, A, O, batch, st);
+}
+
+hipError_t prepare_wide_grad()
+{
+    if (hipError_t e = allow_lds<1, false>()) return e;
+    if (hipError_t e = allow_lds<1, true>()) return e;
+    if (hipError_t e = allow_lds<2, false>()) return e;
+    if (hipError_t e = allow_lds<2, true>()) return e;
+    return hipSuccess;
 }
 
 }  // namespace mcd

@@ -278,6 +278,9 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
         HIP_TRY(hipMemcpy(h->d_Wtb, Wtb.data(), Wtb.size() * sizeof(double), hipMemcpyHostToDevice));
         h->dev.Wt = h->d_Wt;
         h->dev.Wtb = h->d_Wtb;
+        HIP_TRY(mcd::prepare_wide());
+        HIP_TRY(mcd::prepare_wide_grad());
+        HIP_TRY(mcd::prepare_wide_grad_mc());
     }
     *out = h.release();
     return MCD_OK;

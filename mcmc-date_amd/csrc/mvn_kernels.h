@@ -107,6 +107,9 @@ hipError_t launch_grad_wide_mc(const MvnDev& M, const double* X, int64_t ldx, in
 hipError_t launch_tree_grad_wide_mc(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                     const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu,
                                     hipStream_t st);
+hipError_t prepare_wide();            // per-device attribute set-up of the multiply-form kernels (current device)
+hipError_t prepare_wide_grad();
+hipError_t prepare_wide_grad_mc();
 bool use_wide_grad(const MvnDev& M, int64_t batch);
 int wide_chain_tiles(int64_t batch);
 bool use_wide(const MvnDev& M, int64_t batch);

@@ -405,6 +405,32 @@ def test_multiply_form_tree_gradient(gpu, multiply_form, leaves, batch):
     assert np.max(np.abs(sw[3] - out[3]) / np.abs(sw[3])) <= 1e-9 and np.max(np.abs(sw[4] - out[4]) / np.abs(sw[4])) <= 1e-9
 
 
+def test_multiply_form_first_launch_under_capture(gpu):
+    """The large dynamic LDS of the multiply-form kernels is allowed when the handle is created, so the very first launch
+    may already sit inside a stream capture (a sampler that replays its step from a hipGraph)."""
+    import torch
+
+    n, batch = 144, 4100
+    mu, sigma = S.random_spd_problem(n, seed=21)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma)
+    X = torch.as_tensor(S.sample_chains(mu, sigma, batch, seed=21), device=gpu)
+    out = torch.zeros(batch, dtype=torch.float64, device=gpu)
+    G = torch.zeros_like(X)
+    ll2 = torch.zeros_like(out)
+    L = M._capi.lib()
+    stream = torch.cuda.Stream(device=gpu)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        lik.logpdf_into(X, out)
+        M._capi.check(L.mcd_mvn_grad_batch(lik._h, X.data_ptr(), X.stride(0), batch, 1, torch.cuda.current_stream().cuda_stream,
+                                           ll2.data_ptr(), G.data_ptr(), G.stride(0)))
+    g.replay()
+    torch.cuda.synchronize()
+    ref_ll, ref_G = lik.grad(X)
+    assert torch.equal(out, ref_ll) and torch.equal(ll2, ref_ll) and torch.equal(G, ref_G)
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
+
+
 def test_form_selection(gpu):
     """auto = sweep for a sampler's usual batch, multiply for thousands of chains of a large tree; unknown values are
     refused; non-finite inputs flow through the multiply form as through the sweep."""
