@@ -405,6 +405,46 @@ def test_multiply_form_tree_gradient(gpu, multiply_form, leaves, batch):
     assert np.max(np.abs(sw[3] - out[3]) / np.abs(sw[3])) <= 1e-9 and np.max(np.abs(sw[4] - out[4]) / np.abs(sw[4])) <= 1e-9
 
 
+def test_multiply_form_random_shapes(gpu, multiply_form):
+    """Seeded random dimensions and batch sizes (partial row blocks, partial super blocks, ragged chain tiles) for ll and
+    gradient, raw x and tree states, against the column sweeps chain by chain."""
+    rng = np.random.default_rng(20251003)
+    for case in range(36):
+        n = int(rng.integers(1, 1025)) if case % 3 else int(rng.choice([15, 16, 17, 31, 240, 241, 255, 256, 257, 271, 272, 273, 511, 512, 513, 1023, 1024]))
+        batch = int(rng.integers(1, 200))
+        mu, sigma = S.random_spd_problem(n, seed=1000 + case)
+        X = S.sample_chains(mu, sigma, batch, seed=case)
+        lik = M.MvnLikelihood.from_covariance(mu, sigma)
+        ll, G = lik.grad(X)
+        ll1 = lik.logpdf(X)
+        M.set_logpdf_form("sweep")
+        ll_s, G_s = lik.grad(X)
+        M.set_logpdf_form("multiply")
+        kappa = np.linalg.cond(sigma)
+        assert np.array_equal(ll, ll1), (n, batch)
+        assert np.max(rel_err(ll, ll_s)) <= 64 * n * EPS * kappa, (n, batch, np.max(rel_err(ll, ll_s)))
+        assert np.max(np.abs(G - G_s)) <= 256 * n * EPS * kappa * np.abs(G_s).max(), (n, batch)
+    for case in range(14):
+        leaves = int(rng.integers(3, 514))
+        batch = int(rng.integers(1, 120))
+        topo = S.random_topology(leaves, seed=case)
+        n = topo.n_nodes - 2
+        mu, sigma = S.random_spd_problem(n, seed=2000 + case)
+        st = S.random_states(topo, batch, seed=case)
+        tl = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+        out = tl.grad(st)
+        ll1, lj1 = tl.loglik(st)
+        M.set_logpdf_form("sweep")
+        sw = tl.grad(st)
+        ll_s, lj_s = tl.loglik(st)
+        M.set_logpdf_form("multiply")
+        assert np.array_equal(out[0], ll1) and np.array_equal(lj1, lj_s), (leaves, batch)
+        assert np.max(np.abs(ll1 - ll_s) / np.abs(ll_s)) <= 1e-11, (leaves, batch)
+        sc = max(np.abs(sw[1]).max(), np.abs(sw[2]).max())
+        assert np.max(np.abs(sw[1] - out[1])) <= 1e-9 * sc and np.max(np.abs(sw[2] - out[2])) <= 1e-9 * sc, (leaves, batch)
+        assert np.max(np.abs(sw[3] - out[3]) / np.abs(sw[3])) <= 1e-8 and np.max(np.abs(sw[4] - out[4]) / np.abs(sw[4])) <= 1e-8, (leaves, batch)
+
+
 def test_multiply_form_first_launch_under_capture(gpu):
     """The large dynamic LDS of the multiply-form kernels is allowed when the handle is created, so the very first launch
     may already sit inside a stream capture (a sampler that replays its step from a hipGraph)."""
