@@ -118,9 +118,9 @@ int main(int argc, char** argv)
         if (std::fabs(ll - ll_ref) > 1e-10 * std::fmax(1.0, std::fabs(ll_ref))) return 1;
         if (std::fabs(lj - lj_ref) > 1e-12 * std::fmax(1.0, std::fabs(lj_ref))) return 1;
         // the same state through the matrix-core multiply form: same value to rounding, same Jacobian bits
-        if (mcmcdate::setLogpdfForm(mcmcdate::LogpdfForm::Multiply) != mcmcdate::LogpdfForm::Auto) return 1;
+        const mcmcdate::LogpdfForm before = mcmcdate::setLogpdfForm(mcmcdate::LogpdfForm::Multiply);   // (MCD_WIDE may preset it)
         const double ll_m = fn(x), lj_m = lik.jacobianRootBranch(x);
-        if (mcmcdate::setLogpdfForm(mcmcdate::LogpdfForm::Auto) != mcmcdate::LogpdfForm::Multiply) return 1;
+        if (mcmcdate::setLogpdfForm(before) != mcmcdate::LogpdfForm::Multiply) return 1;
         if (std::fabs(ll_m - ll_ref) > 1e-10 * std::fmax(1.0, std::fabs(ll_ref)) || lj_m != lj) return 1;
         // structural fault: trifurcating root -> exception with the reference's message
         mcmcdate::Topology bad;
