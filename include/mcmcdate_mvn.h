@@ -65,7 +65,8 @@ const char* mcd_last_error(void);
  *   MCD_FORM_MULTIPLY always the multiply form z = L^-1 (x - mu) on the fp64 matrix cores (the throughput form).
  * The environment variable MCD_WIDE=0|1 sets the initial value to SWEEP | MULTIPLY.  Returns the previous value.
  * The gradient entry points follow the same choice; above N = 256 the multiply form uses the gradient rows (`G`, `g_heights`)
- * as scratch while it runs, so they must not alias an input.
+ * as scratch while it runs: a call whose gradient array IS an input array (in place) takes the sweeps instead; partially
+ * overlapping arrays are not supported by either form.
  */
 #define MCD_FORM_AUTO 0
 #define MCD_FORM_SWEEP 1

@@ -93,8 +93,12 @@ hipError_t launch_grad(const MvnDev& M, const double* X, int64_t ldx, int64_t ba
                        hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
-    if (use_wide_grad(M, batch))
-        return M.n <= 256 ? launch_grad_wide(M, X, ldx, batch, ll, G, ldg, st) : launch_grad_wide_mc(M, X, ldx, batch, ll, G, ldg, st);
+    if (use_wide_grad(M, batch)) {
+        if (M.n <= 256) return launch_grad_wide(M, X, ldx, batch, ll, G, ldg, st);
+        // above 256 the gradient rows double as scratch for z: an in-place call (G == X) keeps the sweep, which reads a chain's
+        // x completely before it writes
+        if ((const double*)G != X) return launch_grad_wide_mc(M, X, ldx, batch, ll, G, ldg, st);
+    }
     if (M.R == 6 || M.R == 8) return launch_grad_g1(M, X, ldx, batch, ll, G, ldg, st);
     if (M.R == 12) return launch_grad_g2(M, X, ldx, batch, ll, G, ldg, st);
     if (M.R == 16) return launch_grad_g3(M, X, ldx, batch, ll, G, ldg, st);

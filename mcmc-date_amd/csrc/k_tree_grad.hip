@@ -138,9 +138,11 @@ hipError_t launch_tree_grad(const MvnDev& M, const TreeDev& T, const double* H, 
                             double* gtH, double* grMu, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
-    if (use_wide_grad(M, batch))
-        return M.n <= 256 ? launch_tree_grad_wide(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st)
-                          : launch_tree_grad_wide_mc(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
+    if (use_wide_grad(M, batch)) {
+        if (M.n <= 256) return launch_tree_grad_wide(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
+        if ((const double*)gH != H && (const double*)gH != Rt)      // (the height-gradient rows double as scratch above 256)
+            return launch_tree_grad_wide_mc(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
+    }
     if (M.R == 6 || M.R == 8) return launch_tree_grad_g1(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
     if (M.R == 12) return launch_tree_grad_g2(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
     if (M.R == 16) return launch_tree_grad_g3(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);

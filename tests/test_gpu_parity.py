@@ -445,6 +445,24 @@ def test_multiply_form_random_shapes(gpu, multiply_form):
         assert np.max(np.abs(sw[3] - out[3]) / np.abs(sw[3])) <= 1e-8 and np.max(np.abs(sw[4] - out[4]) / np.abs(sw[4])) <= 1e-8, (leaves, batch)
 
 
+def test_in_place_gradient(gpu, multiply_form):
+    """G may be the very array that holds x (a chain's x is read before its gradient is written): the multiply form up to
+    N = 256 allows it, above that the call falls back to the sweep, which does as well."""
+    import torch
+
+    for n, batch in ((200, 300), (300, 70)):
+        mu, sigma = S.random_spd_problem(n, seed=n)
+        X = S.sample_chains(mu, sigma, batch, seed=n)
+        lik = M.MvnLikelihood.from_covariance(mu, sigma)
+        ll, G = lik.grad(X)
+        Xd = torch.as_tensor(X, device=gpu).clone()
+        out = torch.empty(batch, dtype=torch.float64, device=gpu)
+        M._capi.check(M._capi.lib().mcd_mvn_grad_batch(lik._h, Xd.data_ptr(), n, batch, 1, None, out.data_ptr(), Xd.data_ptr(), n))
+        torch.cuda.synchronize()
+        assert np.max(rel_err(out.cpu().numpy(), ll)) <= 1e-12
+        assert np.max(np.abs(Xd.cpu().numpy() - G)) <= 1e-10 * np.abs(G).max()
+
+
 def test_multiply_form_first_launch_under_capture(gpu):
     """The large dynamic LDS of the multiply-form kernels is allowed when the handle is created, so the very first launch
     may already sit inside a stream capture (a sampler that replays its step from a hipGraph)."""
