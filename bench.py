@@ -206,11 +206,13 @@ def main():
         form = args.form
     else:
         form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
+        if args.kind == "logpdf" and 192 < n <= 256 and 64 <= B <= 1024:
+            form = "split"                               # k_split.hip: W's row blocks over 8 workgroups per chain tile
     # hipGraph replay hides the per-launch dispatch cost of the few-microsecond sweep launches; the multiply form's launches
     # are longer than an eager dispatch and are launched eagerly.  (On this pool about one run in twenty sees the host learn
     # of the completion ~60 ms late -- graph or eager, blocking wait or polling, HSA_ENABLE_INTERRUPT=0 or not -- while the HIP
     # events of the same run agree with the kernel trace; the default run is long enough that such an outlier costs < 10 %.)
-    use_graph = (not args.no_graph) and gathered is None and form == "sweep"
+    use_graph = (not args.no_graph) and gathered is None and form in ("sweep", "split")
     K, W = args.steps, args.warmup
 
     # --- build the launch schedule -----------------------------------------------------------
@@ -321,7 +323,7 @@ def main():
                                        else f"chains sharded x{world} + ll all-gather every {args.swap_period} steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic() if (n == 256 and B == 512 and args.kind == "logpdf" and form == "sweep") else None,
+                         "traffic": measured_traffic() if (n == 256 and B == 512 and args.kind == "logpdf" and form == "split") else None,
                          "kernel_us_per_launch": per_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_b,
                          "fp64_tflops": flops, "fp64_frac": flops / FP64_PEAK_TFLOPS},

@@ -111,6 +111,13 @@ bool use_wide(const MvnDev& M, int64_t batch)
     return (M.n >= 96 && batch >= 2048) || (M.n >= 32 && batch >= 8192);
 }
 
+bool use_split(const MvnDev& M, int64_t batch)
+{
+    // measured window (tools/microbench/split/README.md): with four 64-row blocks in the sweep the split wins for every batch
+    // up to 1024 chains; at N <= 192 the sweep's shorter dependent chain wins; from 2048 chains k_wide takes over
+    return g_form.load(std::memory_order_relaxed) == 0 && M.Wt != nullptr && M.n > 192 && M.n <= 256 && batch >= 64 && batch <= kSplitMaxBatch;
+}
+
 bool use_wide_grad(const MvnDev& M, int64_t batch)
 {
     // N <= 256: z and y stay in one LDS chunk (k_wide_grad.hip); above they pass through the output buffer (k_wide_grad_mc.hip)

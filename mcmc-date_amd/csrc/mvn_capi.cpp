@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -135,6 +136,13 @@ struct mcd_mvn {
     double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr, *d_Wt = nullptr, *d_Wtb = nullptr;
     std::vector<double> L;  // host copy of the factor (row-major lower)
     mutable WorkspacePool pool;
+    // k_split.hip: partial sums and tile counters of a launch in flight, one set per stream this handle is used on
+    struct SplitScratch {
+        double* partials = nullptr;
+        unsigned* counters = nullptr;
+    };
+    mutable std::mutex split_mu;
+    mutable std::map<hipStream_t, SplitScratch> split;
 
     ~mcd_mvn()
     {
@@ -145,6 +153,10 @@ struct mcd_mvn {
         if (d_Ft) (void)hipFree(d_Ft);
         if (d_Ut) (void)hipFree(d_Ut);
         if (d_Wt) (void)hipFree(d_Wt);
+        for (auto& kv : split) {
+            if (kv.second.partials) (void)hipFree(kv.second.partials);
+            if (kv.second.counters) (void)hipFree(kv.second.counters);
+        }
         if (d_Wtb) (void)hipFree(d_Wtb);
     }
 };
@@ -305,6 +317,34 @@ int mcd_mvn_get_factor(const mcd_mvn_t* h, double* L_out)
     return MCD_OK;
 }
 
+// One batched log-density launch on `st`: the row-split kernel inside its window (it needs the per-stream scratch of this
+// handle, created on first use -- outside any stream capture), otherwise the sweep / k_wide choice of launch_logpdf.
+static int launch_logpdf_any(const mcd_mvn* h, const double* X, int64_t ld, int64_t batch, double* ll, hipStream_t st)
+{
+    if (!mcd::use_split(h->dev, batch)) {
+        HIP_TRY(mcd::launch_logpdf(h->dev, X, ld, batch, ll, st));
+        return MCD_OK;
+    }
+    mcd_mvn::SplitScratch s;
+    {
+        std::lock_guard<std::mutex> lock(h->split_mu);
+        auto it = h->split.find(st);
+        if (it == h->split.end()) {
+            mcd_mvn::SplitScratch fresh;
+            HIP_TRY(hipMalloc((void**)&fresh.partials, mcd::kSplitScratchDoubles * sizeof(double)));
+            if (hipError_t e = hipMalloc((void**)&fresh.counters, mcd::kSplitCounters * sizeof(unsigned))) {
+                (void)hipFree(fresh.partials);
+                HIP_TRY(e);
+            }
+            HIP_TRY(hipMemset(fresh.counters, 0, mcd::kSplitCounters * sizeof(unsigned)));   // (synchronous: ordered before any launch)
+            it = h->split.emplace(st, fresh).first;
+        }
+        s = it->second;
+    }
+    HIP_TRY(mcd::launch_logpdf_split(h->dev, X, ld, batch, ll, s.partials, s.counters, st));
+    return MCD_OK;
+}
+
 int mcd_mvn_logpdf_batch(const mcd_mvn_t* h, const double* X, int64_t ld, int64_t batch, int on_device, void* stream,
                          double* ll)
 {
@@ -314,7 +354,7 @@ int mcd_mvn_logpdf_batch(const mcd_mvn_t* h, const double* X, int64_t ld, int64_
     if (!X || !ll) return fail(MCD_ERR_INVALID_ARG, "mcd_mvn_logpdf_batch: NULL data pointer");
     HIP_TRY(hipSetDevice(h->device));
     if (on_device) {
-        HIP_TRY(mcd::launch_logpdf(h->dev, X, ld, batch, ll, (hipStream_t)stream));
+        if (int rc = launch_logpdf_any(h, X, ld, batch, ll, (hipStream_t)stream)) return rc;
         return MCD_OK;
     }
     WsGuard g{&h->pool, h->pool.acquire()};
@@ -324,7 +364,7 @@ int mcd_mvn_logpdf_batch(const mcd_mvn_t* h, const double* X, int64_t ld, int64_
         if (int rc = ensure_mapped(g.w, nx + (size_t)batch)) return rc;
         double* hX = g.w->hbuf;
         for (int64_t b = 0; b < batch; ++b) memcpy(hX + (size_t)b * h->n, X + (size_t)b * ld, sizeof(double) * (size_t)h->n);
-        HIP_TRY(mcd::launch_logpdf(h->dev, g.w->hbuf_dev, h->n, batch, g.w->hbuf_dev + nx, g.w->stream));
+        if (int rc = launch_logpdf_any(h, g.w->hbuf_dev, h->n, batch, g.w->hbuf_dev + nx, g.w->stream)) return rc;
         HIP_TRY(hipStreamSynchronize(g.w->stream));
         memcpy(ll, hX + nx, sizeof(double) * (size_t)batch);
         return MCD_OK;
@@ -334,7 +374,7 @@ int mcd_mvn_logpdf_batch(const mcd_mvn_t* h, const double* X, int64_t ld, int64_
     double* dll = dX + nx;
     HIP_TRY(hipMemcpy2DAsync(dX, sizeof(double) * h->n, X, sizeof(double) * ld, sizeof(double) * h->n, (size_t)batch,
                              hipMemcpyHostToDevice, g.w->stream));
-    HIP_TRY(mcd::launch_logpdf(h->dev, dX, h->n, batch, dll, g.w->stream));
+    if (int rc = launch_logpdf_any(h, dX, h->n, batch, dll, g.w->stream)) return rc;
     HIP_TRY(hipMemcpyAsync(ll, dll, sizeof(double) * (size_t)batch, hipMemcpyDeviceToHost, g.w->stream));
     HIP_TRY(hipStreamSynchronize(g.w->stream));
     return MCD_OK;
