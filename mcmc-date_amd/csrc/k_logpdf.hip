@@ -114,8 +114,9 @@ bool use_wide(const MvnDev& M, int64_t batch)
 bool use_split(const MvnDev& M, int64_t batch)
 {
     // measured window (tools/microbench/split/README.md): with four 64-row blocks in the sweep the split wins for every batch
-    // up to 1024 chains; at N <= 192 the sweep's shorter dependent chain wins; from 2048 chains k_wide takes over
-    return g_form.load(std::memory_order_relaxed) == 0 && M.Wt != nullptr && M.n > 192 && M.n <= 256 && batch >= 64 && batch <= kSplitMaxBatch;
+    // from 1 to 1024 chains (4.7 us against 7.0 us for a single chain); at N <= 192 the sweep's shorter dependent chain wins;
+    // from 2048 chains k_wide takes over
+    return g_form.load(std::memory_order_relaxed) == 0 && M.Wt != nullptr && M.n > 192 && M.n <= 256 && batch >= 1 && batch <= kSplitMaxBatch;
 }
 
 bool use_wide_grad(const MvnDev& M, int64_t batch)

@@ -1,4 +1,4 @@
-// k_split.hip -- log-density for a sampler's usual batch (<= 1024 chains) at 192 < N <= 256: the multiply form with the
+// k_split.hip -- log-density for a sampler's usual batch (1 .. 1024 chains) at 192 < N <= 256: the multiply form with the
 // row blocks of W = L^-1 split over 8 workgroups per 16-chain tile (gfx950).  tools/microbench/split/README.md has the
 // measurements that led here.
 //
