@@ -206,7 +206,7 @@ def main():
         form = args.form
     else:
         form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
-        if args.kind == "logpdf" and 192 < n <= 256 and B <= 1024:
+        if args.kind == "logpdf" and ((192 < n <= 256 and B <= 1024) or (128 < n <= 192 and B <= 128)):
             form = "split"                               # k_split.hip: W's row blocks over 8 workgroups per chain tile
     # hipGraph replay hides the per-launch dispatch cost of the few-microsecond sweep launches; the multiply form's launches
     # are longer than an eager dispatch and are launched eagerly.  (On this pool about one run in twenty sees the host learn

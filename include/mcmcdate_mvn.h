@@ -61,7 +61,7 @@ const char* mcd_last_error(void);
 /*
  * Which of the two forms of the log-density kernels a launch uses (process wide; results agree to rounding):
  *   MCD_FORM_AUTO     (default) by dimension and batch size (multiply from 2048 chains at N >= 96, from 8192 at N >= 32;
- *                     for 192 < N <= 256 and up to 1024 chains mcd_mvn_logpdf[_batch] uses a row-split variant of the multiply
+ *                     for 192 < N <= 256 and up to 1024 chains (128 < N <= 192: up to 128) mcd_mvn_logpdf[_batch] uses a row-split variant of the multiply
  *                     form, whose per-stream scratch is created on the first such call of a stream -- not under capture);
  *   MCD_FORM_SWEEP    always the column sweep (one chain per wave -- the latency form);
  *   MCD_FORM_MULTIPLY always the multiply form z = L^-1 (x - mu) on the fp64 matrix cores (the throughput form).

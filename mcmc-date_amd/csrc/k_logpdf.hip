@@ -115,8 +115,11 @@ bool use_split(const MvnDev& M, int64_t batch)
 {
     // measured window (tools/microbench/split/README.md): with four 64-row blocks in the sweep the split wins for every batch
     // from 1 to 1024 chains (4.7 us against 7.0 us for a single chain); at N <= 192 the sweep's shorter dependent chain wins;
-    // from 2048 chains k_wide takes over
-    return g_form.load(std::memory_order_relaxed) == 0 && M.Wt != nullptr && M.n > 192 && M.n <= 256 && batch >= 1 && batch <= kSplitMaxBatch;
+    // from 2048 chains k_wide takes over.  128 < N <= 192: 3.9-5.0 us against 4.8-5.6 us up to 128 chains, the sweep from 256;
+    // N <= 128: the sweep (3.1-3.7 us against 3.9-4.7 us)
+    if (g_form.load(std::memory_order_relaxed) != 0 || M.Wt == nullptr || batch < 1) return false;
+    if (M.n > 192 && M.n <= 256) return batch <= kSplitMaxBatch;
+    return M.n > 128 && M.n <= 192 && batch <= 128;       // three 64-row blocks in the sweep: the split only wins while few CUs are busy
 }
 
 bool use_wide_grad(const MvnDev& M, int64_t batch)

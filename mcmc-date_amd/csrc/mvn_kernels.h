@@ -107,7 +107,7 @@ hipError_t launch_grad_wide_mc(const MvnDev& M, const double* X, int64_t ldx, in
 hipError_t launch_tree_grad_wide_mc(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                     const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu,
                                     hipStream_t st);
-// Row blocks of W split over 8 workgroups per chain tile (k_split.hip): 192 < N <= 256, up to 1024 chains, automatic form only.
+// Row blocks of W split over 8 workgroups per chain tile (k_split.hip): 192 < N <= 256 up to 1024 chains, 128 < N <= 192 up to 128 chains, automatic form only.
 // scratch: kSplitScratchDoubles doubles, counter: kSplitCounters zero-initialised unsigned, both owned by the call's stream.
 constexpr int64_t kSplitMaxBatch = 1024;
 constexpr size_t kSplitScratchDoubles = (kSplitMaxBatch / 16) * 8 * 16;

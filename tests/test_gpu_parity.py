@@ -160,7 +160,7 @@ def test_synthetic_logpdf_and_grad(gpu, n, batch):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ll)
     ll2, G = lik.grad(X)
-    if 192 < n <= 256 and batch <= 1024:
+    if (192 < n <= 256 and batch <= 1024) or (128 < n <= 192 and batch <= 128):
         assert np.all(np.abs(ll2 - ll) <= tol)               # log-density: row-split kernel (k_split.hip); gradient: sweeps
     else:
         assert np.array_equal(ll2, ll)
@@ -169,9 +169,9 @@ def test_synthetic_logpdf_and_grad(gpu, n, batch):
     assert np.max(np.abs(G - Gref)) <= gtol, (np.max(np.abs(G - Gref)), gtol)
 
 
-@pytest.mark.parametrize("n,batch", [(193, 64), (200, 65), (224, 130), (255, 1000), (256, 512), (256, 1024), (241, 77), (256, 1), (230, 5), (199, 17)])
+@pytest.mark.parametrize("n,batch", [(193, 64), (200, 65), (224, 130), (255, 1000), (256, 512), (256, 1024), (241, 77), (256, 1), (230, 5), (199, 17), (129, 1), (160, 100), (192, 128)])
 def test_row_split_form(gpu, n, batch):
-    """192 < N <= 256 with up to 1024 chains: W's row blocks split over 8 workgroups per chain tile, partial sums added by
+    """192 < N <= 256 with up to 1024 chains (128 < N <= 192: up to 128): W's row blocks split over 8 workgroups per chain tile, partial sums added by
     the last row group to arrive (k_split.hip).  Oracle bound of the sweeps, ragged tiles, padded rows, repeatable bits,
     the same bits from the host-pointer path (another stream, another scratch) and from concurrent callers."""
     import threading
@@ -193,7 +193,8 @@ def test_row_split_form(gpu, n, batch):
         sw = lik.logpdf(X)
     finally:
         M.set_logpdf_form("auto")
-    assert not np.array_equal(sw, ll) and np.all(np.abs(sw - ll) <= tol)      # really another kernel, same values
+    assert np.all(np.abs(sw - ll) <= tol)
+    assert batch < 64 or not np.array_equal(sw, ll)          # really another kernel (a few chains may agree to the last bit)
     ld = n + 3
     Xd = torch.full((batch, ld), np.nan, dtype=torch.float64, device=gpu)
     Xd[:, :n] = torch.as_tensor(X, device=gpu)
