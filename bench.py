@@ -206,8 +206,8 @@ def main():
         form = args.form
     else:
         form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
-        if args.kind == "logpdf" and ((192 < n <= 256 and B <= 1024) or (128 < n <= 192 and B <= 128)):
-            form = "split"                               # k_split.hip: W's row blocks over 8 workgroups per chain tile
+        if args.kind in ("logpdf", "tree") and B <= 1024 and (n > 192 or (n > 128 and B <= 128)):
+            form = "split"                               # k_split.hip: W's row blocks over 8-32 workgroups per chain tile
     # hipGraph replay hides the per-launch dispatch cost of the few-microsecond sweep launches; the multiply form's launches
     # are longer than an eager dispatch and are launched eagerly.  (On this pool about one run in twenty sees the host learn
     # of the completion ~60 ms late -- graph or eager, blocking wait or polling, HSA_ENABLE_INTERRUPT=0 or not -- while the HIP

@@ -59,21 +59,29 @@ const char* mcd_version(void);
 const char* mcd_last_error(void);
 
 /*
- * Which of the two forms of the log-density kernels a launch uses (process wide; results agree to rounding):
- *   MCD_FORM_AUTO     (default) by dimension and batch size (multiply from 2048 chains at N >= 96, from 8192 at N >= 32;
- *                     for 192 < N <= 256 and up to 1024 chains (128 < N <= 192: up to 128) mcd_mvn_logpdf[_batch] uses a row-split variant of the multiply
- *                     form, whose per-stream scratch is created on the first such call of a stream -- not under capture);
+ * Which form of the log-density kernels a launch uses (results agree to rounding, not bit for bit):
+ *   MCD_FORM_AUTO     (default) by dimension and batch size: the column sweep for small N and small batches; for N > 192 and
+ *                     up to 1024 chains (128 < N <= 192: up to 128) a row-split variant of the multiply form (k_split.hip: the
+ *                     row blocks of L^-1 dealt to 8-32 workgroups per 16-chain tile, partial sums handed over through a
+ *                     per-stream scratch owned by the handle); the multiply form from 2048 chains at N >= 96, from 8192 at
+ *                     N >= 32;
  *   MCD_FORM_SWEEP    always the column sweep (one chain per wave -- the latency form);
  *   MCD_FORM_MULTIPLY always the multiply form z = L^-1 (x - mu) on the fp64 matrix cores (the throughput form).
- * The environment variable MCD_WIDE=0|1 sets the initial value to SWEEP | MULTIPLY.  Returns the previous value.
+ * mcd_mvn_set_form chooses per handle (two samplers with a handle each can pin different forms); a handle whose choice is
+ * MCD_FORM_AUTO follows the process default, which mcd_set_logpdf_form sets (a test and tuning knob; the environment
+ * variable MCD_WIDE=0|1 sets its initial value to SWEEP | MULTIPLY).  Both return the previous value.
  * The gradient entry points follow the same choice; above N = 256 the multiply form uses the gradient rows (`G`, `g_heights`)
  * as scratch while it runs: a call whose gradient array IS an input array (in place) takes the sweeps instead; partially
  * overlapping arrays are not supported by either form.
+ * Stream capture: every entry point that takes a stream may be captured into a hipGraph.  The row-split form gives a stream
+ * under capture a scratch set of the capture's own, so a graph may be replayed on any stream while eager calls go on on the
+ * stream it was captured from; two executable graphs instantiated from ONE capture must not be replayed concurrently.
  */
 #define MCD_FORM_AUTO 0
 #define MCD_FORM_SWEEP 1
 #define MCD_FORM_MULTIPLY 2
 int mcd_set_logpdf_form(int form);
+int mcd_mvn_set_form(const mcd_mvn_t* h, int form);
 
 /*
  * Build the immutable likelihood operands on GPU `device_id`.

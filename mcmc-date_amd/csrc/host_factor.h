@@ -1,6 +1,7 @@
 // host_factor.h -- one-time host preparation of the likelihood operands (internal).
 #pragma once
 #include <cstddef>
+#include <cstdint>
 #include <vector>
 
 namespace mcd {
@@ -23,5 +24,18 @@ void pack_factors(int n, int R, const std::vector<double>& L, std::vector<double
 // Wtb: the same for the transposed product y = W^T z (k_wide_grad.hip): row block ib holds the k tiles kt = 4 ib ..
 // 4 NB - 1 at tile index 4 (ib NB - ib (ib - 1) / 2) + (kt - 4 ib), lane l = W[4 kt + (l >> 4)][16 ib + (l & 15)].
 void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt, std::vector<double>& Wtb);
+// W = L^-1, row-major lower triangular, long double accumulation.
+void invert_factor(int n, const std::vector<double>& L, std::vector<double>& W);
+
+// Tile stream of the row-split form (k_split.hip) for G row groups per chain tile.  The schedule itself is arithmetic
+// (split_sched.hpp) shared with the device; here the tiles are packed group after group in the order of a group's stream, in
+// pairs (lane l: its element of tile 2 i, then of tile 2 i + 1), plus one zero pair at the end; base[g] = first tile of group g.
+constexpr int SPH_MAXSEG = 10;
+struct SplitScheduleHost {
+    int G = 0, nc = 0, NB = 0;
+    std::vector<double> Ws;
+    std::vector<int32_t> base;
+};
+void build_split_schedule(int n, int G, const std::vector<double>& W, SplitScheduleHost& out);
 
 }  // namespace mcd

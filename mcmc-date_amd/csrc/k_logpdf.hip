@@ -97,13 +97,20 @@ int wide_chain_tiles(int64_t batch)
     return batch <= 256 * 16 ? 1 : 2;
 }
 
-static std::atomic<int> g_form{getenv("MCD_WIDE") ? (atoi(getenv("MCD_WIDE")) ? 2 : 1) : 0};   // MCD_FORM_*
+static std::atomic<int> g_form{getenv("MCD_WIDE") ? (atoi(getenv("MCD_WIDE")) ? 2 : 1) : 0};   // MCD_FORM_*: the process default
 
 int set_logpdf_form(int form) { return g_form.exchange(form); }
 
+// the form in force for a handle: its own choice (mcd_mvn_set_form) or, if it has none, the process default
+int effective_form(const MvnDev& M)
+{
+    const int own = M.form ? __atomic_load_n(M.form, __ATOMIC_RELAXED) : 0;
+    return own != 0 ? own : g_form.load(std::memory_order_relaxed);
+}
+
 bool use_wide(const MvnDev& M, int64_t batch)
 {
-    const int form = g_form.load(std::memory_order_relaxed);
+    const int form = effective_form(M);
     if (M.Wt == nullptr || form == 1) return false;
     if (form == 2) return true;
     // measured crossovers (tools/bench_forms.py, profiles/r01_form_crossover.jsonl): at 1024 chains the sweep still wins
@@ -113,13 +120,14 @@ bool use_wide(const MvnDev& M, int64_t batch)
 
 bool use_split(const MvnDev& M, int64_t batch)
 {
-    // measured window (tools/microbench/split/README.md): with four 64-row blocks in the sweep the split wins for every batch
-    // from 1 to 1024 chains (4.7 us against 7.0 us for a single chain); at N <= 192 the sweep's shorter dependent chain wins;
-    // from 2048 chains k_wide takes over.  128 < N <= 192: 3.9-5.0 us against 4.8-5.6 us up to 128 chains, the sweep from 256;
-    // N <= 128: the sweep (3.1-3.7 us against 3.9-4.7 us)
-    if (g_form.load(std::memory_order_relaxed) != 0 || M.Wt == nullptr || batch < 1) return false;
-    if (M.n > 192 && M.n <= 256) return batch <= kSplitMaxBatch;
-    return M.n > 128 && M.n <= 192 && batch <= 128;       // three 64-row blocks in the sweep: the split only wins while few CUs are busy
+    // measured window (tools/microbench/split/README.md, profiles/r02_split_window.jsonl): from four 64-row blocks in the sweep
+    // (N > 192) the split wins for every batch from 1 to 1024 chains; at N <= 128 the sweep's short dependent chain wins;
+    // 128 < N <= 192: the split up to 128 chains, the sweep from 256; from 2048 chains k_wide takes over
+    static const int force = getenv("MCD_SPLIT") ? atoi(getenv("MCD_SPLIT")) : -1;
+    if (effective_form(M) != 0 || M.split == nullptr || batch < 1 || batch > kSplitMaxBatch || force == 0) return false;
+    if (force == 1) return true;
+    if (M.n > 192) return true;
+    return M.n > 128 && batch <= 128;
 }
 
 bool use_wide_grad(const MvnDev& M, int64_t batch)
@@ -145,6 +153,7 @@ hipError_t launch_logpdf_g3(const MvnDev& M, const double* X, int64_t ldx, int64
 hipError_t launch_logpdf(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (use_split(M, batch)) return launch_logpdf_split(M, X, ldx, batch, ll, st);
     if (use_wide(M, batch)) return launch_logpdf_wide(M, X, ldx, batch, ll, st);
     if (M.R == 6 || M.R == 8) return launch_logpdf_g1(M, X, ldx, batch, ll, st);
     if (M.R == 12) return launch_logpdf_g2(M, X, ldx, batch, ll, st);

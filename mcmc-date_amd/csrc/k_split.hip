@@ -1,114 +1,606 @@
-// k_split.hip -- log-density for a sampler's usual batch (1 .. 1024 chains) at 192 < N <= 256: the multiply form with the
-// row blocks of W = L^-1 split over 8 workgroups per 16-chain tile (gfx950).  tools/microbench/split/README.md has the
-// measurements that led here.
+// k_split.hip -- log-density (raw x and tree states) for a sampler's usual batch (1 .. 1024 chains) at 128 < N <= 1024: the
+// multiply form z = W (x - mu), W = L^-1, on the fp64 matrix cores with the ROW BLOCKS of W split over G workgroups per
+// 16-chain tile (gfx950).  tools/microbench/split/README.md has the measurements that led here.
 //
-// 512 chains = 32 tiles x 8 row groups = 256 workgroups, one per CU: a workgroup takes in 1/8 of W (35 KB at N = 256)
-// instead of all of it, and no dependent column chain is left.  Row group g owns the row blocks g and 15 - g (equal work),
-// its 4 waves share the 68 k tiles of the two blocks, the partial z tiles are added through LDS in a fixed order.  The
-// price is a reduction across workgroups: the partial sums of squares of a row group are published with relaxed
-// agent-scope exchanges (performed at the coherence point; the returned value tells the thread so), a counter per tile
-// is incremented after a workgroup barrier, and the row group that sees 7 adds the eight partials in a fixed order,
-// writes ll and resets the counter.  No agent-scope fence: it would write the XCD's L2 back on every workgroup (measured
-// 22.8 us per launch instead of 6.2).  The eight row groups of a tile share blockIdx % 8, i.e. one XCD and one L2 -- a
-// latency matter, not a correctness one.  The scratch (8 x 16 partials per tile) and the counters belong to the call:
-// mvn_capi.cpp keeps one set per handle and stream.
+// 512 chains = 32 tiles x 8 row groups = 256 workgroups, one per CU: a workgroup takes in 1/G of W (35 KB at N = 256, 532 KB
+// at N = 1024) instead of all of it, and no dependent column chain is left.  The schedule is arithmetic (split_sched.hpp):
+// the row blocks are dealt to the groups in alternating direction, a group's k tiles are cut into eight equal runs (one per
+// wave, two waves per SIMD) and packed once per handle in the order the waves consume them (host_factor.cpp), so a wave
+// streams ONE linear run of tile pairs (16 bytes per lane and load) through a register ring whatever blocks it crosses.  A block that a
+// wave holds completely is squared in registers; a block cut between waves leaves partial z tiles in LDS, added in a fixed
+// order.  The residuals of the tile's 16 chains (all the columns the group needs: up to 131 KB at N = 1024) are staged once.
+//
+// The price is a reduction across workgroups.  Hand-over, correct under the memory model alone (no ordering between different
+// locations is relied on, no placement of workgroups on XCDs -- MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility") and free of deadlock whatever the dispatch order and residency:
+//   * every partial sum has a scratch slot of its own, an 8-byte atomic variable that holds SP_POISON (a NaN pattern no
+//     arithmetic produces) between launches;
+//   * the first thing a row group does is to take a ticket: a RETURNING agent-scope atomic add on the tile's counter
+//     (read-modify-writes on device memory are performed at the memory side, not in an XCD's L2: no add is lost whatever
+//     XCDs the adders run on); the answer travels while the chain vectors are staged.  The group that draws G - 1 STARTED
+//     last: it is the reader.  Every other group of the tile has started before it, is running and never waits for
+//     anything -- so the reader may wait for them;
+//   * a group that is not the reader stores its 16 partial sums with relaxed agent-scope atomic stores
+//     (global_store_dwordx2 sc1: written through to the coherence point) and ends;
+//   * the reader keeps its own partial sums in registers and reads the other G - 1 x 16 slots with relaxed agent-scope atomic
+//     loads (global_load_dwordx2 sc1: never served from the CU's L1), repeating a load until it no longer sees SP_POISON -- a
+//     store that is still to come or on its way is waited for, a stale value cannot be mistaken for a fresh one; then it adds
+//     the partial sums in group order, writes ll, puts SP_POISON back into the slots and zero into the counter (ordered before
+//     the next launch by the kernel boundary).  One memory round trip at the end of the kernel instead of the two an election
+//     by the LAST ARRIVAL costs (counter add, then the loads).
+// No agent-scope fence: it would write the XCD's L2 back on every workgroup (measured 22.8 us per launch instead of 6.2).
+// The groups of a tile share blockIdx % 8, i.e. in practice one XCD and one L2: a matter of speed only (the chain vectors
+// are fetched once per XCD); MCD_SPLIT_SCATTER=1 deals a tile's groups to consecutive workgroups -- different XCDs -- and the
+// stress test runs both.  The scratch (G x 16 slots per tile, a counter per tile) belongs to the stream the call is made
+// on (or to the capture while a stream is being captured): SplitHost keeps the sets.
 #include "wide_device.hpp"
+#include "host_factor.h"
+#include "split_sched.hpp"
+
+#include <stdlib.h>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace mcd {
 
-constexpr int SP_WAVES = 4;
+static_assert(SP_MAXSEG == SPH_MAXSEG, "host_factor.h and mvn_kernels.h differ");
 
-// N <= 256 (one chunk).  grid = 64 * ceil(tiles / 8); block = 256 threads.
-__global__ void __launch_bounds__(64 * SP_WAVES) k_logpdf_split(MvnDev M, const double* __restrict__ X, int64_t ldx, int64_t batch, double* __restrict__ ll,
-                                                                double* __restrict__ scratch, unsigned* __restrict__ counter)
+constexpr unsigned long long SP_POISON = 0x7FF8C0DEDEADBEEFull;   // "no partial sum yet": a quiet NaN with a payload no arithmetic produces
+
+constexpr int SP_Z = 256;                                  // doubles of one partial z tile (16 rows x 16 chains)
+template <int NC>
+constexpr size_t split_lds_bytes()
 {
-    const double* __restrict__ Wt = M.Wt;
-    const double* __restrict__ mu = M.mu;
-    const int n = M.n;
-    const double c = M.c, logdet = M.logdet;
-    __shared__ double rs[16 * WD_LD];                     // residuals of the tile's 16 chains
-    __shared__ double zsum[SP_WAVES][2][16][17];          // partial z tiles of the two row blocks, per wave
-    __shared__ unsigned last_flag;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    const int tile = (bid >> 6) * 8 + (bid & 7), grp = (bid >> 3) & 7;
-    const int64_t b0 = (int64_t)tile * 16;
-    if (b0 >= batch) return;                              // whole workgroup (tiles are dealt in groups of eight)
-    const int nb = (n + 15) >> 4, shift = 16 - nb;
-    const int bA = grp - shift, bB = 15 - grp - shift;
-    const int col = lane & 15, kq = lane >> 4;
-    // stage: 256 threads = one chain row per pass
-    {
-        const bool live = tid < n;
-        const double m = live ? mu[tid] : 0.0;
-        double v[16];
-#pragma unroll
-        for (int ch = 0; ch < 16; ++ch) v[ch] = (live && b0 + ch < batch) ? X[(b0 + ch) * ldx + tid] : m;
-#pragma unroll
-        for (int ch = 0; ch < 16; ++ch) rs[ch * WD_LD + tid] = v[ch] - m;
-    }
-    __syncthreads();
-    // the k tiles of block A then block B, dealt evenly to the 4 waves
-    const int ntA = bA >= 0 ? 4 * (bA + 1) : 0, ntB = bB >= 0 ? 4 * (bB + 1) : 0;
-    const int total = ntA + ntB, per = ((total + SP_WAVES - 1) / SP_WAVES + 3) & ~3;   // multiples of 4
-    const int lo = wave * per, hi = (lo + per < total) ? lo + per : total;
-    d4 accA[1] = {d4{0.0, 0.0, 0.0, 0.0}}, accB[1] = {d4{0.0, 0.0, 0.0, 0.0}};
-    if (lo < hi) {
-        const int a0 = lo < ntA ? lo : ntA, a1 = hi < ntA ? hi : ntA;          // part in block A
-        const int c0 = (lo > ntA ? lo : ntA) - ntA, c1 = (hi > ntA ? hi : ntA) - ntA;   // part in block B
-        if (a1 > a0) wide_tri_pass<1>(Wt + ((int64_t)(2 * bA * (bA + 1)) + a0) * 64 + lane, a1 - a0, a0, rs, col, kq, accA);
-        if (c1 > c0) wide_tri_pass<1>(Wt + ((int64_t)(2 * bB * (bB + 1)) + c0) * 64 + lane, c1 - c0, c0, rs, col, kq, accB);
+    return (size_t)(16 * (NC * 256 + 2) + SP_NSLOT * SP_Z + SP_NW * 16) * sizeof(double);
+}
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// diagnostic build (make stamp_split): s_memtime phase stamps of every wave of workgroup 0 and of the workgroup that came
+// last for tile 0, read back with mcd_split_debug_stamps (tools/microbench/split_stamps.py)
+#ifdef MCD_SPLIT_STAMP
+__device__ unsigned long long g_split_dbg[2 * SP_NW * 8];
+#define SP_T(i) do { if (tile == 0 && (grp == 0 || grp == G - 1) && lane == 0) g_split_dbg[((grp == 0 ? 0 : 1) * SP_NW + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SP_T(i) do { } while (0)
+#endif
+constexpr int SP_RING = 8;                                 // tile PAIRS in flight per wave (8 KiB)
+
+// One group: 4 tiles = the ring slots 2 PH and 2 PH + 1 against the four B operands in `bc`.  Software pipeline, written out
+// because the compiler's own ordering (every load as early as possible) makes a refilled slot overlap the value still waiting
+// for its MFMA, which costs a register copy and a full vmcnt drain at every loop end: the group first refills the two slots
+// the PREVIOUS group consumed (dead by now: the refill lands in the same registers) with the pairs 6 and 7 ahead, reads the
+// NEXT group's B operands from LDS into `bn`, then issues its own four MFMAs, whose operands were requested three groups
+// (A) and one group (B) ago; nothing moves across the group boundary.
+template <int PH>
+__device__ __forceinline__ void split_group(const d2* __restrict__ w, d2 (&ring)[SP_RING], int jp, int lastp, const double* rk_next,
+                                            const double (&bc)[4], double (&bn)[4], d4& acc)
+{
+    constexpr int NP = SP_RING / 2, PR = (PH + NP - 1) % NP;
+    if (jp + SP_RING - 1 <= lastp) {                       // wave-uniform: no request past the end of the run (the loop end waits
+#pragma unroll                                             // for everything in flight: a useless load would cost a round trip)
+        for (int p = 0; p < 2; ++p) ring[2 * PR + p] = w[(jp + SP_RING - 2 + p) * 64];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        zsum[wave][0][kq + 4 * q][col] = accA[0][q];
-        zsum[wave][1][kq + 4 * q][col] = accB[0][q];
-    }
-    __syncthreads();
-    // z = sum over the waves (fixed order); one thread per (block, row, chain): 512 values, 256 threads x 2
-    double ss = 0.0;
+    for (int i = 0; i < 4; ++i) bn[i] = rk_next[i * 4];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH].x, bc[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH].y, bc[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH + 1].x, bc[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH + 1].y, bc[3], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // 2 VMEM reads, then
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // 2 DS reads (ds_read2_b64), then
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // 4 MFMAs
+}
+
+// ng groups starting at phase PH (compile time); jp = pair index of the first group; rk = this lane's B operand of the first
+// k tile.  The B operands one group past the end of the run are read and dropped (LDS behind rs is the kernel's own).
+template <int PH>
+__device__ __forceinline__ void split_run(const d2* __restrict__ w, d2 (&ring)[SP_RING], int jp, int lastp, int ng, const double* rk, d4& acc)
+{
+    constexpr int NP = SP_RING / 2;
+    double b0[4], b1[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = tid >> 4, cc = tid & 15;
-        const double z = ((zsum[0][h][row][cc] + zsum[1][h][row][cc]) + zsum[2][h][row][cc]) + zsum[3][h][row][cc];
-        ss = fma(z, z, ss);
+    for (int i = 0; i < 4; ++i) b0[i] = rk[i * 4];
+    __builtin_amdgcn_sched_barrier(0);
+    int g = 0;
+    for (; g + NP <= ng; g += NP) {
+        split_group<PH>(w, ring, jp, lastp, rk + 16, b0, b1, acc);
+        split_group<(PH + 1) % NP>(w, ring, jp + 2, lastp, rk + 32, b1, b0, acc);
+        split_group<(PH + 2) % NP>(w, ring, jp + 4, lastp, rk + 48, b0, b1, acc);
+        split_group<(PH + 3) % NP>(w, ring, jp + 6, lastp, rk + 64, b1, b0, acc);
+        jp += 8;
+        rk += 64;
     }
-    // sum over the 16 rows of a chain: lanes with the same tid & 15 (stride 16 within a wave, then the 4 waves)
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
-    __syncthreads();
-    double* part = &zsum[0][0][0][0];
-    if (lane < 16) part[wave * 16 + lane] = ss;
-    __syncthreads();
-    if (tid < 16) {
-        const double q = ((part[tid] + part[16 + tid]) + part[32 + tid]) + part[48 + tid];
-        // a read-modify-write is performed in the XCD's L2 and its return tells this thread that it has been: no agent-scope
-        // fence (which would write the whole L2 back: measured 22 us per launch with __threadfence()) is needed, because every
-        // workgroup that touches this tile's scratch and counter runs on the same XCD
-        (void)__hip_atomic_exchange(&scratch[((int64_t)tile * 8 + grp) * 16 + tid], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (tid == 0) last_flag = (__hip_atomic_fetch_add(&counter[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7u) ? 1u : 0u;
-    __syncthreads();
-    if (last_flag && tid < 16) {
-        double q = 0.0;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) q += __hip_atomic_load(&scratch[((int64_t)tile * 8 + g) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (b0 + tid < batch) ll[b0 + tid] = c + (-0.5) * (logdet + q);
-        if (tid == 0) __hip_atomic_store(&counter[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g < ng) {
+        split_group<PH>(w, ring, jp, lastp, rk + 16, b0, b1, acc);
+        if (g + 1 < ng) {
+            split_group<(PH + 1) % NP>(w, ring, jp + 2, lastp, rk + 32, b1, b0, acc);
+            if (g + 2 < ng) split_group<(PH + 2) % NP>(w, ring, jp + 4, lastp, rk + 48, b0, b1, acc);
+        }
     }
 }
 
-hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* scratch, unsigned* counter,
-                               hipStream_t st)
+// grid = ceil(tiles / 8) * 8 * G; block = 512 threads (8 waves, two per SIMD: one waits for tiles while the other multiplies).
+template <int NC, bool TREE>
+__global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M, SplitSched S, WideSrc A, int64_t batch, int flags,
+                                                                        double* __restrict__ ll, double* scratch, unsigned* counter)
+{
+    constexpr int LD = NC * 256 + 2;                       // LDS row stride in doubles: = 4 dwords (mod 64 banks)
+    extern __shared__ double smem[];
+    double* rs = smem;                                     // [16][LD] residuals of the tile's chains
+    double* zsum = rs + 16 * LD;                           // [SP_NSLOT][SP_Z] partial z tiles of the blocks cut between waves
+    double* part = zsum + SP_NSLOT * SP_Z;                 // [SP_NW][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = S.G;
+    int tile, grp;
+    {
+        const int bid = blockIdx.x;
+        if (flags & 1) {                                   // test layout: a tile's groups on consecutive workgroups (different XCDs)
+            tile = bid / G;
+            grp = bid - tile * G;
+        } else {                                           // a tile's groups share blockIdx % 8
+            const int sup = bid / (8 * G), rem = bid - sup * 8 * G;
+            tile = sup * 8 + (rem & 7);
+            grp = rem >> 3;
+        }
+    }
+    const int64_t b0 = (int64_t)tile * 16;
+    if (b0 >= batch) return;                               // whole workgroup
+    // who will add up the tile's partial sums: the row group that STARTS last (see the header).  The answer travels while
+    // the chain vectors are staged.
+    unsigned ticket = 0;
+    if (wave == 0 && lane == 0) ticket = __hip_atomic_fetch_add(&counter[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int rot = (flags & 2) ? 0 : 2 * grp;             // first chain a group stages (experiment knob: bit 1 = no rotation)
+    const int NB = S.NB;
+    const SpGroup sg = sp_group(NB, G, grp);               // split_sched.hpp: scalar arithmetic on blockIdx, no table to fetch
+    const int lo = wave * sg.per, hi = (lo + sg.per < sg.Tg) ? lo + sg.per : sg.Tg;
+    const int T = hi > lo ? hi - lo : 0;
+    const int ncols = sg.ncols;
+    const int col = lane & 15, kq = lane >> 4;
+    SP_T(0);
+#ifdef MCD_SPLIT_STAMP
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // the first tiles of this wave's run are requested before anything else: they travel while the chain vectors do.  Tiles
+    // are stored in pairs (lane l: its element of tile 2 i, then of tile 2 i + 1), so one 16-byte load per lane brings two
+    const int npair = T >> 1, lastp = npair > 0 ? npair - 1 : 0;
+    const d2* __restrict__ w = reinterpret_cast<const d2*>(S.Ws) + (int64_t)((S.base[grp] + lo) >> 1) * 64 + lane;
+    d2 ring[SP_RING];
+#pragma unroll
+    for (int p = 0; p < SP_RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
+
+    // ---- stage the residuals
+    if constexpr (!TREE) {
+        // thread = column ((tid & 255) + 256 c), every second chain.  Every load is unconditional on a clamped address (a load
+        // behind a condition costs a branch and its own wait each); padding is then forced to exact zeros by the select.  The
+        // groups of a tile start on different chains, so that they do not ask one L2 channel for the same line at the same time.
+        double m[NC], v[NC][8];
+        const int nlast = M.n - 1, tc = tid & 255, ch0 = tid >> 8;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = c * 256 + tc;
+            const int kc = k < nlast ? k : nlast;
+            m[c] = M.mu[kc];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ch = (2 * i + ch0 + rot) & 15;
+                const int64_t b = (b0 + ch < batch) ? b0 + ch : batch - 1;
+                const double* __restrict__ rowp = A.X + b * A.ldx;              // wave-uniform row base, per-lane 32-bit column
+                v[c][i] = rowp[kc];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = c * 256 + tc;
+            if (k < ncols) {
+                const bool live = k < M.n;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ch = (2 * i + ch0 + rot) & 15;
+                    const double d = v[c][i] - m[c];                            // dxs = xs - mu  (app/Probability.hs:171)
+                    rs[ch * LD + k] = (live && b0 + ch < batch) ? d : 0.0;      // padded columns and chains: exact zeros
+                }
+            }
+        }
+    } else {
+        // distances from the tree state -- app/Probability.hs:201-207, the arithmetic of load_tree (mvn_device.hpp) and
+        // wide_stage (wide_device.hpp): d = ((h_parent - h_node) * rate) * (tH * rMu), slot 0 = the two root branches added
+        // (sumFirstTwo, app/Tools.hs:36-48).  A wave owns two chains: a chain's heights arrive as one contiguous row
+        // (coalesced) in the chain's own LDS row, the parent / node heights of a slot are gathered from there -- a gather from
+        // global memory costs a 128-byte line per lane -- and the distances then overwrite the row (one wave, LDS operations
+        // in order: no barrier).  The rates are read by slot: slot k's node is k + 1 or k + 2, nearly contiguous.
+        constexpr int NI = NC * 4;                         // columns per lane: k = 64 i + lane
+        const int nn = A.T.n_nodes;
+        int na[NI], npa[NI];
+        double m[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int k = i * 64 + lane;
+            const int kc = k < M.n - 1 ? k : M.n - 1;     // unconditional loads on clamped addresses; `live` decides later
+            na[i] = A.T.slot_node[kc];
+            npa[i] = A.T.slot_parent[kc];
+            m[i] = M.mu[kc];
+        }
+        const int rr = A.T.root_right;
+        constexpr int CB = NC >= 4 ? 1 : 2;                // chains whose loads are in flight together per wave (registers)
+#pragma unroll 1
+        for (int j0 = 0; j0 < 2; j0 += CB) {
+            double hv[CB][NI + 1], ra[CB][NI], sc[CB], rrr[CB];
+#pragma unroll
+            for (int jj = 0; jj < CB; ++jj) {
+                const int ch = (8 * (j0 + jj) + wave + rot) & 15;      // the groups of a tile start on different chains
+                const int64_t b = (b0 + ch < batch) ? b0 + ch : batch - 1;
+                const double* __restrict__ h = A.H + b * A.lds;
+                const double* __restrict__ r = A.Rt + b * A.lds;
+#pragma unroll
+                for (int i = 0; i <= NI; ++i) {
+                    const int v = i * 64 + lane;
+                    hv[jj][i] = h[v < nn ? v : nn - 1];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) ra[jj][i] = r[na[i]];
+                rrr[jj] = r[rr];
+                sc[jj] = A.tH[b] * A.rMu[b];
+            }
+#pragma unroll
+            for (int jj = 0; jj < CB; ++jj) {
+                const int ch = (8 * (j0 + jj) + wave + rot) & 15;
+                const bool in = b0 + ch < batch;
+                double* row = rs + ch * LD;
+#pragma unroll
+                for (int i = 0; i <= NI; ++i) {
+                    const int v = i * 64 + lane;
+                    if (v < LD) row[v] = hv[jj][i];
+                }
+                double ha[NI], hp[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    ha[i] = row[na[i]];
+                    hp[i] = row[npa[i]];
+                }
+                const double h0 = row[0], hr = row[rr];
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): every height has been read before the row is overwritten
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int k = i * 64 + lane;
+                    double d = (hp[i] - ha[i]) * ra[jj][i];
+                    if (k == 0) {                          // the root slot: both root branches; the root-branch Jacobian
+                        d = d + (h0 - hr) * rrr[jj];
+                        d = d * sc[jj];
+                        if (grp == 0 && in && A.logjac != nullptr) A.logjac[b0 + ch] = log(1.0 / d);   // app/Probability.hs:394, 409
+                    } else {
+                        d = d * sc[jj];
+                    }
+                    if (k < ncols) row[k] = (in && k < M.n) ? d - m[i] : 0.0;     // padded columns and chains: exact zeros
+                }
+            }
+        }
+    }
+    SP_T(1);
+    __syncthreads();
+
+    // ---- this wave's run of tiles: z tile += W tile x R tile, segment after segment.  A segment (a run of k tiles inside
+    // one row block) is a whole number of groups of 4 tiles = 2 ring slots; the ring has SP_RING slots, so a group's slots
+    // are known at compile time once its phase (group index mod SP_RING / 2) is: split_run is instantiated per starting phase
+    double ss = 0.0;                                       // sum of squares of the blocks this wave holds completely
+    SP_T(2);
+    if (T > 0) {
+        const double* rb = rs + col * LD + kq;
+        int jp = 0, ph = 0;                                // pair index of the next tile pair to be used, its phase
+        sp_for_each_segment(NB, G, grp, sg, wave, [&](int k0, int nt, int kind) {
+            const int ng = nt >> 2;
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            const double* rk = rb + k0 * 4;
+            switch (ph) {
+            case 0: split_run<0>(w, ring, jp, lastp, ng, rk, acc); break;
+            case 1: split_run<1>(w, ring, jp, lastp, ng, rk, acc); break;
+            case 2: split_run<2>(w, ring, jp, lastp, ng, rk, acc); break;
+            default: split_run<3>(w, ring, jp, lastp, ng, rk, acc); break;
+            }
+            jp += 2 * ng;
+            ph = (ph + ng) & (SP_RING / 2 - 1);
+            if (kind == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ss = fma(acc[q], acc[q], ss);
+            } else {
+                double* zs = zsum + (kind == 1 ? 2 * wave - 1 : 2 * wave) * SP_Z;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zs[(kq + 4 * q) * 16 + col] = acc[q];        // f64 result layout: row = (lane >> 4) + 4 reg
+            }
+        });
+    }
+    SP_T(3);
+    __syncthreads();
+
+    // ---- the blocks cut between waves: thread = (row, chain) of the z tile, contributions added in wave order (256 threads)
+    if (tid < SP_Z) {
+        sp_for_each_cut(NB, G, grp, sg, [&](int wf, int wl) {
+            double z = zsum[2 * wf * SP_Z + tid];
+            for (int x = wf + 1; x <= wl; ++x) z += zsum[(2 * x - 1) * SP_Z + tid];
+            ss = fma(z, z, ss);
+        });
+    }
+    // both layouts keep a chain on lane & 15: the rows of a chain sit on lanes 16 apart, then on the waves
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    if (lane < 16) part[wave * 16 + lane] = ss;
+    __syncthreads();
+
+    SP_T(4);
+    // ---- hand-over (see the header): all of it inside wave 0
+    if (wave == 0) {
+        unsigned long long* slots = reinterpret_cast<unsigned long long*>(scratch) + (int64_t)tile * G * 16;
+        double q = 0.0;
+        if (lane < 16) {
+#pragma unroll
+            for (int x = 0; x < SP_NW; ++x) q += part[x * 16 + lane];
+        }
+        ticket = __builtin_amdgcn_readfirstlane(ticket);   // uses the value the add returned (long since)
+        const bool reader = ticket == (unsigned)(G - 1);   // every other group of the tile had started before this one
+        if (!reader) {
+            if (lane < 16) {
+                unsigned long long bits = (unsigned long long)__double_as_longlong(q);
+                if (bits == SP_POISON) bits = 0x7FF8000000000000ull;             // (a NaN input with this very payload: any NaN will do)
+                __hip_atomic_store(&slots[grp * 16 + lane], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            SP_T(5);
+        } else {
+            SP_T(5);
+            if (lane < 16) {
+                // the G - 1 other groups are running (they took their tickets before this one) and wait for nothing: each of
+                // their slots will leave SP_POISON.  All loads in flight together, 8 at a time, in group order (fixed order of
+                // the sum); a slot still empty is polled again.
+                double sum = 0.0;
+                bool lost = false;
+                for (int g0 = 0; g0 < G; g0 += 8) {
+                    unsigned long long bits[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        bits[i] = __hip_atomic_load(&slots[(g0 + i) * 16 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (g0 + i == grp) {
+                            sum += q;                                           // this group's own partial sum never left the registers
+                            continue;
+                        }
+                        for (int spin = 0; bits[i] == SP_POISON && spin < (1 << 24); ++spin) {   // bounded: never hang
+                            __builtin_amdgcn_s_sleep(2);
+                            bits[i] = __hip_atomic_load(&slots[(g0 + i) * 16 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        lost |= bits[i] == SP_POISON;
+                        sum += __longlong_as_double((long long)bits[i]);
+                        __hip_atomic_store(&slots[(g0 + i) * 16 + lane], SP_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (lost) sum = __longlong_as_double(0x7FF8000000000000ll);
+                if (b0 + lane < batch) ll[b0 + lane] = M.c + (-0.5) * (M.logdet + sum);   // app/Probability.hs:169
+            }
+            if (lane == 0) __hip_atomic_store(&counter[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        SP_T(6);
+#ifdef MCD_SPLIT_STAMP
+        if (tile == 0 && (grp == 0 || grp == G - 1) && lane == 0) g_split_dbg[((grp == 0 ? 0 : 1) * SP_NW + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;
+#endif
+    }
+}
+
+__global__ void k_split_poison(unsigned long long* slots, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = SP_POISON;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side: schedules per handle, scratch sets per stream
+// ------------------------------------------------------------------------------------------------------------------
+struct SplitHost {
+    int n = 0, device = 0;
+    SplitSched sched[3] = {};                              // G = 8, 16, 32 (G = 0: not built for this N)
+    std::vector<void*> dev_allocs;
+    struct Set {
+        double* partials = nullptr;
+        unsigned* counters = nullptr;
+    };
+    std::mutex mu;
+    std::vector<Set> spare;                                // zeroed, unassigned
+    std::map<std::pair<unsigned long long, hipStream_t>, Set> assigned;   // (capture id or 0, stream)
+    hipStream_t init_stream = nullptr;
+};
+
+static hipError_t new_set(SplitHost* s, SplitHost::Set& out)
+{
+    // may run while the calling thread captures a stream: allocations are legal under the relaxed capture mode, and the
+    // clearing memset goes to a stream of the pool's own
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    hipError_t e = hipMalloc((void**)&out.partials, kSplitScratchDoubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&out.counters, kSplitCounters * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(out.counters, 0, kSplitCounters * sizeof(unsigned), s->init_stream);
+    if (e == hipSuccess) {                                 // every slot starts as "no partial sum yet"
+        static_assert(sizeof(unsigned long long) == sizeof(double), "");
+        hipLaunchKernelGGL(k_split_poison, dim3((unsigned)((kSplitScratchDoubles + 255) / 256)), dim3(256), 0, s->init_stream,
+                           reinterpret_cast<unsigned long long*>(out.partials), (size_t)kSplitScratchDoubles);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->init_stream);
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    return e;
+}
+
+template <int NC, bool TREE>
+static hipError_t split_allow_lds()
+{
+    if (split_lds_bytes<NC>() <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void*)k_split<NC, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes<NC>());
+}
+
+SplitHost* split_host_create(int n, const double* L_rowmajor, hipError_t* err)
+{
+    *err = hipSuccess;
+    SplitHost* s = new SplitHost();
+    s->n = n;
+    auto fail = [&](hipError_t e) {
+        *err = e;
+        split_host_destroy(s);
+        return (SplitHost*)nullptr;
+    };
+    if (hipError_t e = hipGetDevice(&s->device)) return fail(e);
+    if (hipError_t e = hipStreamCreateWithFlags(&s->init_stream, hipStreamNonBlocking)) return fail(e);
+    const int NB = (n + 15) / 16;
+    std::vector<double> L(L_rowmajor, L_rowmajor + (size_t)n * n), W;
+    invert_factor(n, L, W);
+    const int Gs[3] = {8, 16, 32};
+    for (int v = 0; v < 3; ++v) {
+        const int G = Gs[v];
+        if (v > 0 && (int64_t)NB * (NB + 1) < 32 * (int64_t)G) continue;   // fewer than 16 tiles per wave: not worth a variant
+        SplitScheduleHost h;
+        build_split_schedule(n, G, W, h);
+        if (h.nc > 4) continue;
+        void* dW = nullptr;
+        if (hipError_t e = hipMalloc(&dW, h.Ws.size() * sizeof(double))) return fail(e);
+        s->dev_allocs.push_back(dW);
+        if (hipError_t e = hipMemcpy(dW, h.Ws.data(), h.Ws.size() * sizeof(double), hipMemcpyHostToDevice)) return fail(e);
+        SplitSched& S = s->sched[v];
+        S.G = G;
+        S.nc = h.nc;
+        S.NB = h.NB;
+        S.Ws = (const double*)dW;
+        for (int g = 0; g < G; ++g) S.base[g] = h.base[g];
+    }
+    // more than 64 KiB of dynamic LDS has to be allowed once per kernel and device, outside any stream capture
+    if (hipError_t e = split_allow_lds<2, false>()) return fail(e);
+    if (hipError_t e = split_allow_lds<2, true>()) return fail(e);
+    if (hipError_t e = split_allow_lds<3, false>()) return fail(e);
+    if (hipError_t e = split_allow_lds<3, true>()) return fail(e);
+    if (hipError_t e = split_allow_lds<4, false>()) return fail(e);
+    if (hipError_t e = split_allow_lds<4, true>()) return fail(e);
+    for (int i = 0; i < 4; ++i) {                          // a few scratch sets ahead, so that a first use under capture finds one
+        SplitHost::Set set;
+        if (hipError_t e = new_set(s, set)) return fail(e);
+        s->spare.push_back(set);
+    }
+    return s;
+}
+
+void split_host_destroy(SplitHost* s)
+{
+    if (!s) return;
+    for (void* p : s->dev_allocs) (void)hipFree(p);
+    for (auto& x : s->spare) {
+        if (x.partials) (void)hipFree(x.partials);
+        if (x.counters) (void)hipFree(x.counters);
+    }
+    for (auto& kv : s->assigned) {
+        if (kv.second.partials) (void)hipFree(kv.second.partials);
+        if (kv.second.counters) (void)hipFree(kv.second.counters);
+    }
+    if (s->init_stream) (void)hipStreamDestroy(s->init_stream);
+    delete s;
+}
+
+// The scratch set of a launch on `st`: launches on one stream are ordered, so they share a set; a stream being captured gets
+// a set of the capture's own (the capture id), because the graph may later be replayed on any stream, concurrently with eager
+// launches on the stream it was captured from.
+static hipError_t scratch_for(SplitHost* s, hipStream_t st, SplitHost::Set& out)
+{
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipError_t e = hipStreamGetCaptureInfo(st, &status, &id)) return e;
+    if (status == hipStreamCaptureStatusInvalidated) return hipErrorStreamCaptureInvalidated;
+    const std::pair<unsigned long long, hipStream_t> key(status == hipStreamCaptureStatusActive ? id + 1 : 0ull, st);
+    std::lock_guard<std::mutex> lock(s->mu);
+    auto it = s->assigned.find(key);
+    if (it == s->assigned.end()) {
+        SplitHost::Set set;
+        if (!s->spare.empty()) {
+            set = s->spare.back();
+            s->spare.pop_back();
+        } else if (hipError_t e = new_set(s, set)) {
+            return e;
+        }
+        it = s->assigned.emplace(key, set).first;
+    }
+    out = it->second;
+    return hipSuccess;
+}
+
+static int pick_variant(const SplitHost* s, int64_t batch)
+{
+    const char* env = getenv("MCD_SPLIT_G");               // tuning / tests: force G (read per launch)
+    const int force = env ? atoi(env) : 0;
+    const int64_t tiles = (batch + 15) / 16;
+    int best = 0;
+    for (int v = 0; v < 3; ++v) {
+        if (s->sched[v].G == 0) continue;
+        if (force == s->sched[v].G) return v;
+        if (tiles * s->sched[v].G <= 256) best = v;        // more row groups while every workgroup still has a CU to itself
+    }
+    return best;
+}
+
+template <bool TREE>
+static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
-    if (M.Wt == nullptr || M.n > WD_SB || batch > kSplitMaxBatch || scratch == nullptr || counter == nullptr) return hipErrorInvalidValue;
+    SplitHost* s = const_cast<SplitHost*>(M.split);
+    if (s == nullptr || batch > kSplitMaxBatch) return hipErrorInvalidValue;
+    const SplitSched& S = s->sched[pick_variant(s, batch)];
+    if (S.G == 0) return hipErrorInvalidValue;
+    SplitHost::Set set;
+    if (hipError_t e = scratch_for(s, st, set)) return e;
+    const char* env = getenv("MCD_SPLIT_SCATTER");         // tests: a tile's row groups on different XCDs (read per launch)
+    int scatter = env ? (atoi(env) & 1) : 0;
+    env = getenv("MCD_SPLIT_NOROT");
+    if (env && atoi(env)) scatter |= 2;
+
     const int64_t tiles = (batch + 15) / 16;
-    const unsigned grid = (unsigned)(((tiles + 7) / 8) * 64);
-    hipLaunchKernelGGL(k_logpdf_split, dim3(grid), dim3(64 * SP_WAVES), 0, st, M, X, ldx, batch, ll, scratch, counter);
+    const unsigned grid = (scatter & 1) ? (unsigned)(tiles * S.G) : (unsigned)(((tiles + 7) / 8) * 8 * S.G);
+    const dim3 block(64 * SP_NW);
+#define MCD_SPLIT_LAUNCH(NC_) \
+    hipLaunchKernelGGL((k_split<NC_, TREE>), dim3(grid), block, split_lds_bytes<NC_>(), st, M, S, A, batch, scatter, ll, set.partials, set.counters)
+    switch (S.nc) {
+    case 1: MCD_SPLIT_LAUNCH(1); break;
+    case 2: MCD_SPLIT_LAUNCH(2); break;
+    case 3: MCD_SPLIT_LAUNCH(3); break;
+    case 4: MCD_SPLIT_LAUNCH(4); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef MCD_SPLIT_LAUNCH
     return hipGetLastError();
 }
 
+hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
+{
+    WideSrc A{};
+    A.X = X;
+    A.ldx = ldx;
+    return launch_split<false>(M, A, batch, ll, st);
+}
+
+hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                    const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st)
+{
+    WideSrc A{};
+    A.T = T;
+    A.H = H;
+    A.Rt = Rt;
+    A.lds = lds;
+    A.tH = tH;
+    A.rMu = rMu;
+    A.logjac = logjac;
+    return launch_split<true>(M, A, batch, ll, st);
+}
+
 }  // namespace mcd
+
+#ifdef MCD_SPLIT_STAMP
+extern "C" int mcd_split_debug_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_split_dbg), sizeof(unsigned long long) * 2 * mcd::SP_NW * 8);
+}
+#endif

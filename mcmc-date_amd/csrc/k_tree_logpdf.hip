@@ -90,6 +90,7 @@ hipError_t launch_tree_logpdf(const MvnDev& M, const TreeDev& T, const double* H
                               hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (use_split(M, batch)) return launch_tree_logpdf_split(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st);
     if (use_wide(M, batch)) return launch_tree_logpdf_wide(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st);
     if (M.R == 6 || M.R == 8) return launch_tree_logpdf_g1(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st);
     if (M.R == 12) return launch_tree_logpdf_g2(M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, st);

@@ -8,7 +8,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -136,13 +135,8 @@ struct mcd_mvn {
     double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr, *d_Wt = nullptr, *d_Wtb = nullptr;
     std::vector<double> L;  // host copy of the factor (row-major lower)
     mutable WorkspacePool pool;
-    // k_split.hip: partial sums and tile counters of a launch in flight, one set per stream this handle is used on
-    struct SplitScratch {
-        double* partials = nullptr;
-        unsigned* counters = nullptr;
-    };
-    mutable std::mutex split_mu;
-    mutable std::map<hipStream_t, SplitScratch> split;
+    mcd::SplitHost* split = nullptr;   // k_split.hip: schedules of the row-split form + scratch sets per stream
+    mutable int form = 0;              // MCD_FORM_* chosen for this handle (0: the process default); read with atomic loads
 
     ~mcd_mvn()
     {
@@ -153,10 +147,7 @@ struct mcd_mvn {
         if (d_Ft) (void)hipFree(d_Ft);
         if (d_Ut) (void)hipFree(d_Ut);
         if (d_Wt) (void)hipFree(d_Wt);
-        for (auto& kv : split) {
-            if (kv.second.partials) (void)hipFree(kv.second.partials);
-            if (kv.second.counters) (void)hipFree(kv.second.counters);
-        }
+        mcd::split_host_destroy(split);
         if (d_Wtb) (void)hipFree(d_Wtb);
     }
 };
@@ -293,6 +284,13 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
         HIP_TRY(mcd::prepare_wide());
         HIP_TRY(mcd::prepare_wide_grad());
         HIP_TRY(mcd::prepare_wide_grad_mc());
+        if (n > 128) {                       // row-split form (k_split.hip): below, the sweep's short dependent chain wins
+            hipError_t e = hipSuccess;
+            h->split = mcd::split_host_create(n, h->L.data(), &e);
+            HIP_TRY(e);
+        }
+        h->dev.split = h->split;
+        h->dev.form = &h->form;
     }
     *out = h.release();
     return MCD_OK;
@@ -306,6 +304,13 @@ int mcd_set_logpdf_form(int form)
     return mcd::set_logpdf_form(form);
 }
 
+int mcd_mvn_set_form(const mcd_mvn_t* h, int form)
+{
+    if (!h) return fail(MCD_ERR_INVALID_ARG, "mcd_mvn_set_form: NULL handle");
+    if (form < MCD_FORM_AUTO || form > MCD_FORM_MULTIPLY) return fail(MCD_ERR_INVALID_ARG, "mcd_mvn_set_form: unknown form");
+    return __atomic_exchange_n(&h->form, form, __ATOMIC_RELAXED);
+}
+
 int mcd_mvn_dim(const mcd_mvn_t* h) { return h ? h->n : fail(MCD_ERR_INVALID_ARG, "mcd_mvn_dim: NULL handle"); }
 int mcd_mvn_device(const mcd_mvn_t* h) { return h ? h->device : fail(MCD_ERR_INVALID_ARG, "mcd_mvn_device: NULL handle"); }
 double mcd_mvn_logdet(const mcd_mvn_t* h) { return h ? h->logdet : std::nan(""); }
@@ -317,31 +322,9 @@ int mcd_mvn_get_factor(const mcd_mvn_t* h, double* L_out)
     return MCD_OK;
 }
 
-// One batched log-density launch on `st`: the row-split kernel inside its window (it needs the per-stream scratch of this
-// handle, created on first use -- outside any stream capture), otherwise the sweep / k_wide choice of launch_logpdf.
 static int launch_logpdf_any(const mcd_mvn* h, const double* X, int64_t ld, int64_t batch, double* ll, hipStream_t st)
 {
-    if (!mcd::use_split(h->dev, batch)) {
-        HIP_TRY(mcd::launch_logpdf(h->dev, X, ld, batch, ll, st));
-        return MCD_OK;
-    }
-    mcd_mvn::SplitScratch s;
-    {
-        std::lock_guard<std::mutex> lock(h->split_mu);
-        auto it = h->split.find(st);
-        if (it == h->split.end()) {
-            mcd_mvn::SplitScratch fresh;
-            HIP_TRY(hipMalloc((void**)&fresh.partials, mcd::kSplitScratchDoubles * sizeof(double)));
-            if (hipError_t e = hipMalloc((void**)&fresh.counters, mcd::kSplitCounters * sizeof(unsigned))) {
-                (void)hipFree(fresh.partials);
-                HIP_TRY(e);
-            }
-            HIP_TRY(hipMemset(fresh.counters, 0, mcd::kSplitCounters * sizeof(unsigned)));   // (synchronous: ordered before any launch)
-            it = h->split.emplace(st, fresh).first;
-        }
-        s = it->second;
-    }
-    HIP_TRY(mcd::launch_logpdf_split(h->dev, X, ld, batch, ll, s.partials, s.counters, st));
+    HIP_TRY(mcd::launch_logpdf(h->dev, X, ld, batch, ll, st));
     return MCD_OK;
 }
 

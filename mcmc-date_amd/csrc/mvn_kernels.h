@@ -19,6 +19,20 @@ struct MvnDev {
     const double* Ut;       // backward factor L[i][r]/L[r][r], same layout, NP*NP
     const double* Wt;       // W = L^-1 as 16 x 4 MFMA operand tiles (host_factor.h: pack_w_tiles), for k_wide.hip
     const double* Wtb;      // the tiles of W^T for the gradient's second product (k_wide_grad.hip)
+    const struct SplitHost* split;   // HOST pointer (never dereferenced on the device): schedules + scratch of the row-split form (k_split.hip)
+    const int* form;        // HOST pointer: this handle's form override (MCD_FORM_*; 0 = the process default), mcd_mvn_set_form
+};
+
+// Row-split multiply form (k_split.hip).  One tile stream per (handle, G): the row blocks of W = L^-1 dealt to G row groups of
+// 8 waves, every group's tiles packed in the order its waves consume them (host_factor.cpp: build_split_schedule; the
+// schedule itself is arithmetic, split_sched.hpp).
+constexpr int SP_MAXSEG = 10;                 // segments (runs of k tiles inside one row block) per wave, at most
+struct SplitSched {
+    int G;                  // row groups per 16-chain tile (0: this variant does not exist for the handle's N)
+    int nc;                 // 256-column chunks of the residuals a workgroup stages (ceil(16 NB / 256))
+    int NB;                 // row blocks of 16 rows
+    const double* Ws;       // tile streams of all groups (device)
+    int base[32];           // first tile of group g's stream
 };
 
 // Topology tables of the time/rate trees (pre-order node ids, root = 0).
@@ -107,14 +121,20 @@ hipError_t launch_grad_wide_mc(const MvnDev& M, const double* X, int64_t ldx, in
 hipError_t launch_tree_grad_wide_mc(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                     const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu,
                                     hipStream_t st);
-// Row blocks of W split over 8 workgroups per chain tile (k_split.hip): 192 < N <= 256 up to 1024 chains, 128 < N <= 192 up to 128 chains, automatic form only.
-// scratch: kSplitScratchDoubles doubles, counter: kSplitCounters zero-initialised unsigned, both owned by the call's stream.
+// Row blocks of W split over G workgroups per chain tile (k_split.hip): N > 128 up to 1024 chains, raw x and tree states.
+// The cross-workgroup scratch (G x 16 partial sums and a counter per tile) is taken from the handle's pool (M.split), one set
+// per stream, or per (capture, stream) while a stream is being captured.
 constexpr int64_t kSplitMaxBatch = 1024;
-constexpr size_t kSplitScratchDoubles = (kSplitMaxBatch / 16) * 8 * 16;
+constexpr int kSplitMaxG = 32;
+constexpr size_t kSplitScratchDoubles = (kSplitMaxBatch / 16) * kSplitMaxG * 16;
 constexpr size_t kSplitCounters = kSplitMaxBatch / 16;
+SplitHost* split_host_create(int n, const double* L_rowmajor, hipError_t* err);   // schedules on the current device + scratch pool
+void split_host_destroy(SplitHost* s);
 bool use_split(const MvnDev& M, int64_t batch);
-hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* scratch, unsigned* counter,
-                               hipStream_t st);
+hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
+hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                    const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st);
+int effective_form(const MvnDev& M);   // MCD_FORM_* in force for this handle
 hipError_t prepare_wide();            // per-device attribute set-up of the multiply-form kernels (current device)
 hipError_t prepare_wide_grad();
 hipError_t prepare_wide_grad_mc();

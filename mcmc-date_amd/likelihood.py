@@ -216,6 +216,18 @@ class MvnLikelihood:
         except Exception:
             pass
 
+    def set_form(self, form: str) -> str:
+        """Pin the form of the log-density kernels for THIS handle ("auto": follow the process default, "sweep",
+        "multiply"); mcd_mvn_set_form.  Returns the previous choice."""
+        if form not in FORMS:
+            raise ValueError(f"set_form: expected one of {sorted(FORMS)}, got {form!r}")
+        if self._nodata:
+            return "auto"
+        prev = _capi.lib().mcd_mvn_set_form(self._h, FORMS[form])
+        if prev < 0:
+            _capi.check(prev)
+        return {v: k for k, v in FORMS.items()}[prev]
+
     @property
     def logdet_sigma(self) -> float:
         return 0.0 if self._nodata else float(_capi.lib().mcd_mvn_logdet(self._h))

@@ -232,3 +232,19 @@ def test_nuts_control_flow_on_an_analytic_target():
     assert np.all(np.abs(x.mean(axis=0)) < 0.06 * sds * 4), x.mean(axis=0) / sds
     assert np.all(np.abs(x.std(axis=0) / sds - 1.0) < 0.08), x.std(axis=0) / sds
     assert 2.5 < np.mean(depths) <= 7.0                     # the widest coordinate needs long trajectories
+
+
+def test_split_schedule_selftest():
+    """The schedule of the row-split form (csrc/host_factor.cpp: build_split_schedule) is host code: the library walks it on
+    the CPU for a random residual vector -- tile runs, whole and cut row blocks, the fixed-order combination, the tile pairs
+    as the kernel loads them -- and must find |W r|^2.  No GPU involved."""
+    import ctypes as C
+
+    L = C.CDLL(M._capi.LIB_PATH)
+    f = L.mcd_split_schedule_selftest_
+    f.restype = C.c_double
+    f.argtypes = [C.c_int, C.c_int, C.c_uint]
+    for n in (1, 15, 16, 17, 129, 160, 192, 193, 255, 256, 257, 300, 384, 500, 512, 513, 700, 768, 1000, 1021, 1023, 1024):
+        for G in (8, 16, 32):
+            err = f(n, G, 7 * n + G)
+            assert 0.0 <= err <= 1e-14, (n, G, err)
