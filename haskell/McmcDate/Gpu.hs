@@ -74,16 +74,19 @@ foreign import ccall unsafe "mcd_last_error"
 foreign import ccall unsafe "mcd_set_logpdf_form"
   c_set_logpdf_form :: CInt -> IO CInt
 
+-- | The same choice for ONE likelihood handle (0 = follow the process default); returns the previous value.
+foreign import ccall unsafe "mcd_mvn_set_form"
+  c_mvn_set_form :: Ptr McdMvn -> CInt -> IO CInt
+
 check :: String -> CInt -> IO ()
 check _ 0 = pure ()
 check ctx _ = c_last_error >>= peekCString >>= \m -> error (ctx <> ": " <> m)
 
 -- | Pre-order parent array of a tree (root = 0, parent of the root = -1): the order of 'branches'.
 parents :: T.Tree e a -> [Int32]
-parents t = go (-1) 0 t `seq` reverse (snd (walk (-1) (0, []) t))
+parents t = reverse (snd (walk (-1) (0, []) t))
   where
     walk p (i, acc) (T.Node _ _ ts) = foldl (walk i) (i + 1, p : acc) ts
-    go _ _ _ = ()
 
 -- | Stage mu, Sigma^-1 and log det Sigma on GPU @dev@ once (replaces 'getLikelihoodFunction',
 -- app/Main.hs:333-347) and bind the topology of the mean tree.
