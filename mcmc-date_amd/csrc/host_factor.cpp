@@ -47,6 +47,24 @@ static void tri_lower_inverse(int n, const std::vector<double>& C, std::vector<d
     }
 }
 
+bool precision_factors(int n, const std::vector<double>& P, std::vector<double>& W, std::vector<double>& L)
+{
+    // P = W^T W with W lower triangular: the Cholesky factor of P with rows and columns reversed, reversed back and
+    // transposed (J P J = C C^T, W = J C^T J).  No matrix is inverted on the way to W -- the factor the multiply-form kernels
+    // stream -- so its error is that of one Cholesky factorisation; L = W^-1 (Sigma = L L^T), which the column sweeps
+    // stream, costs one triangular inversion: errors grow with cond(W) = sqrt(cond(P)), not with cond(P)^2 as through
+    // Sigma = P^-1 followed by a second factorisation.
+    std::vector<double> R((size_t)n * n), C;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) R[(size_t)i * n + j] = P[(size_t)(n - 1 - i) * n + (n - 1 - j)];
+    if (!cholesky_lower(n, R, C)) return false;
+    W.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) W[(size_t)i * n + j] = C[(size_t)(n - 1 - j) * n + (n - 1 - i)];
+    tri_lower_inverse(n, W, L);
+    return true;
+}
+
 bool spd_inverse(int n, const std::vector<double>& P, std::vector<double>& S)
 {
     std::vector<double> C, W;
@@ -163,10 +181,8 @@ void build_split_schedule(int n, int G, const std::vector<double>& W, SplitSched
     out.Ws.resize(out.Ws.size() + 128, 0.0);                       // one zero pair: the clamped prefetch of an empty run reads it
 }
 
-void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt, std::vector<double>& Wtb)
+void pack_w_tiles(int n, const std::vector<double>& W, std::vector<double>& Wt, std::vector<double>& Wtb)
 {
-    std::vector<double> W;
-    invert_factor(n, L, W);
     const int NB = (n + 15) / 16;
     Wt.assign((size_t)2 * NB * (NB + 1) * 64, 0.0);
     for (int ib = 0; ib < NB; ++ib)

@@ -8,6 +8,9 @@ namespace mcd {
 
 // Lower Cholesky factor of a symmetric matrix (row-major n x n).  false if not positive definite.
 bool cholesky_lower(int n, const std::vector<double>& A, std::vector<double>& L);
+// From a symmetric positive definite PRECISION matrix P = Sigma^-1: W lower triangular with W^T W = P (so |W dx|^2 is the
+// quadratic form) and L = W^-1 (Sigma = L L^T), without inverting P.  false if P is not positive definite.
+bool precision_factors(int n, const std::vector<double>& P, std::vector<double>& W, std::vector<double>& L);
 // Inverse of a symmetric positive definite matrix through its Cholesky factor.
 bool spd_inverse(int n, const std::vector<double>& P, std::vector<double>& S);
 // Offset of element (row, col) in the pair-interleaved column layout the kernels stream
@@ -17,13 +20,13 @@ size_t packed_index(int R, int row, int col);
 void pack_factors(int n, int R, const std::vector<double>& L, std::vector<double>& mu_pad, const double* mu,
                   std::vector<double>& invdiag, std::vector<double>& Ft, std::vector<double>& Ut);
 
-// W = L^-1 (row-major lower triangular) as the operand tiles k_wide.hip streams: row block ib (16 rows) holds the
+// W = L^-1 (row-major lower triangular, given) as the operand tiles k_wide.hip streams: row block ib (16 rows) holds the
 // k tiles kt = 0 .. 4 (ib + 1) - 1 (4 columns each) at tile index 2 ib (ib + 1) + kt; a tile is 64 doubles in lane
 // order, lane l = W[16 ib + (l & 15)][4 kt + (l >> 4)] (the A operand of v_mfma_f64_16x16x4_f64); zeros above the
 // diagonal and beyond n.
 // Wtb: the same for the transposed product y = W^T z (k_wide_grad.hip): row block ib holds the k tiles kt = 4 ib ..
 // 4 NB - 1 at tile index 4 (ib NB - ib (ib - 1) / 2) + (kt - 4 ib), lane l = W[4 kt + (l >> 4)][16 ib + (l & 15)].
-void pack_w_tiles(int n, const std::vector<double>& L, std::vector<double>& Wt, std::vector<double>& Wtb);
+void pack_w_tiles(int n, const std::vector<double>& W, std::vector<double>& Wt, std::vector<double>& Wtb);
 // W = L^-1, row-major lower triangular, long double accumulation.
 void invert_factor(int n, const std::vector<double>& L, std::vector<double>& W);
 

@@ -439,7 +439,7 @@ static hipError_t split_allow_lds()
     return hipFuncSetAttribute((const void*)k_split<NC, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes<NC>());
 }
 
-SplitHost* split_host_create(int n, const double* L_rowmajor, hipError_t* err)
+SplitHost* split_host_create(int n, const double* W_rowmajor, hipError_t* err)
 {
     *err = hipSuccess;
     SplitHost* s = new SplitHost();
@@ -452,8 +452,7 @@ SplitHost* split_host_create(int n, const double* L_rowmajor, hipError_t* err)
     if (hipError_t e = hipGetDevice(&s->device)) return fail(e);
     if (hipError_t e = hipStreamCreateWithFlags(&s->init_stream, hipStreamNonBlocking)) return fail(e);
     const int NB = (n + 15) / 16;
-    std::vector<double> L(L_rowmajor, L_rowmajor + (size_t)n * n), W;
-    invert_factor(n, L, W);
+    const std::vector<double> W(W_rowmajor, W_rowmajor + (size_t)n * n);
     const int Gs[3] = {8, 16, 32};
     for (int v = 0; v < 3; ++v) {
         const int G = Gs[v];

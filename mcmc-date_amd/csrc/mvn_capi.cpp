@@ -226,17 +226,20 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
             if (!std::isfinite(a)) return fail(MCD_ERR_INVALID_ARG, "mcd_mvn_create: mat[%d][%d] is not finite", i, j);
             A[(size_t)i * n + j] = 0.5 * (a + b);
         }
-    std::vector<double> sigma;
+    std::unique_ptr<mcd_mvn> h(new mcd_mvn());
+    std::vector<double> W;                               // W = L^-1: the factor of the multiply forms (W^T W = Sigma^-1)
     if (mat_kind == MCD_MAT_SIGMA_INV) {
+        // the reference's own operand (app/Main.hs:240: .data files carry Sigma^-1 and log det Sigma): factored directly,
+        // nothing is inverted twice.  A precision matrix that is not positive definite is refused (the reference would
+        // evaluate its quadratic form all the same; `prepare` never writes one: it aborts unless det Sigma > 0, :231).
         if (!std::isfinite(logdet_sigma)) return fail(MCD_ERR_INVALID_ARG, "mcd_mvn_create: logdet_sigma is not finite");
-        if (!mcd::spd_inverse(n, A, sigma))
+        if (!mcd::precision_factors(n, A, W, h->L))
             return fail(MCD_ERR_NOT_SPD, "mcd_mvn_create: inverse covariance matrix is not positive definite");
     } else {
-        sigma.swap(A);
+        if (!mcd::cholesky_lower(n, A, h->L))
+            return fail(MCD_ERR_NOT_SPD, "mcd_mvn_create: covariance matrix is not positive definite");
+        mcd::invert_factor(n, h->L, W);
     }
-    std::unique_ptr<mcd_mvn> h(new mcd_mvn());
-    if (!mcd::cholesky_lower(n, sigma, h->L))
-        return fail(MCD_ERR_NOT_SPD, "mcd_mvn_create: covariance matrix is not positive definite");
     h->n = n;
     h->R = mcd::padded_blocks(n);
     h->device = device_id;
@@ -274,7 +277,7 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
     h->dev.Ut = h->d_Ut;
     {   // multiply form for large batches (k_wide.hip): W = L^-1 as MFMA operand tiles
         std::vector<double> Wt, Wtb;
-        mcd::pack_w_tiles(n, h->L, Wt, Wtb);
+        mcd::pack_w_tiles(n, W, Wt, Wtb);
         HIP_TRY(hipMalloc((void**)&h->d_Wt, Wt.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(h->d_Wt, Wt.data(), Wt.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void**)&h->d_Wtb, Wtb.size() * sizeof(double)));
@@ -286,7 +289,7 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
         HIP_TRY(mcd::prepare_wide_grad_mc());
         if (n > 128) {                       // row-split form (k_split.hip): below, the sweep's short dependent chain wins
             hipError_t e = hipSuccess;
-            h->split = mcd::split_host_create(n, h->L.data(), &e);
+            h->split = mcd::split_host_create(n, W.data(), &e);
             HIP_TRY(e);
         }
         h->dev.split = h->split;

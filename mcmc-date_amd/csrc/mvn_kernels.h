@@ -128,7 +128,7 @@ constexpr int64_t kSplitMaxBatch = 1024;
 constexpr int kSplitMaxG = 32;
 constexpr size_t kSplitScratchDoubles = (kSplitMaxBatch / 16) * kSplitMaxG * 16;
 constexpr size_t kSplitCounters = kSplitMaxBatch / 16;
-SplitHost* split_host_create(int n, const double* L_rowmajor, hipError_t* err);   // schedules on the current device + scratch pool
+SplitHost* split_host_create(int n, const double* W_rowmajor, hipError_t* err);   // W = L^-1; tile streams on the current device + scratch pool
 void split_host_destroy(SplitHost* s);
 bool use_split(const MvnDev& M, int64_t batch);
 hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
