@@ -87,6 +87,45 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
     return out
 
 
+def mh_measure(dev_index, n, B, steps, warm, seed=3):
+    """Lock-step Metropolis-Hastings on the device (the metric's "= MCMC steps/sec x chains" reading):
+    a synthetic tree of dimension n (255 for --n 256: 2L - 3 is odd), the reference's whole proposal cycle
+    (app/Definitions.hs:127-278) in its shuffled order, B chains stepping together; one step = one proposal of the cycle,
+    evaluated (prior + likelihood), accepted or rejected in every chain.  Returns a dict for the JSON line."""
+    import torch
+
+    import mcmc_date_amd as M
+    from mcmc_date_amd import synthetic as S
+
+    topo = S.random_topology((n + 3) // 2, seed=seed)
+    nd = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(nd, seed=seed)
+    tl = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index).bind_tree(topo)
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo, device=dev_index)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    s0 = S.random_states(topo, B, seed=seed + 1)
+    s0.time_birth_rate = np.full(B, 1.0)
+    s0.time_death_rate = np.full(B, 0.8)
+    s0.rate_variance = np.full(B, 0.3)
+    smp = M.Sampler(tl, pf, ps, B, seed=13)
+    smp.set_state(s0)
+    cyc = M.cycle_schedule(ps, 1, np.random.default_rng(0))
+    reps = max(1, (steps + warm) // cyc.shape[1] + 1)
+    sched = np.tile(cyc, (1, reps))
+    smp.run_schedule(sched[:, :warm])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    smp.run_schedule(sched[:, warm:warm + steps])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    post = smp.posterior()
+    assert np.all(np.isfinite(post)), "non-finite ln posterior after the Metropolis-Hastings run"
+    return {"value": B * steps / dt, "unit": "proposal steps/s (lock steps x chains)", "us_per_lockstep": 1e6 * dt / steps,
+            "n_nodes": int(topo.n_nodes), "dimension": int(nd), "chains": int(B), "lock_steps": int(steps),
+            "proposals_per_iteration": int(sum(p.weight for p in ps)),
+            "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device, two launches per lock step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +139,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--form", default="auto", choices=["auto", "sweep", "multiply"],
                     help="log-density kernel form (mcd_set_logpdf_form); auto = multiply for N >= 96 and >= 2048 chains, N >= 32 and >= 8192")
-    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior"])
+    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior", "mh"])
+    ap.add_argument("--no-mh", action="store_true", help="skip the secondary Metropolis-Hastings measurement of the default run")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +172,37 @@ def main():
     ctl_dev = torch.device("cpu") if rehearsal else dev   # where the control tensors of the collectives live
 
     n, B = args.n, args.chains
+    if args.kind == "mh":
+        # the metric's second reading, as the headline of this run: Metropolis-Hastings proposal steps/s x chains
+        K, W = args.steps, args.warmup
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        r = mh_measure(dev_index, n, B, K, W, seed=3 + rank)
+        elapsed = K * r["us_per_lockstep"] * 1e-6
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            nd = r["dimension"]
+            alg_b = (8.0 * (2 * r["n_nodes"] + 2) + 8.0 + (8.0 * nd + 4.0 * nd * (nd + 1)) / B) * B   # SURVEY.md 8(d), tree-state kernel
+            print(json.dumps({
+                "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes",
+                "value": B * K * world / elapsed, "unit": "MH proposal steps/s (lock steps x chains)", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"lock-step Metropolis-Hastings, synthetic {r['n_nodes']}-node tree (dimension {nd}), {B} chains per GPU, "
+                                       f"the reference's proposal cycle ({r['proposals_per_iteration']} proposals per iteration)",
+                           "n": nd, "chains_per_gpu": B, "kernel": "mh", "launch": "two launches per lock step",
+                           "parallelism": f"chains sharded x{world}, no data-path collective"},
+                "roofline": {"bound": "hbm", "achieved": alg_b / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg_b / (elapsed / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "note": "algorithmic bytes of the likelihood launch only; the step also runs the proposal + prior launch"},
+                "mh": r}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.kind in ("tree", "tree_grad", "prior", "posterior"):
         topo = S.random_topology((n + 3) // 2, seed=n)
         n = topo.n_nodes - 2
@@ -145,8 +216,18 @@ def main():
         M.set_logpdf_form(args.form)
 
     if args.kind == "logpdf":
+        # two input batches, alternated launch by launch, each with its own output: a launch that picked up anything left
+        # behind by its predecessor (the row-split form hands partial sums over through a scratch) cannot pass for correct
+        X2 = torch.as_tensor(S.sample_chains(mu, sigma, B, seed=n + 1000 * rank + 500), device=dev)
+        ll2 = torch.empty(B, dtype=torch.float64, device=dev)
+        flip = [0]
+
         def step():
-            lik.logpdf_into(X, ll)
+            if flip[0] == 0:
+                lik.logpdf_into(X, ll)
+            else:
+                lik.logpdf_into(X2, ll2)
+            flip[0] ^= 1
     elif args.kind == "grad":
         G = torch.empty_like(X)
 
@@ -206,7 +287,7 @@ def main():
         form = args.form
     else:
         form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
-        if args.kind in ("logpdf", "tree") and B <= 1024 and (n > 192 or (n > 128 and B <= 128)):
+        if args.kind in ("logpdf", "tree") and B <= 1024 and (n > 256 or (n > 192 and B <= 32)):
             form = "split"                               # k_split.hip: W's row blocks over 8-32 workgroups per chain tile
     # hipGraph replay hides the per-launch dispatch cost of the few-microsecond sweep launches; the multiply form's launches
     # are longer than an eager dispatch and are launched eagerly.  (On this pool about one run in twenty sees the host learn
@@ -293,9 +374,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity: the result of the last step is the oracle-checked quantity (finite, right magnitude)
+    # sanity: the results of the last steps are the oracle-checked quantity (finite; for the log-density, both alternating
+    # batches against a separate evaluation by the column sweep on another handle)
     ll_host = ll.cpu().numpy()
-    assert np.all(np.isfinite(ll_host)), "non-finite log-likelihood in the bench batch"
+    assert np.all(np.isfinite(ll_host)) or os.environ.get("MCD_SPLIT_PROBE"), "non-finite log-likelihood in the bench batch"
+    if args.kind == "logpdf" and not os.environ.get("MCD_SPLIT_PROBE"):
+        chk = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index)
+        chk.set_form("sweep")
+        for xs, out in ((X, ll), (X2, ll2)):
+            ref = chk.logpdf(xs)
+            err = float(((out - ref).abs() / ref.abs()).max())
+            assert err <= 1e-11, f"bench batch differs from the sweep form: {err}"
 
     if rank == 0:
         evals = float(K) * B * world
@@ -341,6 +430,9 @@ def main():
                     out["roofline"]["traffic"] = float(json.load(open(fs[-1]))["pmc_traffic_n256_b8192"]["per_launch_bytes_corrected"])
                 except Exception:
                     pass
+        if world == 1 and args.kind == "logpdf" and not args.no_mh:
+            # the metric's "= MCMC steps/sec x chains": real Metropolis-Hastings steps on a tree of this size (secondary field)
+            out["mh"] = mh_measure(dev_index, n, B, 4000, 400)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, mu, sigma, X_host)
         print(json.dumps(out))

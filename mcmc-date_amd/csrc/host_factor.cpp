@@ -231,12 +231,12 @@ extern "C" double mcd_split_schedule_selftest_(int n, int G, unsigned seed)
     int fault = 0;
     for (int g = 0; g < G; ++g) {
         const mcd::SpGroup q = mcd::sp_group(NB, G, g);
-        if ((q.per & 3) || (h.base[g] & 3)) return -3.0;
+        if ((h.base[g] & 3) || mcd::sp_run_start(q, mcd::SP_NW) != q.Tg) return -3.0;
         std::vector<std::vector<double>> slot(mcd::SP_NSLOT, std::vector<double>(16, 0.0));
         std::vector<bool> slot_set(mcd::SP_NSLOT, false), used(mcd::SP_NSLOT, false);
         long double ss = 0.0L;
         for (int w = 0; w < mcd::SP_NW; ++w) {
-            int pos = w * q.per;                                                   // stream position of the run's next tile
+            int pos = mcd::sp_run_start(q, w);                                     // stream position of the run's next tile
             int nseg = 0;
             mcd::sp_for_each_segment(NB, G, g, q, w, [&](int k0, int nt, int kind) {
                 if (nt <= 0 || (nt & 3) || (k0 & 3) || kind < 0 || kind > 2) fault = 4;
@@ -261,8 +261,7 @@ extern "C" double mcd_split_schedule_selftest_(int n, int G, unsigned seed)
                     for (int i = 0; i < 16; ++i) slot[sl][i] = acc[i];
                 }
             });
-            const int hi = (w + 1) * q.per < q.Tg ? (w + 1) * q.per : q.Tg;
-            if (pos != (hi > w * q.per ? hi : w * q.per)) fault = 7;
+            if (pos != mcd::sp_run_start(q, w + 1)) fault = 7;
         }
         mcd::sp_for_each_cut(NB, G, g, q, [&](int wf, int wl) {
             if (wf < 0 || wl >= mcd::SP_NW || wl <= wf) {

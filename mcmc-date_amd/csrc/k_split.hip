@@ -54,7 +54,8 @@ constexpr int SP_Z = 256;                                  // doubles of one par
 template <int NC>
 constexpr size_t split_lds_bytes()
 {
-    return (size_t)(16 * (NC * 256 + 2) + SP_NSLOT * SP_Z + SP_NW * 16) * sizeof(double);
+    // NC = 4 fills the CU's 160 KiB: there the per-wave sums go where the residuals were (an extra barrier), not beside them
+    return (size_t)(16 * (NC * 256 + 2) + SP_NSLOT * SP_Z + (NC < 4 ? SP_NW * 64 : 0) + 8) * sizeof(double);
 }
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -62,10 +63,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // diagnostic build (make stamp_split): s_memtime phase stamps of every wave of workgroup 0 and of the workgroup that came
 // last for tile 0, read back with mcd_split_debug_stamps (tools/microbench/split_stamps.py)
 #ifdef MCD_SPLIT_STAMP
-__device__ unsigned long long g_split_dbg[2 * SP_NW * 8];
-#define SP_T(i) do { if (tile == 0 && (grp == 0 || grp == G - 1) && lane == 0) g_split_dbg[((grp == 0 ? 0 : 1) * SP_NW + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_split_dbg[2 * SP_NW * 16];
+// stamps stay in scalar registers until the wave ends (a store per stamp would put waits into the phases being timed)
+#define SP_T(i) do { spt[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SP_T_FLUSH() do { if (tile == 0 && (grp == 0 || grp == G - 1) && lane == 0) { \
+        for (int i_ = 0; i_ < 16; ++i_) g_split_dbg[((grp == 0 ? 0 : 1) * SP_NW + wave) * 16 + i_] = spt[i_]; } } while (0)
 #else
 #define SP_T(i) do { } while (0)
+#define SP_T_FLUSH() do { } while (0)
 #endif
 constexpr int SP_RING = 8;                                 // tile PAIRS in flight per wave (8 KiB)
 
@@ -86,6 +91,8 @@ __device__ __forceinline__ void split_group(const d2* __restrict__ w, d2 (&ring)
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) bn[i] = rk_next[i * 4];
+    // one accumulator: a wave issues a v_mfma_f64_16x16x4_f64 every 64 cycles whether or not it depends on the one before
+    // (tools/microbench/mfma64: 1, 2 or 4 chains alike), and two waves of a SIMD each keep that rate
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH].x, bc[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH].y, bc[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH + 1].x, bc[2], acc, 0, 0, 0);
@@ -123,16 +130,25 @@ __device__ __forceinline__ void split_run(const d2* __restrict__ w, d2 (&ring)[S
     }
 }
 
-// grid = ceil(tiles / 8) * 8 * G; block = 512 threads (8 waves, two per SIMD: one waits for tiles while the other multiplies).
+// grid = ceil(tiles / 8) * 8 * G; block = 576 threads: 8 working waves (two per SIMD) and a helper wave, which takes the
+// group's ticket and works out which row blocks are cut between waves -- a memory round trip and a few hundred scalar
+// instructions that would otherwise sit on the working waves' critical path -- and leaves both in LDS.
+// The helper wave exists where a kernel is a few microseconds long (NC = 1: N <= 256); above, where a ninth wave would cost the
+// other eight a third of their registers, wave 0 does both jobs behind its staging loads.
+template <int NC>
+constexpr int split_threads()
+{
+    return 64 * (SP_NW + (NC == 1 ? 1 : 0));
+}
 template <int NC, bool TREE>
-__global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M, SplitSched S, WideSrc A, int64_t batch, int flags,
+__global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(MvnDev M, SplitSched S, WideSrc A, int64_t batch, int flags,
                                                                         double* __restrict__ ll, double* scratch, unsigned* counter)
 {
     constexpr int LD = NC * 256 + 2;                       // LDS row stride in doubles: = 4 dwords (mod 64 banks)
     extern __shared__ double smem[];
     double* rs = smem;                                     // [16][LD] residuals of the tile's chains
     double* zsum = rs + 16 * LD;                           // [SP_NSLOT][SP_Z] partial z tiles of the blocks cut between waves
-    double* part = zsum + SP_NSLOT * SP_Z;                 // [SP_NW][16]
+    double* part = NC < 4 ? zsum + SP_NSLOT * SP_Z : rs;   // [SP_NW][64] (NC = 4: over the residuals, once every wave is done with them)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = S.G;
@@ -150,29 +166,80 @@ __global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M,
     }
     const int64_t b0 = (int64_t)tile * 16;
     if (b0 >= batch) return;                               // whole workgroup
-    // who will add up the tile's partial sums: the row group that STARTS last (see the header).  The answer travels while
-    // the chain vectors are staged.
-    unsigned ticket = 0;
-    if (wave == 0 && lane == 0) ticket = __hip_atomic_fetch_add(&counter[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MCD_SPLIT_STAMP
+    unsigned long long spt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    int* aux = reinterpret_cast<int*>((NC < 4 ? zsum + SP_NSLOT * SP_Z + SP_NW * 64 : zsum + SP_NSLOT * SP_Z));   // [16]: ticket, cuts
     const int rot = (flags & 2) ? 0 : 2 * grp;             // first chain a group stages (experiment knob: bit 1 = no rotation)
     const int NB = S.NB;
     const SpGroup sg = sp_group(NB, G, grp);               // split_sched.hpp: scalar arithmetic on blockIdx, no table to fetch
-    const int lo = wave * sg.per, hi = (lo + sg.per < sg.Tg) ? lo + sg.per : sg.Tg;
-    const int T = hi > lo ? hi - lo : 0;
+    const bool HELPER = NC == 1 && blockDim.x > 64 * SP_NW;   // (the launcher leaves the helper wave out when two workgroups have to share a CU)
+    // Who will add up the tile's partial sums: the row group that STARTS last (see the header) -- a returning atomic add,
+    // whose answer travels while the chain vectors are staged; and which row blocks are cut between waves.  Both go to LDS.
+    auto ticket_and_cuts = [&]() {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&counter[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ncut = 0, cuts[SP_NW - 1] = {0, 0, 0, 0, 0, 0, 0};
+        sp_for_each_cut(NB, G, grp, sg, [&](int wf, int wl) {
+#pragma unroll
+            for (int x = 0; x < SP_NW - 1; ++x)
+                if (ncut == x) cuts[x] = wf | (wl << 4);
+            ++ncut;
+        });
+        if (lane == 0) {
+            aux[0] = (int)ticket;
+            aux[1] = ncut;
+#pragma unroll
+            for (int x = 0; x < SP_NW - 1; ++x) aux[2 + x] = cuts[x];
+        }
+    };
+    if (HELPER && wave == SP_NW) {                         // the helper wave
+        if (flags & 4) return;
+        ticket_and_cuts();
+        __syncthreads();                                   // staging done (the working waves' first barrier)
+        if (flags & 8) return;
+        __syncthreads();                                   // runs done
+        return;
+    }
+    const int lo = sp_run_start(sg, wave);
+    const int T = sp_run_start(sg, wave + 1) - lo;
     const int ncols = sg.ncols;
     const int col = lane & 15, kq = lane >> 4;
+    if (flags & 4) return;                                 // timing probe (MCD_SPLIT_PROBE): the launch alone
     SP_T(0);
-#ifdef MCD_SPLIT_STAMP
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
 
     // the first tiles of this wave's run are requested before anything else: they travel while the chain vectors do.  Tiles
     // are stored in pairs (lane l: its element of tile 2 i, then of tile 2 i + 1), so one 16-byte load per lane brings two
     const int npair = T >> 1, lastp = npair > 0 ? npair - 1 : 0;
     const d2* __restrict__ w = reinterpret_cast<const d2*>(S.Ws) + (int64_t)((S.base[grp] + lo) >> 1) * 64 + lane;
+    // (N <= 256, where a microsecond counts.  Above, the staging needs the registers -- a ring kept alive across it gets
+    // spilled, and reloaded inside the multiply loop -- and the first tiles are requested once the staging loads are done.)
     d2 ring[SP_RING];
+    if constexpr (NC == 1) {
 #pragma unroll
-    for (int p = 0; p < SP_RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
+        for (int p = 0; p < SP_RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
+    }
+
+    // a run that fits the ring (at most 4 groups of 4 tiles: N <= 352 with 8 row groups) is multiplied by straight-line code
+    // with the ring slots as they stand; what each group needs -- its first k tile, and whether it ends a segment and how --
+    // is worked out here, under the latency of the loads above
+    const bool fits = npair <= SP_RING;
+    int gk[4] = {0, 0, 0, 0}, ge[4] = {-1, -1, -1, -1};
+    if (fits && T > 0) {
+        int gi = 0;
+        sp_for_each_segment(NB, G, grp, sg, wave, [&](int k0, int nt, int kind) {
+            const int ng = nt >> 2;
+            for (int j = 0; j < ng; ++j, ++gi) {
+                const int k = k0 + 4 * j, e = (j == ng - 1) ? kind : -1;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (gi == x) {
+                        gk[x] = k;
+                        ge[x] = e;
+                    }
+            }
+        });
+    }
 
     // ---- stage the residuals
     if constexpr (!TREE) {
@@ -194,6 +261,7 @@ __global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M,
                 v[c][i] = rowp[kc];
             }
         }
+        if (!HELPER && wave == 0) ticket_and_cuts();       // behind the loads: its wait coincides with theirs
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int k = c * 256 + tc;
@@ -247,6 +315,7 @@ __global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M,
                 rrr[jj] = r[rr];
                 sc[jj] = A.tH[b] * A.rMu[b];
             }
+            if (!HELPER && wave == 0 && j0 == 0) ticket_and_cuts();   // behind the loads: its wait coincides with theirs
 #pragma unroll
             for (int jj = 0; jj < CB; ++jj) {
                 const int ch = (8 * (j0 + jj) + wave + rot) & 15;
@@ -281,15 +350,58 @@ __global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M,
             }
         }
     }
+    if constexpr (NC > 1) {
+#pragma unroll
+        for (int p = 0; p < SP_RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
+    }
     SP_T(1);
     __syncthreads();
+    if (flags & 8) return;                                 // timing probe: launch + staging
 
     // ---- this wave's run of tiles: z tile += W tile x R tile, segment after segment.  A segment (a run of k tiles inside
     // one row block) is a whole number of groups of 4 tiles = 2 ring slots; the ring has SP_RING slots, so a group's slots
     // are known at compile time once its phase (group index mod SP_RING / 2) is: split_run is instantiated per starting phase
     double ss = 0.0;                                       // sum of squares of the blocks this wave holds completely
     SP_T(2);
-    if (T > 0) {
+    auto flush = [&](d4& acc, int kind) {                  // a segment ends: square a whole block, park a partial z tile
+        if (kind == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ss = fma(acc[q], acc[q], ss);
+        } else {
+            double* zs = zsum + (kind == 1 ? 2 * wave - 1 : 2 * wave) * SP_Z;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zs[(kq + 4 * q) * 16 + col] = acc[q];            // f64 result layout: row = (lane >> 4) + 4 reg
+        }
+        acc = d4{0.0, 0.0, 0.0, 0.0};
+    };
+    if (fits) {
+        if (T > 0) {
+            const double* rb = rs + col * LD + kq;
+            const int ngr = T >> 2;
+            double b[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[g][i] = rb[(gk[g] + i) * 4];              // (groups past the end read k tile 0 and drop it)
+            }
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            SP_T(8);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g == 1) SP_T(9);
+                if (g == 2) SP_T(10);
+                if (g == 3) SP_T(11);
+                if (g < ngr) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * g].x, b[g][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * g].y, b[g][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * g + 1].x, b[g][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * g + 1].y, b[g][3], acc, 0, 0, 0);
+                    if (ge[g] >= 0) flush(acc, ge[g]);
+                }
+            }
+            SP_T(12);
+        }
+    } else if (T > 0) {
         const double* rb = rs + col * LD + kq;
         int jp = 0, ph = 0;                                // pair index of the next tile pair to be used, its phase
         sp_for_each_segment(NB, G, grp, sg, wave, [&](int k0, int nt, int kind) {
@@ -304,43 +416,60 @@ __global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M,
             }
             jp += 2 * ng;
             ph = (ph + ng) & (SP_RING / 2 - 1);
-            if (kind == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ss = fma(acc[q], acc[q], ss);
-            } else {
-                double* zs = zsum + (kind == 1 ? 2 * wave - 1 : 2 * wave) * SP_Z;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) zs[(kq + 4 * q) * 16 + col] = acc[q];        // f64 result layout: row = (lane >> 4) + 4 reg
-            }
+            flush(acc, kind);
         });
     }
     SP_T(3);
+    if constexpr (NC >= 4) __syncthreads();
+    part[wave * 64 + lane] = ss;                           // the blocks this wave squared itself: lane = (chain, row quarter)
     __syncthreads();
 
-    // ---- the blocks cut between waves: thread = (row, chain) of the z tile, contributions added in wave order (256 threads)
-    if (tid < SP_Z) {
-        sp_for_each_cut(NB, G, grp, sg, [&](int wf, int wl) {
-            double z = zsum[2 * wf * SP_Z + tid];
-            for (int x = wf + 1; x <= wl; ++x) z += zsum[(2 * x - 1) * SP_Z + tid];
-            ss = fma(z, z, ss);
-        });
+    // ---- everything else happens in wave 0 (one barrier instead of three): lane = (chain col, row quarter kq), the layout of
+    // the MFMA result.  First the whole blocks of the eight waves, then the blocks cut between waves: the partial z tiles are
+    // added in wave order, squared, and added over the lane's four rows; all in a fixed order.
+    if (wave != 0) {
+        SP_T_FLUSH();
+        return;
     }
-    // both layouts keep a chain on lane & 15: the rows of a chain sit on lanes 16 apart, then on the waves
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
-    if (lane < 16) part[wave * 16 + lane] = ss;
-    __syncthreads();
-
-    SP_T(4);
-    // ---- hand-over (see the header): all of it inside wave 0
-    if (wave == 0) {
-        unsigned long long* slots = reinterpret_cast<unsigned long long*>(scratch) + (int64_t)tile * G * 16;
-        double q = 0.0;
-        if (lane < 16) {
+    SP_T(13);
+    double tot = 0.0;
+    {
+        double pv[SP_NW];
 #pragma unroll
-            for (int x = 0; x < SP_NW; ++x) q += part[x * 16 + lane];
+        for (int x = 0; x < SP_NW; ++x) pv[x] = part[x * 64 + lane];
+#pragma unroll
+        for (int x = 0; x < SP_NW; ++x) tot += pv[x];
+    }
+    const int ncut = aux[1];
+#pragma unroll 1
+    for (int ci = 0; ci < ncut; ++ci) {
+        const int cw = aux[2 + ci], wf = cw & 15, wl = cw >> 4;
+        double z[4];
+        const double* z0 = zsum + 2 * wf * SP_Z + kq * 16 + col;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] = z0[64 * q];
+        for (int x = wf + 1; x <= wl; ++x) {               // partial z tiles in wave order
+            const double* zx = zsum + (2 * x - 1) * SP_Z + kq * 16 + col;
+            double t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = zx[64 * q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] += t[q];
         }
-        ticket = __builtin_amdgcn_readfirstlane(ticket);   // uses the value the add returned (long since)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tot = fma(z[q], z[q], tot);
+    }
+    SP_T(14);
+    // the four row quarters of a chain sit on the lanes col, col + 16, col + 32, col + 48
+    tot += __shfl_xor(tot, 16);
+    tot += __shfl_xor(tot, 32);
+    SP_T(4);
+    if (flags & 16) return;                                // timing probe: everything but the hand-over
+    // ---- hand-over (see the header): all of it inside wave 0
+    {
+        unsigned long long* slots = reinterpret_cast<unsigned long long*>(scratch) + (int64_t)tile * G * 16;
+        const double q = tot;
+        const unsigned ticket = (unsigned)__builtin_amdgcn_readfirstlane(aux[0]);   // taken by the helper wave at the start
         const bool reader = ticket == (unsigned)(G - 1);   // every other group of the tile had started before this one
         if (!reader) {
             if (lane < 16) {
@@ -383,9 +512,7 @@ __global__ void __launch_bounds__(64 * SP_NW, NC <= 1 ? 4 : 2) k_split(MvnDev M,
             if (lane == 0) __hip_atomic_store(&counter[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         SP_T(6);
-#ifdef MCD_SPLIT_STAMP
-        if (tile == 0 && (grp == 0 || grp == G - 1) && lane == 0) g_split_dbg[((grp == 0 ? 0 : 1) * SP_NW + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;
-#endif
+        SP_T_FLUSH();
     }
 }
 
@@ -556,12 +683,14 @@ static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch,
     int scatter = env ? (atoi(env) & 1) : 0;
     env = getenv("MCD_SPLIT_NOROT");
     if (env && atoi(env)) scatter |= 2;
+    env = getenv("MCD_SPLIT_PROBE");                       // timing probes (results are then garbage): 4 launch only, 8 + staging, 16 all but the hand-over
+    if (env) scatter |= atoi(env) & 28;
 
     const int64_t tiles = (batch + 15) / 16;
     const unsigned grid = (scatter & 1) ? (unsigned)(tiles * S.G) : (unsigned)(((tiles + 7) / 8) * 8 * S.G);
-    const dim3 block(64 * SP_NW);
+    
 #define MCD_SPLIT_LAUNCH(NC_) \
-    hipLaunchKernelGGL((k_split<NC_, TREE>), dim3(grid), block, split_lds_bytes<NC_>(), st, M, S, A, batch, scatter, ll, set.partials, set.counters)
+    hipLaunchKernelGGL((k_split<NC_, TREE>), dim3(grid), dim3(tiles * S.G <= 256 ? split_threads<NC_>() : 64 * SP_NW), split_lds_bytes<NC_>(), st, M, S, A, batch, scatter, ll, set.partials, set.counters)
     switch (S.nc) {
     case 1: MCD_SPLIT_LAUNCH(1); break;
     case 2: MCD_SPLIT_LAUNCH(2); break;
@@ -600,6 +729,6 @@ hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const dou
 #ifdef MCD_SPLIT_STAMP
 extern "C" int mcd_split_debug_stamps(unsigned long long* out)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_split_dbg), sizeof(unsigned long long) * 2 * mcd::SP_NW * 8);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_split_dbg), sizeof(unsigned long long) * 2 * mcd::SP_NW * 16);
 }
 #endif

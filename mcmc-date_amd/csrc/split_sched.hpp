@@ -5,7 +5,8 @@
 // W = L^-1 has NB = ceil(N / 16) row blocks of 16 rows; block b holds the k tiles 0 .. 4 (b + 1) - 1 (4 columns each).
 // G row groups per 16-chain tile.  Round r deals the blocks r G .. r G + G - 1 to the groups forwards (r even) or backwards
 // (r odd), so every group gets small and large blocks alike.  A group's tiles -- block after block in ascending order, k
-// ascending inside a block -- form one stream of Tg tiles, cut into SP_NW runs of `per` tiles (a multiple of 4), one per wave.
+// ascending inside a block -- form one stream of Tg tiles = Tg / 4 groups of 4, dealt to the SP_NW waves as evenly as whole
+// groups allow (the first `rem` waves take one group more): one contiguous run per wave.
 // Inside a run, the tiles of one block are a SEGMENT {first k tile, tiles, kind}: kind 0 = the wave holds the whole block
 // and squares the z tile itself; otherwise the block is cut between waves and the wave's partial z tile goes to an LDS slot:
 // kind 1 = the run begins inside the block (slot 2 w - 1), kind 2 = the run begins with the block but ends inside it (slot
@@ -27,28 +28,42 @@ constexpr int SP_NSLOT = 2 * SP_NW - 2;   // LDS slots for partial z tiles
 
 struct SpGroup {
     int Tg;      // tiles of the group
-    int per;     // tiles per wave (multiple of 4)
+    int base;    // groups of 4 tiles per wave: the first `rem` waves take base + 1, the others base
+    int rem;
     int ncols;   // residual columns the group needs: 16 (last block + 1)
 };
 
 SP_HD SpGroup sp_group(int NB, int G, int g)
 {
-    SpGroup q{0, 0, 0};
+    SpGroup q{0, 0, 0, 0};
     for (int r = 0; r * G < NB; ++r) {
         const int b = sp_block(G, g, r);
         if (b >= NB) continue;                            // only the last round can be short
         q.Tg += 4 * (b + 1);
         q.ncols = 16 * (b + 1);
     }
-    q.per = (((q.Tg + SP_NW - 1) / SP_NW) + 3) & ~3;
+    q.base = (q.Tg >> 2) / SP_NW;
+    q.rem = (q.Tg >> 2) - q.base * SP_NW;
     return q;
+}
+
+// first tile of wave w's run (w = SP_NW: the end of the stream)
+SP_HD int sp_run_start(const SpGroup& q, int w) { return 4 * (w * q.base + (w < q.rem ? w : q.rem)); }
+
+// the wave whose run holds stream position pos (0 <= pos < Tg); no division: the device has none
+SP_HD int sp_wave_of(const SpGroup& q, int pos)
+{
+    int w = 0;
+#pragma unroll
+    for (int x = 1; x < SP_NW; ++x) w += (sp_run_start(q, x) <= pos && sp_run_start(q, x) < q.Tg) ? 1 : 0;
+    return w;
 }
 
 // f(k0, nt, kind) for every segment of wave `wave` of group `g`, in stream order
 template <class F>
 SP_HD void sp_for_each_segment(int NB, int G, int g, const SpGroup& q, int wave, F&& f)
 {
-    const int lo = wave * q.per, hi = (lo + q.per < q.Tg) ? lo + q.per : q.Tg;
+    const int lo = sp_run_start(q, wave), hi = sp_run_start(q, wave + 1);
     int s = 0;
     for (int r = 0; r * G < NB; ++r) {
         const int b = sp_block(G, g, r);
@@ -70,7 +85,7 @@ SP_HD void sp_for_each_cut(int NB, int G, int g, const SpGroup& q, F&& f)
         const int b = sp_block(G, g, r);
         if (b >= NB) continue;
         const int e = s + 4 * (b + 1);
-        const int wf = s / q.per, wl = (e - 1) / q.per;
+        const int wf = sp_wave_of(q, s), wl = sp_wave_of(q, e - 1);
         if (wl > wf) f(wf, wl);
         s = e;
     }

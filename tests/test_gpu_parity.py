@@ -160,7 +160,7 @@ def test_synthetic_logpdf_and_grad(gpu, n, batch):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ll)
     ll2, G = lik.grad(X)
-    if (n > 192 and batch <= 1024) or (128 < n <= 192 and batch <= 128):
+    if (n > 256 and batch <= 1024) or (192 < n <= 256 and batch <= 32):
         assert np.all(np.abs(ll2 - ll) <= tol)               # log-density: row-split kernel (k_split.hip); gradient: sweeps
     else:
         assert np.array_equal(ll2, ll)
@@ -170,12 +170,15 @@ def test_synthetic_logpdf_and_grad(gpu, n, batch):
 
 
 @pytest.mark.parametrize("n,batch", [(193, 64), (200, 65), (224, 130), (255, 1000), (256, 512), (256, 1024), (241, 77), (256, 1), (230, 5), (199, 17), (129, 1), (160, 100), (192, 128)])
-def test_row_split_form(gpu, n, batch):
-    """192 < N <= 256 with up to 1024 chains (128 < N <= 192: up to 128): W's row blocks split over 8 workgroups per chain tile, partial sums added by
-    the last row group to arrive (k_split.hip).  Oracle bound of the sweeps, ragged tiles, padded rows, repeatable bits,
-    the same bits from the host-pointer path (another stream, another scratch) and from concurrent callers."""
+def test_row_split_form(gpu, n, batch, monkeypatch):
+    """128 < N <= 256 through the row-split form (k_split.hip; forced here with MCD_SPLIT=1 -- the automatic choice takes it at
+    these sizes only up to 32 chains, see tests/test_gpu_split.py for N > 256): W's row blocks split over 8 workgroups per chain
+    tile, partial sums added by the row group that started last.  Oracle bound of the sweeps, ragged tiles, padded rows,
+    repeatable bits, the same bits from the host-pointer path (another stream, another scratch) and from concurrent callers."""
     import threading
     import torch
+
+    monkeypatch.setenv("MCD_SPLIT", "1")
 
     mu, sigma = S.random_spd_problem(n, seed=n)
     X = S.sample_chains(mu, sigma, batch, seed=n + 7)

@@ -41,6 +41,14 @@ class env:
                 os.environ[k] = v
 
 
+@pytest.fixture(autouse=True)
+def split_wherever_possible():
+    """The automatic choice takes the row split above N = 256 (192 < N <= 256: up to 32 chains); these tests exercise it over
+    its whole range (N > 128, up to 1024 chains): MCD_SPLIT=1, read per launch."""
+    with env(MCD_SPLIT=1):
+        yield
+
+
 def problem(n, batch, seed):
     mu, sigma = S.random_spd_problem(n, seed=seed)
     X = S.sample_chains(mu, sigma, batch, seed=seed + 7)
@@ -112,8 +120,7 @@ def test_row_split_tree_states(gpu, leaves, batch):
     tl.mvn.set_form("auto")
     assert np.max(np.abs(ll - ll_s) / np.abs(ll_s)) <= 1e-12
     assert np.array_equal(lj, lj_s)                          # the same arithmetic for the Jacobian
-    if n > 192 or batch <= 128:
-        assert not np.array_equal(ll, ll_s)                  # really the other kernel
+    assert not np.array_equal(ll, ll_s)                      # really the other kernel
     with env(MCD_SPLIT_G=16, MCD_SPLIT_SCATTER=1):
         ll_g, lj_g = tl.loglik(st)
     assert np.max(np.abs(ll_g - ll_s) / np.abs(ll_s)) <= 1e-12 and np.array_equal(lj_g, lj)

@@ -37,18 +37,19 @@ for it in range(reps + 5):
         else:
             lik.logpdf_into(X, out)
     torch.cuda.synchronize()
-    st = np.zeros(128, dtype=np.uint64)
+    st = np.zeros(256, dtype=np.uint64)
     L.mcd_split_debug_stamps(st.ctypes.data)
-    st = st.reshape(16, 8).astype(np.int64)
+    st = st.reshape(16, 16).astype(np.int64)
     if it >= 5:
         d = np.diff(st[:, :7], axis=1)
         ok = (d > 0) & (d < 10**7)
         acc += np.where(ok, d, 0)
         cnt += ok
 acc /= np.maximum(cnt, 1)
-rt = st[[0, 8], 7]
-tot = st[[0, 8], 6] - st[[0, 8], 0]
-print("last launch, wave 0 of the two groups: %s cycles in %s ticks of 10 ns -> clock %.2f / %.2f GHz" % (tot, rt, tot[0] / rt[0] / 10.0, tot[1] / rt[1] / 10.0))
+fine = st[:, [2, 8, 9, 10, 11, 12, 3, 13, 14, 4, 5, 6]]
+print("last launch, fine stamps (cycles since the barrier): B reads issued | group 1 | group 2 | group 3 | runs done | T3 | after barrier (wave 0) | cut blocks done | T4 | T5 | T6")
+for i in range(16):
+    print("  group %s wave %d: %s" % ("0  " if i < 8 else "G-1", i % 8, "  ".join("%6d" % (v - fine[i, 0]) for v in fine[i, 1:])))
 print("cycles per phase [n=%d chains=%d%s]: sched | stage | barrier | mfma | combine | store+add | read+ll" % (n, B, " tree" if tree else ""))
 for g in range(2):
     for w in range(8):
