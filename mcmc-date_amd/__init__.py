@@ -11,7 +11,7 @@ from .likelihood import (Full, LikelihoodData, MvnLikelihood, set_logpdf_form, N
 from .hmc import DualAveraging, Leapfrog, hmc_transition, nuts_transition, nuts_warmup, run_cycle_with_nuts
 from .hamiltonian import from_vector_with, get_mask, grad_to_vector, target_grad, to_vector
 from .prior import (Brace, Calibration, Constraint, PriorFunction, get_mean_root_height, load_braces,
-                    load_calibrations, load_constraints, prior_function)
+                    load_calibrations, load_calibrations_from_tree, load_constraints, prior_function)
 from .sampler import MC3, Proposal, Sampler, cycle_schedule, init_with, proposals, table_arrays, weight_n_branches
 from .state import State, StateBatch
 from .tree import (Topology, TreeError, branch_slots, get_branches, height_tree_to_length_tree, parse_newick,
@@ -22,7 +22,7 @@ __all__ = [
     "likelihood_function", "jacobian_root_branch", "read_data_file", "write_data_file", "set_logpdf_form",
     "State", "StateBatch", "Topology", "TreeError", "parse_newick", "read_newick_file", "get_branches",
     "sum_first_two", "branch_slots", "height_tree_to_length_tree",
-    "Calibration", "Constraint", "Brace", "PriorFunction", "prior_function", "load_calibrations", "load_constraints",
+    "Calibration", "Constraint", "Brace", "PriorFunction", "prior_function", "load_calibrations", "load_calibrations_from_tree", "load_constraints",
     "load_braces", "get_mean_root_height",
     "MC3", "Proposal", "Sampler", "cycle_schedule", "init_with", "proposals", "table_arrays", "weight_n_branches",
     "Leapfrog", "hmc_transition", "nuts_transition", "nuts_warmup", "run_cycle_with_nuts", "DualAveraging", "get_mask", "to_vector", "from_vector_with", "grad_to_vector", "target_grad",

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
         const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
         const double lp1 = M.post1[b], ll1 = M.post1[B + b], lj1 = M.post1[2 * B + b];
         double la = M.beta[b] * ((lp1 + ll1) - (lp + ll)) + M.lnqj[b];     // heated chains of MC3: posterior^beta; beta = 1 is exact
-        if (jac_root_acc) la += lj1 - lj;
+        if (jac_root_acc) la += (double)jac_root_acc * (lj1 - lj);   // +1: jf(y) / jf(x); -1 (experiments): the reciprocal
         double ua, ub;
         philox_block(mh_rng(seed, M.chain0 + b, step_acc), 0xFFFFFFFFu, ua, ub);
         ok = (la >= 0) || (ua < exp(la));

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
         }
         MH_TICK(3)
         double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
-        if (row.jac_root) la += lj1 - lj;
+        if (row.jac_root) la += (double)row.jac_root * (lj1 - lj);
         const bool ok = (la >= 0) || (dr.Uacc < exp(la));
         if (ok) {
             Hc[lane] = Hp[lane];

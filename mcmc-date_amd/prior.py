@@ -11,6 +11,7 @@ from __future__ import annotations
 import csv
 import ctypes as C
 import json
+import re
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -90,6 +91,66 @@ def load_calibrations(topo: Topology, path: str) -> List[Calibration]:
             if p is not None and not (0 < p < 1):
                 raise ValueError("probabilityMass: Zero or negative, or 1.0 or larger.")
         out.append(Calibration(r[0], mrca(topo, r[1], r[2]), lo, lop or 0.0, hi, hip or 0.0))
+    nodes = [c.node for c in out]
+    if len(set(nodes)) != len(nodes):
+        raise ValueError("loadCalibrations: Duplicate/conflicting/redundant calibrations have been detected.")
+    return out
+
+
+_MCMCTREE_BOUND = re.compile(r"^\s*([LUB])\(([^()]*)\)\s*$")
+
+
+def load_calibrations_from_tree(topo: Topology, path: str) -> List[Calibration]:
+    """`loadCalibrationsFromTree` -- lib/Mcmc/Tree/Prior/Node/CalibrationFromTree.hs:119-130: calibrations given as node
+    labels of a Newick tree in MCMCtree's notation (only L, U and B; PAML manual p. 49):
+      'L(lower[, cauchyP, cauchyC[, p]])'  lower bound (the two Cauchy parameters are ignored, :29-46),
+      'U(upper[, p])'                      upper bound (:49-63),
+      'B(lower, upper[, pLower[, pUpper]])' both (:66-87);
+    a missing probability mass defaults to 0.01 (`defPM`, :94-97).  A labelled node is identified by its leftmost and its
+    rightmost leaf (`filterBoundedNodes`, :111-123) and looked up in the analysis' own rooted tree `topo` as their most
+    recent common ancestor (`checkAndConvertCalibrationData`); its name is "leafA-leafB"."""
+    from .tree import read_newick_file
+
+    ctopo, _ = read_newick_file(path)[0]
+    kids = [[] for _ in range(ctopo.n_nodes)]
+    for v in range(1, ctopo.n_nodes):
+        kids[int(ctopo.parent[v])].append(v)
+
+    def edge_leaf(v: int, last: bool) -> str:
+        while kids[v]:
+            v = kids[v][-1 if last else 0]
+        return ctopo.names[v]
+
+    out = []
+    for v in range(ctopo.n_nodes):
+        m = _MCMCTREE_BOUND.match(ctopo.names[v])
+        if not m:                                        # any other label (leaf names included) is not a calibration
+            continue
+        try:
+            nums = [float(x) for x in m.group(2).split(",")]
+        except ValueError:
+            continue
+        kind = m.group(1)
+        lo = lop = hi = hip = None
+        if kind == "L" and 1 <= len(nums) <= 4:
+            lo, lop = nums[0], (nums[3] if len(nums) == 4 else None)
+        elif kind == "U" and 1 <= len(nums) <= 2:
+            hi, hip = nums[0], (nums[1] if len(nums) == 2 else None)
+        elif kind == "B" and 2 <= len(nums) <= 4:
+            lo, hi = nums[0], nums[1]
+            lop = nums[2] if len(nums) >= 3 else None
+            hip = nums[3] if len(nums) == 4 else None
+        else:
+            continue
+        lop = 0.01 if (lo is not None and lop is None) else lop          # defPM
+        hip = 0.01 if (hi is not None and hip is None) else hip
+        for p in (lop, hip):
+            if p is not None and not (0 < p < 1):
+                raise ValueError("probabilityMass: Zero or negative, or 1.0 or larger.")
+        a, b = edge_leaf(v, False), edge_leaf(v, True)
+        out.append(Calibration(f"{a}-{b}", mrca(topo, a, b), lo, lop or 0.0, hi, hip or 0.0))
+    if not out:
+        raise ValueError(f"loadCalibrationsFromTree: no calibrations found in file: {path}")
     nodes = [c.node for c in out]
     if len(set(nodes)) != len(nodes):
         raise ValueError("loadCalibrations: Duplicate/conflicting/redundant calibrations have been detected.")

@@ -42,7 +42,7 @@ class Proposal:
     p1: float = 0.0          # second parameter (scaleContrarily: gamma scale; scaleVarianceAndTree: 1 = exact Jacobian)
     n1: int = 0
     n2: int = 0
-    jac_root: bool = False   # liftProposalWith jacobianRootBranch (the "[R]" proposals)
+    jac_root: int = 0        # liftProposalWith jacobianRootBranch (the "[R]" proposals): 1 = ratio jf(y) / jf(x) joins the acceptance ratio (-1: its reciprocal, experiments only)
     dim: int = 1             # PDimension
     weight: int = 1          # PWeight
 

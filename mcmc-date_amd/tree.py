@@ -86,10 +86,14 @@ def parse_newick(s: str):
         parent.append(par)
         length.append(0.0)
         names.append("")
+        while s[pos] == " ":
+            pos += 1
         if s[pos] == "(":
             pos += 1
             while True:
                 node(me)
+                while s[pos] == " ":
+                    pos += 1
                 if s[pos] == ",":
                     pos += 1
                 elif s[pos] == ")":
@@ -97,10 +101,20 @@ def parse_newick(s: str):
                     break
                 else:
                     raise TreeError(f"newick: unexpected {s[pos]!r} at {pos}")
-        st = pos
-        while s[pos] not in ":,();":
+        while s[pos] == " ":
             pos += 1
-        names[me] = s[st:pos].strip()
+        if s[pos] == "'":                         # quoted label, e.g. MCMCtree's 'B(6,8,2.5e-2,2.5e-2)': commas and brackets inside
+            st = pos + 1
+            pos = s.index("'", st)
+            names[me] = s[st:pos]
+            pos += 1
+            while s[pos] == " ":
+                pos += 1
+        else:
+            st = pos
+            while s[pos] not in ":,();":
+                pos += 1
+            names[me] = s[st:pos].strip()
         if s[pos] == ":":
             pos += 1
             st = pos

@@ -505,7 +505,7 @@ int orm_run(const orm_model *M, int64_t batch, double *birth, double *death, dou
                 propose(M, size, p, tune[b * P + p], &x, &y, &g, &lnq, &lnj);
                 posterior(M, &y, &lp1, &ll1, &lj1);
                 double la = (beta ? beta[b] : 1.0) * ((lp1 + ll1) - (lp + ll)) + lnq + lnj;   /* MC3: posterior^beta */
-                if (M->jac_root[p]) la += lj1 - lj;
+                if (M->jac_root[p]) la += (double)M->jac_root[p] * (lj1 - lj);
                 rng_block(&g, 0xFFFFFFFFu, ua);
                 const int ok = (la >= 0) || (ua[0] < exp(la));   /* NaN compares false => reject */
                 if (trace_alpha) trace_alpha[gs * batch + b] = la;

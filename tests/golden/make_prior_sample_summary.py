@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Build tests/golden/mtCDNApri_prior_samples.json from the reference's own prior-only runs (build container only).
+
+The reference ships the node ages sampled by six independent `mcmc-date-run run` chains WITHOUT data
+(`./run -s -f analysis.conf -c ul n r`: calibrations from the MCMCtree-style tree, uncorrelated log-normal clock, no
+likelihood; bench/comparison_with_mcmctree/README.md:615-632) as
+bench/comparison_with_mcmctree/03_compare_estimates/prior_samples_run{1..6}.tsv: 4850 rows each = the last 75 % of the
+monitored iterations (period 2; burn-in with auto tuning 4930 iterations, then 8000), columns = the inner nodes 0 1 2 3 5 9 of
+the rooted tree in pre-order, ages in the calibrations' time unit.  These are outputs of the reference itself, the only ones
+in the repository that depend on nothing but the prior, the proposal cycle and its Jacobians -- rows f1 + f2 of SURVEY.md 8(f).
+
+Committed: summary statistics (data, not source) -- per run and pooled mean, standard deviation and 2.5 / 50 / 97.5 %
+quantiles per node, the between-run standard deviation of the run means -- and the three small INPUT files of that analysis
+(rooted tree, calibration tree, the ten PhyloBayes trees `prepare` averages for the initial state), verbatim, so that the GPU
+test needs nothing outside the repository.
+"""
+import json
+import os
+
+import numpy as np
+
+REF = "/root/reference/bench/comparison_with_mcmctree"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    runs = []
+    for i in range(1, 7):
+        a = np.loadtxt(os.path.join(REF, "03_compare_estimates", f"prior_samples_run{i}.tsv"), skiprows=1)
+        assert a.shape == (4850, 7)
+        runs.append(a[:, 1:])
+    header = open(os.path.join(REF, "03_compare_estimates", "prior_samples_run1.tsv")).readline().split()[1:]
+    nodes = [int(x) for x in header]
+    allr = np.concatenate(runs)
+
+    def stats(a):
+        q = np.quantile(a, [0.025, 0.5, 0.975], axis=0)
+        return {"mean": a.mean(axis=0).tolist(), "sd": a.std(axis=0, ddof=1).tolist(), "q025": q[0].tolist(), "q50": q[1].tolist(),
+                "q975": q[2].tolist()}
+
+    run_means = np.array([r.mean(axis=0) for r in runs])
+    run_q = np.array([np.quantile(r, [0.025, 0.975], axis=0) for r in runs])
+    d = os.path.join(REF, "02_McmcDate", "01_McmcDate", "data")
+    out = {
+        "source": "dschrempf/mcmc-date bench/comparison_with_mcmctree/03_compare_estimates/prior_samples_run{1..6}.tsv (README.md:615-632)",
+        "command": "./run -s -f analysis.conf -c ul n r   (calibrations, UncorrelatedLogNormal, NoData)",
+        "nodes": nodes, "rows_per_run": 4850, "pooled": stats(allr), "runs": [stats(r) for r in runs],
+        "between_run_sd_of_mean": run_means.std(axis=0, ddof=1).tolist(),
+        "between_run_sd_of_q025": run_q[:, 0].std(axis=0, ddof=1).tolist(),
+        "between_run_sd_of_q975": run_q[:, 1].std(axis=0, ddof=1).tolist(),
+        "inputs": {"rooted_tree": open(os.path.join(d, "pb_rooted_mitCDNApri.tree")).read(),
+                   "calibration_tree": open(os.path.join(d, "mtCDNApri_MD.trees")).read(),
+                   "tree_list": open(os.path.join(d, "unr_lg_g5_ncat1.treelist")).read()},
+    }
+    with open(os.path.join(HERE, "mtCDNApri_prior_samples.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("nodes", nodes)
+    print("pooled mean", np.round(out["pooled"]["mean"], 3))
+    print("between-run sd of the mean", np.round(out["between_run_sd_of_mean"], 3))
+    print("pooled q025", np.round(out["pooled"]["q025"], 3), "q975", np.round(out["pooled"]["q975"], 3))
+
+
+if __name__ == "__main__":
+    main()

@@ -248,3 +248,34 @@ def test_split_schedule_selftest():
         for G in (8, 16, 32):
             err = f(n, G, 7 * n + G)
             assert 0.0 <= err <= 1e-14, (n, G, err)
+
+
+def test_load_calibrations_from_tree(tmp_path):
+    """`loadCalibrationsFromTree` (lib/Mcmc/Tree/Prior/Node/CalibrationFromTree.hs:119-130) on the reference's own
+    mtCDNApri analysis (bench/comparison_with_mcmctree/02_McmcDate/01_McmcDate/data/mtCDNApri_MD.trees; inputs kept in
+    tests/golden/mtCDNApri_prior_samples.json): MCMCtree's B / U labels on a Newick tree with quoted labels, nodes found as the
+    MRCA of the labelled node's leftmost and rightmost leaf -- the pre-order indices 0, 1, 3 the reference's own result table
+    names (README.md:641-645) --, default probability mass 0.01, the L form with its ignored Cauchy parameters, no label at all."""
+    import json
+
+    from mcmc_date_amd.prepare import prepare
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "mtCDNApri_prior_samples.json")))
+    paths = {}
+    for k in ("rooted_tree", "calibration_tree", "tree_list"):
+        paths[k] = str(tmp_path / k)
+        open(paths[k], "w").write(fx["inputs"][k])
+    prep = prepare(paths["tree_list"], paths["rooted_tree"], "NoLikelihood")
+    topo = prep.topology
+    assert [i for i in range(topo.n_nodes) if not topo.leaves[i]] == fx["nodes"] == [0, 1, 2, 3, 5, 9]
+    cal = M.load_calibrations_from_tree(topo, paths["calibration_tree"])
+    got = sorted((c.node, c.name, c.lower, c.lower_p, c.upper, c.upper_p) for c in cal)
+    assert got == [(0, "human-gibbon", None, 0.0, 100.0, 0.025), (1, "human-sumatran", 12.0, 0.025, 16.0, 0.025),
+                   (3, "human-bonobo", 6.0, 0.025, 8.0, 0.025)]
+    assert M.get_mean_root_height(cal) == 50.0                      # getMeanRootHeight: (0 + 100) / 2
+    other = str(tmp_path / "other.tree")
+    open(other, "w").write("(((human,(chimpanzee,bonobo))'L(5)',gorilla)'L(9,0.1,1.0,0.05)',(orangutan,sumatran)'U(20)',gibbon)'B(10,90)';")
+    got = sorted((c.node, c.lower, c.lower_p, c.upper, c.upper_p) for c in M.load_calibrations_from_tree(topo, other))
+    assert got == [(0, 10.0, 0.01, 90.0, 0.01), (2, 9.0, 0.05, None, 0.0), (3, 5.0, 0.01, None, 0.0), (9, None, 0.0, 20.0, 0.01)]
+    with pytest.raises(ValueError):
+        M.load_calibrations_from_tree(topo, paths["rooted_tree"])      # no calibrations found
