@@ -78,6 +78,21 @@ foreign import ccall unsafe "mcd_set_logpdf_form"
 foreign import ccall unsafe "mcd_mvn_set_form"
   c_mvn_set_form :: Ptr McdMvn -> CInt -> IO CInt
 
+-- | The path's one exchange across GPUs (one process per GPU): an all-gather of per-chain values over the ranks' chain
+-- shards, RCCL behind the C ABI (no RCCL binding needed here).  Rank 0 draws the 128-byte id, every rank creates the
+-- communicator with it (collective), then one all-gather per swap period (MC3: SwapPeriod 2, app/Main.hs:477).
+foreign import ccall unsafe "mcd_shard_unique_id"
+  c_shard_unique_id :: Ptr CChar -> IO CInt
+
+foreign import ccall safe "mcd_shard_comm_create"
+  c_shard_comm_create :: Ptr (Ptr ()) -> CInt -> CInt -> Ptr CChar -> CInt -> IO CInt
+
+foreign import ccall unsafe "mcd_shard_comm_destroy"
+  c_shard_comm_destroy :: Ptr () -> IO ()
+
+foreign import ccall unsafe "mcd_shard_allgather"
+  c_shard_allgather :: Ptr () -> Ptr CDouble -> Ptr CDouble -> Int64 -> Ptr () -> IO CInt
+
 check :: String -> CInt -> IO ()
 check _ 0 = pure ()
 check ctx _ = c_last_error >>= peekCString >>= \m -> error (ctx <> ": " <> m)

@@ -305,6 +305,25 @@ int mcd_mh_set_temperatures(mcd_mh_t* m, const double* beta);
 int mcd_mh_get_age_sums(const mcd_mh_t* m, double* age_sum, double* age_sq, int64_t* n_samples);
 int mcd_mh_reset_age_sums(mcd_mh_t* m);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU.  Chains are independent: every rank (one process per GPU) holds the operands and evaluates its own
+ * contiguous block of chains; nothing is exchanged on the likelihood path.  The sampler-level exchange -- the per-chain ln
+ * posterior that MC3's swap phase compares (`mc3 (MC3Settings (NChains 4) (SwapPeriod 2) (NSwaps 3))`, app/Main.hs:476-478; in
+ * the reference an in-process matter of `mcmc`), diagnostics -- is ONE all-gather per swap period:
+ *   mcd_shard_allgather   recv[r * count + i] = send of rank r, element i; device pointers, enqueued on `stream`
+ *                         (RCCL ncclAllGather over xGMI; a few KB per rank, latency bound -- no ring of small sends);
+ *   mcd_mh_posterior_device  the sampler's device-resident [3][batch] ln prior / ln likelihood / ln Jacobian, what to send.
+ * RCCL is loaded at run time; the communicator is made by the wrappers below, so that a host in the reference's language
+ * needs no RCCL binding: rank 0 draws an id (mcd_shard_unique_id), hands its MCD_SHARD_ID_BYTES bytes to the other ranks'
+ * processes by its own means, every rank calls mcd_shard_comm_create (collective: returns when all ranks have called).
+ */
+#define MCD_SHARD_ID_BYTES 128
+int mcd_shard_unique_id(char id[MCD_SHARD_ID_BYTES]);
+int mcd_shard_comm_create(void** comm, int world_size, int rank, const char id[MCD_SHARD_ID_BYTES], int device_id);
+void mcd_shard_comm_destroy(void* comm);
+int mcd_shard_allgather(void* comm, const double* send, double* recv, int64_t count, void* stream);
+int mcd_mh_posterior_device(const mcd_mh_t* m, const double** post, void** stream);
+
 #ifdef __cplusplus
 }
 #endif

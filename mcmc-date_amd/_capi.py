@@ -62,6 +62,11 @@ SYMBOLS = {
     "mcd_hmc_get_position": (C.c_int, [_vp, _dp, _dp, _dp]),
     "mcd_hmc_leapfrog": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.c_int]),
     "mcd_hmc_step_from": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "mcd_shard_unique_id": (C.c_int, [C.c_char_p]),
+    "mcd_shard_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "mcd_shard_comm_destroy": (None, [_vp]),
+    "mcd_shard_allgather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "mcd_mh_posterior_device": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "mcd_mh_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
     "mcd_mh_destroy": (None, [_vp]),
     "mcd_mh_set_chain_offset": (C.c_int, [_vp, C.c_int64]),

@@ -305,6 +305,14 @@ int mcd_mh_get_posterior(const mcd_mh_t* cm, double* post)
     return MCD_OK;
 }
 
+int mcd_mh_posterior_device(const mcd_mh_t* cm, const double** post, void** stream)
+{
+    if (!cm || !post) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_posterior_device: NULL argument");
+    *post = cm->dev.post;                      // [3][batch]: ln prior, ln likelihood, ln jacobianRootBranch of the current states
+    if (stream) *stream = (void*)cm->stream;   // the stream the sampler's launches are ordered on
+    return MCD_OK;
+}
+
 int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, int accumulate, double* trace_alpha,
                int8_t* trace_accept)
 {

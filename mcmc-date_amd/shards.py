@@ -88,3 +88,58 @@ def shard_sampler(tree_lik, prior, table, n_chains: int, seed: int, shard: Chain
     from .sampler import Sampler
 
     return Sampler(tree_lik, prior, table, shard.size, seed, first_chain=shard.lo)
+
+
+class ShardComm:
+    """The C ABI's communicator (include/mcmcdate_mvn.h: mcd_shard_*; RCCL's ncclAllGather bound at run time) -- what a host in
+    the reference's language would use.  The unique id is drawn by rank 0 and handed to the other ranks through `exchange`, a
+    callable bytes -> bytes that broadcasts rank 0's argument (default: torch.distributed's object broadcast when a process
+    group exists; with one rank nothing is exchanged)."""
+
+    def __init__(self, shard: ChainShard, device: int = 0, exchange=None):
+        import ctypes as C
+
+        from . import _capi
+
+        self.shard = shard
+        self._lib = _capi.lib()
+        buf = C.create_string_buffer(128)
+        if shard.rank == 0:
+            _capi.check(self._lib.mcd_shard_unique_id(buf))
+        ident = buf.raw
+        if shard.world > 1:
+            if exchange is None:
+                import torch.distributed as dist
+
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                ident = box[0]
+            else:
+                ident = exchange(ident)
+        self._comm = C.c_void_p()
+        _capi.check(self._lib.mcd_shard_comm_create(C.byref(self._comm), shard.world, shard.rank, ident, int(device)))
+
+    def allgather(self, send, stream=None):
+        """send: 1-D float64 CUDA tensor, the same length on every rank; returns [world * len] in rank order."""
+        import ctypes as C
+
+        import torch
+
+        from . import _capi
+
+        send = send.contiguous()
+        out = torch.empty(self.shard.world * send.numel(), dtype=torch.float64, device=send.device)
+        st = C.c_void_p(torch.cuda.current_stream(send.device).cuda_stream if stream is None else stream)
+        _capi.check(self._lib.mcd_shard_allgather(self._comm, C.c_void_p(send.data_ptr()), C.c_void_p(out.data_ptr()), send.numel(), st))
+        return out
+
+    def close(self):
+        if getattr(self, "_comm", None) is not None and self._comm.value:
+            self._lib.mcd_shard_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

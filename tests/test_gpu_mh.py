@@ -464,3 +464,51 @@ def test_prior_only_node_ages_against_the_references_own_samples(gpu, tmp_path):
             assert dev[exact][5] <= 0.03, dev[exact]                       # node 9 (not calibrated)
             assert ref["mean"][0] < mean[0] < 27.0, mean                   # the root: between the reference and a cycle without the lift
     assert np.all(dev[False] <= dev[True] + 0.002), (dev[False], dev[True])   # the reference's samples side with its own Jacobians
+
+
+def test_shard_allgather_through_rccl(gpu, golden):
+    """The path's one exchange step on hardware: the C ABI's all-gather (mcd_shard_*: RCCL loaded at run time,
+    communicator made from a unique id, ncclAllGather on the sampler's stream) of the device-resident per-chain ln posterior of
+    a sampler -- with the one rank a one-GPU box allows, so that the RCCL code path has run once: the gathered values are
+    the sampler's own.  The same through torch.distributed's nccl backend (what shards.py and bench.py --gpus N use).  The
+    N > 1 logic (ragged shards, global chain order, the same chains whatever the number of ranks) is covered by the
+    world-size-2 gloo tests (tests/test_shards_gloo.py)."""
+    import ctypes as C
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from mcmc_date_amd import shards
+
+    topo, ps, smp, twin = setup(golden["12-leaves-variable-rate"], B=64, seed=5)
+    smp.run(2)
+    post = smp.posterior()                                              # host copy [B, 3]
+    lib = M._capi.lib()
+    dptr, st = C.c_void_p(), C.c_void_p()
+    M._capi.check(lib.mcd_mh_posterior_device(smp._h, C.byref(dptr), C.byref(st)))
+    comm = shards.ShardComm(shards.ChainShard(0, 1, 64))
+    send = torch.empty(3 * 64, dtype=torch.float64, device=gpu)
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(send.data_ptr()), dptr, 3 * 64 * 8, 3)   # device to device
+    out = comm.allgather(send)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(3, 64).T, post)
+    # straight from the sampler's device array, on the sampler's stream
+    out2 = torch.zeros(3 * 64, dtype=torch.float64, device=gpu)
+    M._capi.check(lib.mcd_shard_allgather(comm._comm, dptr, C.c_void_p(out2.data_ptr()), 3 * 64, st))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    comm.close()
+    assert lib.mcd_shard_allgather(None, dptr, C.c_void_p(out2.data_ptr()), 1, None) == M._capi.MCD_ERR_INVALID_ARG
+    # torch.distributed over RCCL, one rank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        g = torch.empty(64, dtype=torch.float64, device=gpu)
+        dist.all_gather_into_tensor(g, send[64:128].contiguous())
+        torch.cuda.synchronize()
+        assert np.array_equal(g.cpu().numpy(), post[:, 1])
+        assert torch.equal(shards.gather_loglik(send[64:128], shards.ChainShard(0, 1, 64)), send[64:128])
+    finally:
+        dist.destroy_process_group()
