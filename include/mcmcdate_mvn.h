@@ -214,7 +214,21 @@ int mcd_prior_grad_batch(const mcd_prior_t* p, const double* birth, const double
  *   mcd_hmc_leapfrog       n_steps leapfrog steps with per-chain step size eps[b], per-chain direction dir[b] = +-1 (NULL
  *                          = forward) and diagonal inverse masses inv_mass[dim]; p [batch][dim] in/out (host)
  * A state that leaves the support gets NaN gradients; its momentum and ln target turn NaN (the caller rejects).
- * The NUTS recursion and its tuning (package `mcmc`) are the caller's: they are not part of this library yet.
+ *
+ * The proposal itself -- `nuts` of the package `mcmc` (`nutsWith`, app/Hamiltonian.hs:95-105; not vendored), restated from the
+ * algorithm it implements, Hoffman & Gelman (2014), Algorithm 3 -- runs on the device for all chains in lock step (k_nuts.hip:
+ * slice variable, doubling in a random direction, U-turn and divergence stops, uniform choice among the admissible leaves;
+ * one round = the two gradient launches + one launch that finishes the leapfrog step, books the leaf and sends the next one
+ * on its way; the host only polls a counter):
+ *   mcd_hmc_nuts        one transition from the handle's state with per-chain step sizes eps[batch] and inverse masses
+ *                       inv_mass[dim]; random streams: Philox (seed, chain_offset + b, transition) -- a chain's draw does not
+ *                       depend on the batch it runs in; out: mean acceptance statistic alpha[batch], tree depth[batch]
+ *   mcd_hmc_nuts_run    n transitions; adapt != 0: dual averaging of the step sizes towards the acceptance statistic delta
+ *                       (Algorithm 6; eps in: starting value, out: the averaged value); mean_alpha[batch]; q_mean / q_var[dim]:
+ *                       position means and variances pooled over chains and transitions (what a mass adaptation needs:
+ *                       the reference tunes `HTuneLeapfrog HTuneAllMasses`, app/Hamiltonian.hs:62-63).
+ * `mcmc`'s own defaults and tuning schedule are not available here: parity of this part rests on the CPU twin
+ * (tests/test_gpu_nuts.py) and on the agreement with Metropolis-Hastings chains.
  */
 typedef struct mcd_hmc mcd_hmc_t;
 int mcd_hmc_create(mcd_hmc_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int calibrations_available, int64_t batch);
@@ -226,6 +240,10 @@ int mcd_hmc_get_state(const mcd_hmc_t* m, double* birth, double* death, double* 
                       double* rVar, double* rates, int64_t ld_state);
 int mcd_hmc_get_position(const mcd_hmc_t* m, double* q, double* value, double* grad);
 int mcd_hmc_leapfrog(mcd_hmc_t* m, double* p, const double* eps, const double* dir, const double* inv_mass, int n_steps);
+int mcd_hmc_nuts(mcd_hmc_t* m, const double* eps, const double* inv_mass, int max_depth, uint64_t seed, int64_t chain_offset,
+                 uint64_t transition, double* alpha, int32_t* depth);
+int mcd_hmc_nuts_run(mcd_hmc_t* m, int n_transitions, int adapt, double* eps, const double* inv_mass, double delta, int max_depth,
+                     uint64_t seed, int64_t chain_offset, uint64_t first_transition, double* mean_alpha, double* q_mean, double* q_var);
 /* One leapfrog step from ARBITRARY phase points (what a NUTS tree needs: it extends either end of a trajectory):
  * q, p, grad [batch][dim] in/out (host), value [batch] out (ln target at the new point, may be NULL).  have_grad = 0:
  * the gradient at q is evaluated first (grad is output only).  The handle's own state becomes the new point. */

@@ -67,6 +67,8 @@ SYMBOLS = {
     "mcd_shard_comm_destroy": (None, [_vp]),
     "mcd_shard_allgather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "mcd_mh_posterior_device": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mcd_hmc_nuts": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp, _ip]),
+    "mcd_hmc_nuts_run": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp, _dp, _dp]),
     "mcd_mh_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
     "mcd_mh_destroy": (None, [_vp]),
     "mcd_mh_set_chain_offset": (C.c_int, [_vp, C.c_int64]),

@@ -41,6 +41,8 @@ struct mcd_hmc {
     const mcd::PriorDev* prior = nullptr;
     mcd::HmcDev dev{};
     double *d_eps = nullptr, *d_dir = nullptr, *d_inv_mass = nullptr;
+    mcd::NutsDev nuts{};           // allocated by the first NUTS transition (mcd_hmc_nuts)
+    int* d_active = nullptr;
     bool have_state = false;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
@@ -218,13 +220,15 @@ int mcd_hmc_leapfrog(mcd_hmc_t* m, double* p, const double* eps, const double* d
         D.dir = nullptr;
     }
     // p += eps/2 g;  [ q += eps Minv p;  g = grad(q);  p += eps g ] x (n - 1);  q += eps Minv p;  g = grad(q);  p += eps/2 g
+    // three launches per step (kick + drift fused, prior gradient, likelihood gradient), the closing half kick with the collect
     for (int s = 0; s < n_steps; ++s) {
-        HHIP_TRY(mcd::launch_hmc_kick(D, (s == 0) ? 0.5 : 1.0, 0, m->stream));
-        HHIP_TRY(mcd::launch_hmc_drift(D, m->stream));
+        HHIP_TRY(mcd::launch_hmc_kick_drift(D, (s == 0) ? 0.5 : 1.0, m->stream));
         if (int rc = eval_gradients(m)) return rc;
     }
-    if (n_steps > 0) HHIP_TRY(mcd::launch_hmc_kick(D, 0.5, 0, m->stream));
-    HHIP_TRY(mcd::launch_hmc_collect(D, m->stream));
+    if (n_steps > 0)
+        HHIP_TRY(mcd::launch_hmc_kick_collect(D, 0.5, m->stream));
+    else
+        HHIP_TRY(mcd::launch_hmc_collect(D, m->stream));
     HHIP_TRY(hipMemcpyAsync(p, D.p, sizeof(double) * BD, hipMemcpyDeviceToHost, m->stream));
     HHIP_TRY(hipStreamSynchronize(m->stream));
     return MCD_OK;
@@ -266,6 +270,137 @@ int mcd_hmc_step_from(mcd_hmc_t* m, double* q, double* p, double* grad, int have
     HHIP_TRY(hipMemcpyAsync(grad, D.grad, sizeof(double) * BD, hipMemcpyDeviceToHost, m->stream));
     if (value) HHIP_TRY(hipMemcpyAsync(value, D.value, sizeof(double) * B, hipMemcpyDeviceToHost, m->stream));
     HHIP_TRY(hipStreamSynchronize(m->stream));
+    return MCD_OK;
+}
+
+}  // extern "C"
+
+// ---- NUTS (k_nuts.hip) ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kNutsMaxDepth = 12;
+
+int nuts_alloc(mcd_hmc* m)
+{
+    if (m->nuts.qm) return MCD_OK;
+    const mcd::HmcDev& D = m->dev;
+    const size_t B = (size_t)D.batch, BD = B * (size_t)D.dim;
+    mcd::NutsDev& N = m->nuts;
+    N.max_depth = kNutsMaxDepth;
+    int rc = MCD_OK;
+    double** pd[] = {&N.qm, &N.pm, &N.gm, &N.qp, &N.pp, &N.gp, &N.qc, &N.gc, &N.qn, &N.gn};
+    for (double** p : pd)
+        if ((rc = halloc(m, p, BD))) return rc;
+    if ((rc = halloc(m, &N.sq, BD * kNutsMaxDepth)) || (rc = halloc(m, &N.sp, BD * kNutsMaxDepth))) return rc;
+    double** pb[] = {&N.lpc, &N.lpn, &N.log_u, &N.joint0, &N.alpha};
+    for (double** p : pb)
+        if ((rc = halloc(m, p, B))) return rc;
+    int** pi[] = {&N.j, &N.v, &N.i, &N.n, &N.n1, &N.s1, &N.done, &N.n_alpha, &N.depth, &N.leaf};
+    for (int** p : pi)
+        if ((rc = halloc(m, p, B))) return rc;
+    return halloc(m, &m->d_active, 1);
+}
+
+// one transition for every chain; eps and inv_mass already on the device
+int nuts_transition(mcd_hmc* m, int max_depth, uint64_t seed, int64_t chain0, uint64_t transition)
+{
+    mcd::HmcDev& D = m->dev;
+    D.dir = m->d_dir;
+    HHIP_TRY(mcd::launch_nuts_begin(D, m->nuts, seed, chain0, transition, m->stream));
+    const int64_t max_rounds = (int64_t)1 << max_depth;               // 2^max_depth - 1 leaves at most
+    for (int64_t r = 0; r < max_rounds; ++r) {
+        if (int rc = eval_gradients(m)) return rc;
+        HHIP_TRY(hipMemsetAsync(m->d_active, 0, sizeof(int), m->stream));
+        HHIP_TRY(mcd::launch_nuts_step(D, m->nuts, seed, chain0, transition, max_depth, m->d_active, m->stream));
+        int active = 0;
+        HHIP_TRY(hipMemcpyAsync(&active, m->d_active, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HHIP_TRY(hipStreamSynchronize(m->stream));
+        if (active == 0) break;
+    }
+    HHIP_TRY(mcd::launch_nuts_end(D, m->nuts, m->stream));
+    return MCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcd_hmc_nuts(mcd_hmc_t* m, const double* eps, const double* inv_mass, int max_depth, uint64_t seed, int64_t chain_offset,
+                 uint64_t transition, double* alpha, int32_t* depth)
+{
+    if (!m || !eps || !inv_mass) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts: NULL argument");
+    if (!m->have_state) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts: call mcd_hmc_set_state first");
+    if (max_depth < 1 || max_depth > kNutsMaxDepth) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts: max_depth must be 1 .. %d", kNutsMaxDepth);
+    mcd::HmcDev& D = m->dev;
+    const size_t B = (size_t)D.batch;
+    for (int k = 0; k < D.dim; ++k)
+        if (!(inv_mass[k] > 0) || !std::isfinite(inv_mass[k])) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts: inverse masses must be positive");
+    for (size_t b = 0; b < B; ++b)
+        if (!(eps[b] > 0) || !std::isfinite(eps[b])) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts: step sizes must be positive");
+    HHIP_TRY(hipSetDevice(m->device));
+    if (int rc = nuts_alloc(m)) return rc;
+    HHIP_TRY(hipMemcpyAsync(m->d_eps, eps, sizeof(double) * B, hipMemcpyHostToDevice, m->stream));
+    HHIP_TRY(hipMemcpyAsync(m->d_inv_mass, inv_mass, sizeof(double) * D.dim, hipMemcpyHostToDevice, m->stream));
+    if (int rc = nuts_transition(m, max_depth, seed, chain_offset, transition)) return rc;
+    std::vector<double> a(B);
+    std::vector<int> na(B), dp(B);
+    HHIP_TRY(hipMemcpyAsync(a.data(), m->nuts.alpha, sizeof(double) * B, hipMemcpyDeviceToHost, m->stream));
+    HHIP_TRY(hipMemcpyAsync(na.data(), m->nuts.n_alpha, sizeof(int) * B, hipMemcpyDeviceToHost, m->stream));
+    HHIP_TRY(hipMemcpyAsync(dp.data(), m->nuts.depth, sizeof(int) * B, hipMemcpyDeviceToHost, m->stream));
+    HHIP_TRY(hipStreamSynchronize(m->stream));
+    for (size_t b = 0; b < B; ++b) {
+        if (alpha) alpha[b] = a[b] / (double)(na[b] > 0 ? na[b] : 1);
+        if (depth) depth[b] = dp[b];
+    }
+    return MCD_OK;
+}
+
+int mcd_hmc_nuts_run(mcd_hmc_t* m, int n_transitions, int adapt, double* eps, const double* inv_mass, double delta, int max_depth,
+                     uint64_t seed, int64_t chain_offset, uint64_t first_transition, double* mean_alpha, double* q_mean, double* q_var)
+{
+    if (!m || !eps || !inv_mass) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts_run: NULL argument");
+    if (n_transitions < 0) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts_run: negative number of transitions");
+    if (adapt && !(delta > 0 && delta < 1)) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts_run: delta must be in (0, 1)");
+    const mcd::HmcDev& D = m->dev;
+    const size_t B = (size_t)D.batch, dim = (size_t)D.dim;
+    // dual averaging of ln eps per chain: Hoffman & Gelman (2014), Algorithm 6 (gamma = 0.05, t0 = 10, kappa = 0.75)
+    const double gamma = 0.05, t0 = 10.0, kappa = 0.75;
+    std::vector<double> mu(B), h_bar(B, 0.0), log_eps_bar(B, 0.0), cur(eps, eps + B), alpha(B), asum(B, 0.0);
+    for (size_t b = 0; b < B; ++b) mu[b] = std::log(10.0 * eps[b]);
+    std::vector<double> q(q_mean || q_var ? B * dim : 0), s1(dim, 0.0), s2(dim, 0.0);
+    for (int t = 1; t <= n_transitions; ++t) {
+        if (int rc = mcd_hmc_nuts(m, cur.data(), inv_mass, max_depth, seed, chain_offset, first_transition + (uint64_t)(t - 1), alpha.data(), nullptr))
+            return rc;
+        for (size_t b = 0; b < B; ++b) {
+            asum[b] += alpha[b];
+            if (adapt) {
+                h_bar[b] = (1.0 - 1.0 / (t + t0)) * h_bar[b] + (delta - alpha[b]) / (t + t0);
+                const double log_eps = mu[b] - std::sqrt((double)t) / gamma * h_bar[b];
+                const double w = std::pow((double)t, -kappa);
+                log_eps_bar[b] = w * log_eps + (1.0 - w) * log_eps_bar[b];
+                cur[b] = std::exp(log_eps);
+            }
+        }
+        if (!q.empty()) {
+            HHIP_TRY(hipMemcpy(q.data(), D.q, sizeof(double) * B * dim, hipMemcpyDeviceToHost));
+            for (size_t b = 0; b < B; ++b)
+                for (size_t k = 0; k < dim; ++k) {
+                    const double x = q[b * dim + k];
+                    s1[k] += x;
+                    s2[k] += x * x;
+                }
+        }
+    }
+    for (size_t b = 0; b < B; ++b) {
+        if (adapt && n_transitions > 0) eps[b] = std::exp(log_eps_bar[b]);
+        if (mean_alpha) mean_alpha[b] = n_transitions > 0 ? asum[b] / n_transitions : 0.0;
+    }
+    const double cnt = (double)B * (double)(n_transitions > 0 ? n_transitions : 1);
+    for (size_t k = 0; k < dim && !q.empty(); ++k) {
+        const double mean = s1[k] / cnt;
+        if (q_mean) q_mean[k] = mean;
+        if (q_var) q_var[k] = s2[k] / cnt - mean * mean;          // pooled over chains and transitions (what mass tuning uses)
+    }
     return MCD_OK;
 }
 

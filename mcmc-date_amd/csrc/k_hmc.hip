@@ -119,6 +119,50 @@ __global__ __launch_bounds__(256) void k_hmc_collect(HmcDev D)
     }
 }
 
+// kick and drift of one leapfrog step in ONE launch: a workgroup per chain, so that a barrier separates "every gradient entry of
+// the chain has been read" (the Jacobian term of a coordinate reads state entries that belong to other coordinates) from "the
+// new position is written into the state".  p += kick eps g;  q += eps M^-1 p.
+__global__ __launch_bounds__(256) void k_hmc_kick_drift(HmcDev D, double kick)
+{
+    const int64_t b = blockIdx.x;
+    const int64_t o = b * D.dim;
+    const double e = D.eps[b] * (D.dir ? D.dir[b] : 1.0);
+    for (int k = threadIdx.x; k < D.dim; k += blockDim.x) {
+        const double g = hmc_grad_entry(D, b, D.pos_field[k], D.pos_index[k]);
+        D.grad[o + k] = g;
+        D.p[o + k] = D.p[o + k] + kick * e * g;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < D.dim; k += blockDim.x) {
+        double* slot = hmc_state_slot(D, b, D.pos_field[k], D.pos_index[k]);
+        const double q = *slot + e * D.inv_mass[k] * D.p[o + k];
+        *slot = q;
+        D.q[o + k] = q;
+    }
+}
+
+// the closing half kick together with k_hmc_collect
+__global__ __launch_bounds__(256) void k_hmc_kick_collect(HmcDev D, double kick)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.batch * D.dim) return;
+    const int64_t b = i / D.dim;
+    const int k = (int)(i - b * D.dim);
+    const int field = D.pos_field[k], v = D.pos_index[k];
+    const double e = D.eps[b] * (D.dir ? D.dir[b] : 1.0);
+    const double g = hmc_grad_entry(D, b, field, v);
+    D.p[i] = D.p[i] + kick * e * g;
+    D.grad[i] = g;
+    D.q[i] = *hmc_state_slot(D, b, field, v);
+    if (k == 0) {
+        const double* H = D.H + b * D.ld;
+        const double* R = D.R + b * D.ld;
+        const int l = 1, r = D.root_right;
+        const double root_branch = D.sc[2 * D.batch + b] * D.sc[3 * D.batch + b] * ((H[0] - H[l]) * R[l] + (H[0] - H[r]) * R[r]);
+        D.value[b] = D.lp[b] + D.ll[b] + log(1.0 / root_branch);
+    }
+}
+
 static unsigned hmc_grid(const HmcDev& D) { return (unsigned)((D.batch * D.dim + 255) / 256); }
 
 hipError_t launch_hmc_kick(const HmcDev& D, double kick, int use_pos_grad, hipStream_t st)
@@ -134,6 +178,16 @@ hipError_t launch_hmc_scatter(const HmcDev& D, hipStream_t st)
 hipError_t launch_hmc_drift(const HmcDev& D, hipStream_t st)
 {
     hipLaunchKernelGGL(k_hmc_drift, dim3(hmc_grid(D)), dim3(256), 0, st, D);
+    return hipGetLastError();
+}
+hipError_t launch_hmc_kick_drift(const HmcDev& D, double kick, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_hmc_kick_drift, dim3((unsigned)D.batch), dim3(256), 0, st, D, kick);
+    return hipGetLastError();
+}
+hipError_t launch_hmc_kick_collect(const HmcDev& D, double kick, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_hmc_kick_collect, dim3(hmc_grid(D)), dim3(256), 0, st, D, kick);
     return hipGetLastError();
 }
 hipError_t launch_hmc_collect(const HmcDev& D, hipStream_t st)

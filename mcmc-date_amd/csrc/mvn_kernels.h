@@ -104,6 +104,21 @@ struct HmcDev {
     const double *eps, *dir, *inv_mass;     // [batch] step sizes, [batch] +-1 or null, [dim] inverse masses
 };
 
+// Per-chain state of the device NUTS (k_nuts.hip); all pointers are device memory, position layout [batch][dim] unless noted.
+struct NutsDev {
+    int max_depth;                          // levels of the first-leaf stack
+    double *qm, *pm, *gm, *qp, *pp, *gp;    // the tree's two ends: position, momentum, gradient
+    double *qc, *gc, *lpc;                  // candidate inside the sub tree being built (+ ln target [batch])
+    double *qn, *gn, *lpn;                  // the transition's current proposal
+    double *sq, *sp;                        // [batch][max_depth][dim] first leaf (position, momentum) of the open sub tree of 2^k leaves
+    double *log_u, *joint0, *alpha;         // [batch] slice variable, -H at the start, sum of min(1, exp(H0 - H)) over the leaves
+    int *j, *v, *i, *n, *n1, *s1, *done, *n_alpha, *depth, *leaf;   // [batch] doubling, direction, leaf index, counts, flags
+};
+hipError_t launch_nuts_begin(const HmcDev& D, const NutsDev& N, uint64_t seed, int64_t chain0, uint64_t transition, hipStream_t st);
+hipError_t launch_nuts_step(const HmcDev& D, const NutsDev& N, uint64_t seed, int64_t chain0, uint64_t transition, int max_depth, int* active,
+                            hipStream_t st);
+hipError_t launch_nuts_end(const HmcDev& D, const NutsDev& N, hipStream_t st);
+
 int padded_blocks(int n);          // supported R for dimension n, or -1
 int sweep_chunk_columns(int R);    // columns per register buffer (ncols granularity)
 
@@ -164,6 +179,8 @@ hipError_t launch_hmc_kick(const HmcDev& D, double kick, int use_pos_grad, hipSt
 hipError_t launch_hmc_scatter(const HmcDev& D, hipStream_t st);               // state arrays <- D.q
 hipError_t launch_hmc_drift(const HmcDev& D, hipStream_t st);                 // q += eps Minv p, scattered into the state
 hipError_t launch_hmc_collect(const HmcDev& D, hipStream_t st);               // q, grad, value from the state and the gradient kernels
+hipError_t launch_hmc_kick_drift(const HmcDev& D, double kick, hipStream_t st);     // kick + drift in one launch (gradient from the kernels' outputs)
+hipError_t launch_hmc_kick_collect(const HmcDev& D, double kick, hipStream_t st);   // closing kick + collect
 // one row of the proposal table on the host (k_mh.hip turns it into a kernel argument)
 struct MhRow {
     int kind, node, n1, n2, jac_root;

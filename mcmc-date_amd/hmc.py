@@ -89,6 +89,30 @@ class Leapfrog:
         return p
 
 
+    def nuts(self, eps, inv_mass, max_depth: int = 8, seed: int = 0, transition: int = 0, chain_offset: int = 0):
+        """One NUTS transition of every chain ON THE DEVICE (mcd_hmc_nuts, csrc/k_nuts.hip: Hoffman & Gelman 2014, Algorithm 3
+        as a per-chain state machine; counter-based random streams (seed, chain_offset + b, transition)).  Returns (mean
+        acceptance statistic [B], tree depth [B]); the chains' new states are on the device."""
+        eps = np.ascontiguousarray(np.broadcast_to(np.asarray(eps, np.float64), (self.batch,)))
+        inv_mass = np.ascontiguousarray(np.broadcast_to(np.asarray(inv_mass, np.float64), (self.dim,)))
+        alpha = np.empty(self.batch)
+        depth = np.empty(self.batch, np.int32)
+        _capi.check(_capi.lib().mcd_hmc_nuts(self._h, _p(eps), _p(inv_mass), int(max_depth), int(seed), int(chain_offset), int(transition),
+                                             _p(alpha), depth.ctypes.data_as(C.POINTER(C.c_int32))))
+        return alpha, depth
+
+    def nuts_run(self, n_transitions: int, eps, inv_mass, adapt: bool = False, delta: float = 0.65, max_depth: int = 8, seed: int = 0,
+                 first_transition: int = 0, chain_offset: int = 0):
+        """n transitions in the library (mcd_hmc_nuts_run); adapt: dual averaging of the step sizes (Algorithm 6).  Returns
+        (eps [B] -- the averaged step sizes when adapting --, mean acceptance statistic [B], position means [dim], pooled
+        position variances [dim])."""
+        eps = np.array(np.broadcast_to(np.asarray(eps, np.float64), (self.batch,)), dtype=np.float64, order="C")
+        inv_mass = np.ascontiguousarray(np.broadcast_to(np.asarray(inv_mass, np.float64), (self.dim,)))
+        ma, qm, qv = np.empty(self.batch), np.empty(self.dim), np.empty(self.dim)
+        _capi.check(_capi.lib().mcd_hmc_nuts_run(self._h, int(n_transitions), int(bool(adapt)), _p(eps), _p(inv_mass), float(delta), int(max_depth),
+                                                 int(seed), int(chain_offset), int(first_transition), _p(ma), _p(qm), _p(qv)))
+        return eps, ma, qm, qv
+
     def step_from(self, q, p, grad, eps, inv_mass, direction=None, have_grad=True):
         """One leapfrog step from the given phase points (all [B, dim]); returns (q', p', grad', ln target')."""
         q = np.array(q, dtype=np.float64, order="C")

@@ -423,4 +423,85 @@ private:
     std::unique_ptr<mcd_mh_t, detail::MhDeleter> mh_;
 };
 
+// The Hamiltonian proposal of the reference: `nutsWith calibrationsAvailable x htarget` (app/Hamiltonian.hs:95-105), with the
+// position layout of `toVector` / `getMask` (:33-60) and the target prior x likelihood x jacobianRootBranch of `htargetWith`
+// (:72-92).  The tree building runs on the device for all chains in lock step (csrc/k_nuts.hip), the step sizes adapt by dual
+// averaging inside the library (mcd_hmc_nuts_run); the reference tunes step size and all masses (`htconf`, :62-63):
+// `warmup` alternates step-size windows with pooled-variance masses.
+class Nuts {
+public:
+    Nuts(const Likelihood& lik, const PriorFunction& prior, bool calibrationsAvailable, int64_t batch, uint64_t seed)
+        : topo_(lik.topology()), batch_(batch), seed_(seed)
+    {
+        mcd_hmc_t* h = nullptr;
+        detail::check(mcd_hmc_create(&h, lik.treeHandle(), prior.handle(), calibrationsAvailable ? 1 : 0, batch));
+        h_.reset(h, [](mcd_hmc_t* p) { mcd_hmc_destroy(p); });
+        dim_ = mcd_hmc_dim(h);
+        eps_.assign((size_t)batch, 0.02);
+        invMass_.assign((size_t)dim_, 1.0);
+    }
+    int dim() const { return dim_; }
+    void setState(const std::vector<I>& xs)
+    {
+        const int nn = topo_.nNodes();
+        Vec b, d, t, m, v, H, R;
+        for (const I& x : xs) {
+            b.push_back(x.timeBirthRate); d.push_back(x.timeDeathRate); t.push_back(x.timeHeight); m.push_back(x.rateMean); v.push_back(x.rateVariance);
+            H.insert(H.end(), x.timeTree.begin(), x.timeTree.end()); R.insert(R.end(), x.rateTree.begin(), x.rateTree.end());
+        }
+        detail::check(mcd_hmc_set_state(h_.get(), b.data(), d.data(), t.data(), H.data(), m.data(), v.data(), R.data(), nn));
+        Vec q((size_t)batch_ * dim_);
+        detail::check(mcd_hmc_get_position(h_.get(), q.data(), nullptr, nullptr));
+        for (int k = 0; k < dim_; ++k) {                      // first masses: (0.1 |q|)^2 averaged over the chains
+            double a = 0.0;
+            for (int64_t c = 0; c < batch_; ++c) a += 0.1 * std::fabs(q[(size_t)c * dim_ + k]);
+            a /= (double)batch_;
+            invMass_[k] = a * a > 1e-12 ? a * a : 1e-12;
+        }
+    }
+    // step sizes by dual averaging (Hoffman & Gelman 2014, Algorithm 6), masses = pooled position variances of a window
+    void warmup(int windows = 3, int window = 60, double delta = 0.65, int maxDepth = 6)
+    {
+        Vec alpha((size_t)batch_), qm((size_t)dim_), qv((size_t)dim_);
+        for (int w = 0; w < windows; ++w) {
+            detail::check(mcd_hmc_nuts_run(h_.get(), window, 1, eps_.data(), invMass_.data(), delta, maxDepth, seed_, 0, transition_, alpha.data(),
+                                           qm.data(), qv.data()));
+            transition_ += (uint64_t)window;
+            const double nEff = (double)batch_ * window;
+            for (int k = 0; k < dim_; ++k) invMass_[k] = (nEff / (nEff + 5.0)) * qv[k] + 1e-3 * (5.0 / (nEff + 5.0));
+        }
+        detail::check(mcd_hmc_nuts_run(h_.get(), window, 1, eps_.data(), invMass_.data(), delta, maxDepth, seed_, 0, transition_, alpha.data(), nullptr, nullptr));
+        transition_ += (uint64_t)window;
+    }
+    // n transitions with the tuned step sizes and masses; returns the mean acceptance statistic per chain
+    Vec run(int n, int maxDepth = 6)
+    {
+        Vec alpha((size_t)batch_);
+        detail::check(mcd_hmc_nuts_run(h_.get(), n, 0, eps_.data(), invMass_.data(), 0.65, maxDepth, seed_, 0, transition_, alpha.data(), nullptr, nullptr));
+        transition_ += (uint64_t)n;
+        return alpha;
+    }
+    I state(int64_t chain) const
+    {
+        const int nn = topo_.nNodes();
+        Vec b(batch_), d(batch_), t(batch_), m(batch_), v(batch_), H((size_t)batch_ * nn), R((size_t)batch_ * nn);
+        detail::check(mcd_hmc_get_state(h_.get(), b.data(), d.data(), t.data(), H.data(), m.data(), v.data(), R.data(), nn));
+        I x;
+        x.timeBirthRate = b[chain]; x.timeDeathRate = d[chain]; x.timeHeight = t[chain]; x.rateMean = m[chain]; x.rateVariance = v[chain];
+        x.timeTree.assign(H.begin() + chain * nn, H.begin() + (chain + 1) * nn);
+        x.rateTree.assign(R.begin() + chain * nn, R.begin() + (chain + 1) * nn);
+        return x;
+    }
+    const Vec& stepSizes() const { return eps_; }
+    const Vec& inverseMasses() const { return invMass_; }
+
+private:
+    Topology topo_;
+    int64_t batch_;
+    uint64_t seed_, transition_ = 0;
+    int dim_ = 0;
+    Vec eps_, invMass_;
+    std::shared_ptr<mcd_hmc_t> h_;
+};
+
 }  // namespace mcmcdate

@@ -69,6 +69,17 @@ static int sampler_mode(const char* path)
     for (long long b = 0; b < batch; ++b) std::printf("post %lld %.17g %.17g %.17g\n", b, post[b * 3], post[b * 3 + 1], post[b * 3 + 2]);
     const I last = smp.state(batch - 1);
     std::printf("state %.17g %.17g %.17g\n", last.timeHeight, last.timeTree[1], last.rateTree[nn - 1]);
+    // the Hamiltonian proposal through the same mirror: NUTS on the device from the sampler's states, two transitions with
+    // the library's random streams (seed, chain, transition)
+    {
+        Nuts nuts(lik, prior, ncal > 0, batch, seed);
+        std::vector<I> xs;
+        for (long long b = 0; b < batch; ++b) xs.push_back(smp.state(b));
+        nuts.setState(xs);
+        const Vec alpha = nuts.run(2, 4);
+        const I xn = nuts.state(batch - 1);
+        std::printf("nuts %d %.17g %.17g %.17g %.17g\n", nuts.dim(), alpha[0], alpha[batch - 1], xn.timeHeight, xn.timeTree[1]);
+    }
     std::mt19937_64 rng(1);
     const auto cyc = cycleSchedule(ps, 2, rng);
     if ((int)cyc.size() != 2 * smp.stepsPerIteration()) return 1;

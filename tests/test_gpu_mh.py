@@ -407,6 +407,16 @@ def test_cpp_sampler_mirror(gpu, golden, tmp_path):
     s = smp.state()
     st = [float(v) for v in [l for l in lines if l.startswith("state ")][0].split()[1:]]
     assert st == [s.time_height[B - 1], s.heights[B - 1, 1], s.rates[B - 1, topo.n_nodes - 1]]
+    # the C++ mirror's Nuts (device NUTS through mcd_hmc_nuts_run) against the Python mirror on the same streams: bit for bit
+    nl = [l for l in lines if l.startswith("nuts ")][0].split()[1:]
+    lf = M.Leapfrog(smp._keep[0], smp._keep[1], len(fx["cal"]) > 0, B)
+    lf.set_state(s)
+    q0 = lf.position()[0]
+    inv_mass = np.maximum((0.1 * np.abs(q0)).mean(axis=0) ** 2, 1e-12)
+    eps, alpha, _, _ = lf.nuts_run(2, 0.02, inv_mass, adapt=False, max_depth=4, seed=seed)
+    sn = lf.state()
+    assert int(nl[0]) == lf.dim
+    assert [float(v) for v in nl[1:]] == [alpha[0], alpha[B - 1], sn.time_height[B - 1], sn.heights[B - 1, 1]]
 
 
 def test_prior_only_node_ages_against_the_references_own_samples(gpu, tmp_path):

@@ -1,0 +1,224 @@
+"""Device NUTS (csrc/k_nuts.hip, mcd_hmc_nuts*) -- SURVEY.md 8(f) row f3 -- against a CPU twin, step for step.
+
+The reference's proposal is `nuts` of the un-vendored package `mcmc` (app/Hamiltonian.hs:95-105): parity with it is unpinned.
+What pins the device code is the twin below: the same algorithm (Hoffman & Gelman 2014, Algorithm 3, as the per-chain state
+machine documented in k_nuts.hip) written independently in Python on the CPU oracles -- ln prior from oracle/prior_oracle.c (pinned
+by the reference's known answers), ln likelihood and root-branch Jacobian from oracle/mvn_oracle.c, the gradient of their sum
+by central differences -- drawing from the same counter-based Philox streams.  Tree depth, number of admissible leaves, the
+acceptance statistic and the selected point must agree for every chain and transition.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import mcmc_date_amd as M
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DELTA_MAX = 1000.0
+
+
+def tables(fx):
+    cal = [M.Calibration(f"c{i}", int(r[0]), r[2] if r[1] else None, r[3], r[5] if r[4] else None, r[6]) for i, r in enumerate(fx["cal"])]
+    con = [M.Constraint(f"k{i}", int(r[0]), int(r[1]), r[2]) for i, r in enumerate(fx["con"])]
+    br = [M.Brace(f"b{i}", [int(n) for n in fx["brace_nodes"][fx["brace_ptr"][i]:fx["brace_ptr"][i + 1]]], float(s))
+          for i, s in enumerate(fx["brace_sd"])]
+    return cal, con, br
+
+
+class Twin:
+    """ln [prior x likelihood x jacobianRootBranch] (app/Hamiltonian.hs:85-92) of a position vector on the CPU oracles."""
+
+    def __init__(self, fx, spec, mask, x_template):
+        self.fx, self.spec, self.mask, self.x = fx, spec, mask, x_template
+
+    def value(self, q):
+        x = M.from_vector_with(self.mask, self.x, q)
+        lp = O.prior(self.spec, x.time_birth_rate, x.time_death_rate, x.time_height, x.time_tree, x.rate_mean, x.rate_variance, x.rate_tree)[0]
+        ll, lj = O.tree_loglik_full_batch(self.fx["parent"], x.time_tree[None], x.rate_tree[None], np.array([x.time_height]),
+                                          np.array([x.rate_mean]), self.fx["mu"], self.fx["sigma_inv"], float(self.fx["logdet"]))
+        return lp + ll[0] + lj[0]
+
+    def grad(self, q):
+        g = np.empty_like(q)
+        for k in range(len(q)):
+            h = 1e-6 * max(abs(q[k]), 1e-3)
+            a, b = q.copy(), q.copy()
+            a[k] += h
+            b[k] -= h
+            a2, b2 = q.copy(), q.copy()
+            a2[k] += 2 * h
+            b2[k] -= 2 * h
+            g[k] = (8.0 * (self.value(a) - self.value(b)) - (self.value(a2) - self.value(b2))) / (12.0 * h)
+        return g
+
+
+def twin_transition(tw, q0, g0, lp0, eps, inv_mass, max_depth, seed, chain, transition):
+    """The state machine of k_nuts.hip for one chain; returns (q_new, lp_new, alpha mean, depth, n)."""
+    dim = len(q0)
+
+    def uni(d):
+        return O.uniform_pair(seed, chain, transition, d)
+
+    p0 = np.empty(dim)
+    for k in range(dim):
+        ua, ub = uni(0x4000 + (k >> 1))
+        rad, ang = math.sqrt(-2.0 * math.log(ua)), 6.28318530717958647692 * ub
+        p0[k] = (rad * math.sin(ang) if (k & 1) else rad * math.cos(ang)) / math.sqrt(inv_mass[k])
+    joint0 = lp0 - 0.5 * float(np.sum(p0 * p0 * inv_mass))
+    log_u = joint0 + math.log(uni(1)[0])
+    minus = [q0.copy(), p0.copy(), g0.copy()]
+    plus = [q0.copy(), p0.copy(), g0.copy()]
+    prop = (q0.copy(), lp0)
+    n, j, leaf, alpha, n_alpha = 1, 0, 0, 0.0, 0
+
+    def no_u_turn(qm, rm, qp, rp):
+        d = qp - qm
+        return float(np.dot(d, rm * inv_mass)) >= 0.0 and float(np.dot(d, rp * inv_mass)) >= 0.0
+
+    while True:
+        v = -1 if uni(0x10 + 2 * j)[0] < 0.5 else 1
+        edge = minus if v < 0 else plus
+        n1, s1, cand, stack = 0, True, None, {}
+        for i in range(1 << j):
+            q, p, g = edge
+            e = eps * v
+            p = p + 0.5 * e * g
+            q = q + e * inv_mass * p
+            lp = tw.value(q)
+            g = tw.grad(q) if math.isfinite(lp) else np.full(dim, np.nan)
+            p = p + 0.5 * e * g
+            edge[0], edge[1], edge[2] = q, p, g
+            joint = lp - 0.5 * float(np.sum(p * p * inv_mass))
+            if not math.isfinite(joint):
+                joint = -math.inf
+            nl, sl = log_u <= joint, log_u < DELTA_MAX + joint
+            if nl:
+                n1 += 1
+                if uni(0x100000 + leaf)[0] * n1 < 1.0:
+                    cand = (q.copy(), lp)
+            s1 = s1 and sl
+            alpha += min(1.0, math.exp(min(0.0, joint - joint0)))
+            n_alpha += 1
+            for k in range(1, j + 1):
+                size = 1 << k
+                if i % size == 0:
+                    stack[k] = (q.copy(), p.copy())
+                elif (i + 1) % size == 0 and s1:
+                    lq, lr = stack[k]
+                    s1 = s1 and (no_u_turn(lq, lr, q, p) if v > 0 else no_u_turn(q, p, lq, lr))
+            leaf += 1
+            if not s1:
+                break
+        if not s1:
+            return prop[0], prop[1], alpha / n_alpha, j + 1, n
+        if n1 > 0 and uni(0x11 + 2 * j)[0] * n < n1:
+            prop = cand
+        n += n1
+        s = no_u_turn(minus[0], minus[1], plus[0], plus[1])
+        j += 1
+        if not s or j >= max_depth:
+            return prop[0], prop[1], alpha / n_alpha, j, n
+
+
+def test_device_nuts_follows_the_cpu_twin(gpu, golden):
+    fx = golden["12-leaves-variable-rate"]
+    topo = M.Topology(fx["parent"])
+    cal, con, br = tables(fx)
+    ht = float(fx["prior_ht"])
+    pf = M.PriorFunction(ht, "UncorrelatedGamma", cal, con, br, topo)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    spec = O.PriorSpec(fx["parent"], ht, "UncorrelatedGamma", [(c.node, c.lower, c.lower_p, c.upper, c.upper_p) for c in cal],
+                       [(k.young, k.old, k.p) for k in con], [(b.nodes, b.sd) for b in br])
+    B = 6
+    ps, _ = M.proposals(topo, br, calibrations_available=True)
+    smp = M.Sampler(lik, pf, ps, B, seed=3)
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    x0.time_height = ht
+    smp.set_initial_state(x0)
+    smp.burn_in(fast=[10, 10, 20, 40], slow=[100, 100])           # typical posterior states, different per chain
+    lf = M.Leapfrog(lik, pf, True, B)
+    lf.set_state(smp.state())
+    mask = M.get_mask(True, topo)
+    q0, lp0, g0 = lf.position()
+    inv_mass = np.maximum((0.1 * np.abs(q0)).mean(axis=0) ** 2, 1e-12)
+    eps = np.array([0.05, 0.1, 0.2, 0.3, 0.15, 0.25])
+    st = lf.state()
+    seed, max_depth = 20261004, 5
+    for transition in range(3):
+        q_before, lp_before, g_before = lf.position()
+        alpha, depth = lf.nuts(eps, inv_mass, max_depth=max_depth, seed=seed, transition=transition)
+        q_after, lp_after, g_after = lf.position()
+        for b in range(B):
+            x_t = M.State(st.time_birth_rate[b], st.time_death_rate[b], st.time_height[b], st.heights[b], st.rate_mean[b], st.rate_variance[b],
+                          st.rates[b])
+            tw = Twin(fx, spec, mask, x_t)
+            assert abs(tw.value(q_before[b]) - lp_before[b]) <= 1e-9 * max(1.0, abs(lp_before[b]))
+            qn, lpn, a, d, n = twin_transition(tw, q_before[b], g_before[b], lp_before[b], eps[b], inv_mass, max_depth, seed, b, transition)
+            assert d == depth[b], (transition, b, d, depth[b])
+            assert abs(a - alpha[b]) <= 1e-6, (transition, b, a, alpha[b])
+            assert np.max(np.abs(qn - q_after[b]) / np.maximum(1e-3, np.abs(qn))) <= 1e-6, (transition, b)
+            assert abs(lpn - lp_after[b]) <= 1e-6 * max(1.0, abs(lpn))
+        # the state, position, value and gradient the handle now holds are consistent with each other
+        val, grad = M.target_grad(mask, lik, pf, lf.state())
+        assert np.max(np.abs(val - lp_after) / np.maximum(1.0, np.abs(val))) <= 1e-10
+        assert np.max(np.abs(grad - g_after)) <= 1e-8 * np.max(np.abs(grad))
+    assert len(set(depth.tolist())) >= 1 and depth.max() <= max_depth and depth.min() >= 1
+
+
+def test_device_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden):
+    """End to end in the library (mcd_hmc_nuts_run: NUTS on the device, dual averaging in the C++ host side): node-age means on
+    tests/12-leaves-variable-rate within 3 % of Metropolis-Hastings chains with the same target (every proposal lifted with
+    jacobianRootBranch); the adapted step sizes give the target acceptance statistic; a chain's draws do not depend on the batch."""
+    import dataclasses
+
+    from mcmc_date_amd import monitor as MO
+
+    fx = golden["12-leaves-variable-rate"]
+    topo = M.Topology(fx["parent"])
+    cal, con, br = tables(fx)
+    ht = float(fx["prior_ht"])
+    pf = M.PriorFunction(ht, "UncorrelatedGamma", cal, con, br, topo)
+    lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
+    B = 64
+    ps, _ = M.proposals(topo, br, calibrations_available=True, exact_jacobians=True)
+    ps = [dataclasses.replace(p, jac_root=1) for p in ps]
+    smp = M.Sampler(lik, pf, ps, B, seed=78)
+    x0 = M.init_with(topo, fx["mean_lengths"])
+    x0.time_height = ht
+    smp.set_initial_state(x0)
+    smp.burn_in(fast=[10, 10, 20, 40, 80], slow=[100, 200, 300, 400])
+    tr = MO.collect(smp, 3000, period=50, accumulate=True)
+    ages_mh = smp.node_age_summary()[0]
+    mask = M.get_mask(True, topo)
+    qs = np.array([M.to_vector(mask, M.State(tr.time_birth_rate[k, b], tr.time_death_rate[k, b], tr.time_height[k, b], tr.heights[k, b],
+                                             tr.rate_mean[k, b], tr.rate_variance[k, b], tr.rates[k, b]))
+                   for k in range(tr.heights.shape[0]) for b in range(0, B, 2)])
+    inv_mass = qs.var(axis=0)
+    lf = M.Leapfrog(lik, pf, True, B)
+    lf.set_state(smp.state())
+    eps, alpha_w, _, _ = lf.nuts_run(150, 0.03, inv_mass, adapt=True, delta=0.65, max_depth=6, seed=5)
+    assert np.all((eps > 0.005) & (eps < 0.6)), eps
+    n_tr = 300
+    ages = np.zeros(topo.n_nodes)
+    alphas = []
+    for t in range(n_tr):
+        a, d = lf.nuts(eps, inv_mass, max_depth=6, seed=5, transition=1000 + t)
+        alphas.append(a.mean())
+        s = lf.state()
+        ages += (s.time_height[:, None] * s.heights).mean(axis=0)
+    ages /= n_tr
+    inner = ~topo.leaves
+    rel = np.abs(ages[inner] - ages_mh[inner]) / ages_mh[inner]
+    assert 0.45 < np.mean(alphas) < 0.9, np.mean(alphas)
+    assert rel.max() <= 0.03, (rel, np.mean(alphas))
+    # the random streams are keyed by the global chain index: chains 8 .. 15 alone retrace their part of the batch
+    lf.set_state(smp.state())
+    a_all, d_all = lf.nuts(eps, inv_mass, max_depth=6, seed=9, transition=7)
+    q_all = lf.position()[0]
+    sub = M.Leapfrog(lik, pf, True, 8)
+    sub.set_state(smp.state().slice(8, 16))
+    a_sub, d_sub = sub.nuts(eps[8:16], inv_mass, max_depth=6, seed=9, transition=7, chain_offset=8)
+    assert np.array_equal(d_sub, d_all[8:16]) and np.array_equal(a_sub, a_all[8:16]) and np.array_equal(sub.position()[0], q_all[8:16])
