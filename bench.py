@@ -39,17 +39,20 @@ def algorithmic_flops_per_eval(n: int) -> float:
     return float(n) * n + 5.0 * n
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction applied): profiles/*_pmc_traffic.json of the
-    latest round, or None."""
+def measured_traffic(key=None):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    passes, gfx950 correction applied): profiles/*_pmc_traffic.json of the latest round, entry `key` (the workload the passes
+    were run on: "n256", "n1024", "tree255", "tree1023" -- tools/collect_profiles_r02.sh), or None."""
     import glob
 
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not fs:
         return None
     try:
-        return float(json.load(open(fs[-1]))["per_launch_bytes_corrected"])
+        d = json.load(open(fs[-1]))
+        if key is not None:
+            return float(d[key]["per_launch_bytes_corrected"])
+        return float(d["per_launch_bytes_corrected"])
     except Exception:
         return None
 
@@ -412,7 +415,8 @@ def main():
                                        else f"chains sharded x{world} + ll all-gather every {args.swap_period} steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic() if (n == 256 and B == 512 and args.kind == "logpdf" and form == "split") else None,
+                         "traffic": measured_traffic({("logpdf", 256): "n256", ("logpdf", 1024): "n1024", ("tree", 255): "tree255",
+                                                      ("tree", 1021): "tree1023"}.get((args.kind, n))) if B == 512 and args.form == "auto" else None,
                          "kernel_us_per_launch": per_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_b,
                          "fp64_tflops": flops, "fp64_frac": flops / FP64_PEAK_TFLOPS},

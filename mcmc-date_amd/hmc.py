@@ -10,6 +10,9 @@ Restated here from the published algorithm it implements -- Hoffman & Gelman, "T
 uniform sampling from the admissible set), `DualAveraging` the step-size adaptation of Algorithm 6 -- with the device
 doing every leapfrog step for all chains at once and the per-chain recursion as host-side control flow (one Python
 generator per chain; the driver gathers the leapfrog requests of all active chains into one `mcd_hmc_step_from` call).
+The product path is `Leapfrog.nuts` / `Leapfrog.nuts_run`: the same algorithm as a per-chain state machine ON THE DEVICE
+(csrc/k_nuts.hip, mcd_hmc_nuts*), dual averaging inside the library, step-level parity with a CPU twin
+(tests/test_gpu_nuts.py); the host-side recursion below stays as the readable restatement of the control flow.
 `mcmc`'s own tuning (`HTuneLeapfrog HTuneAllMasses`) and its defaults are NOT restated: parity unpinned for this part.
 `hmc_transition` is the textbook fixed-length HMC step, kept as the simplest end-to-end exercise of the integrator.
 """
@@ -314,19 +317,24 @@ def nuts_warmup(lf: Leapfrog, rng: np.random.Generator, n_windows: int = 3, wind
 
 
 def run_cycle_with_nuts(sampler, lf: Leapfrog, rng: np.random.Generator, n_iter: int, eps, inv_mass, max_depth: int = 6,
-                        accumulate: bool = False):
+                        accumulate: bool = False, device: bool = True, seed: int = 0):
     """The reference's `--hamiltonian` mode: the Metropolis-Hastings cycle plus one NUTS proposal per iteration
     (`maybeHamiltonianProposal`, weight 1, app/Definitions.hs:272-274, 104-105 of app/Hamiltonian.hs).  The cycle runs in the lock-step
-    driver, the NUTS transition on the device leapfrog; the states move between the two handles through the host once per
-    iteration (a few KB).  The reference shuffles the NUTS proposal into the cycle; here it closes every iteration.
+    driver, the NUTS transition on the device (`device=True`: Leapfrog.nuts, tree building in csrc/k_nuts.hip; False: the
+    host-side recursion nuts_transition, kept as the reference implementation of the control flow); the states move between
+    the two handles through the host once per iteration (a few KB).  The reference shuffles the NUTS proposal into the
+    cycle; here it closes every iteration.
     Returns (mean acceptance statistic of the NUTS transitions, mean absolute node ages tH * h_v over chains and
     iterations [n_nodes] or None)."""
     alphas = []
     ages = np.zeros(lf.topo.n_nodes) if accumulate else None
-    for _ in range(n_iter):
+    for it in range(n_iter):
         sampler.run(1)
         lf.set_state(sampler.state())
-        alpha, _ = nuts_transition(lf, rng, eps, inv_mass, max_depth=max_depth)
+        if device:
+            alpha, _ = lf.nuts(eps, inv_mass, max_depth=max_depth, seed=seed, transition=it)
+        else:
+            alpha, _ = nuts_transition(lf, rng, eps, inv_mass, max_depth=max_depth)
         alphas.append(alpha.mean())
         s = lf.state()
         sampler.set_state(s)
