@@ -263,8 +263,8 @@ extern "C" double mcd_split_schedule_selftest_(int n, int G, unsigned seed)
             });
             if (pos != mcd::sp_run_start(q, w + 1)) fault = 7;
         }
-        mcd::sp_for_each_cut(NB, G, g, q, [&](int wf, int wl) {
-            if (wf < 0 || wl >= mcd::SP_NW || wl <= wf) {
+        mcd::sp_for_each_cut(NB, G, g, q, [&](int wf, int wl, int blk) {
+            if (wf < 0 || wl >= mcd::SP_NW || wl <= wf || blk < 0 || blk >= NB) {
                 fault = 9;
                 return;
             }

@@ -93,6 +93,7 @@ hipError_t launch_grad(const MvnDev& M, const double* X, int64_t ldx, int64_t ba
                        hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (use_split_grad(M, batch)) return launch_grad_split(M, X, ldx, batch, ll, G, ldg, st);
     if (use_wide_grad(M, batch)) {
         if (M.n <= 256) return launch_grad_wide(M, X, ldx, batch, ll, G, ldg, st);
         // above 256 the gradient rows double as scratch for z: an in-place call (G == X) keeps the sweep, which reads a chain's

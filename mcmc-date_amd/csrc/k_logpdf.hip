@@ -134,6 +134,17 @@ bool use_split(const MvnDev& M, int64_t batch)
     return M.n > 192 && batch <= 32;
 }
 
+bool use_split_grad(const MvnDev& M, int64_t batch)
+{
+    // the gradient on the row-split schedule: two (tree states: three) launches over 8 row groups x batch / 16 workgroups, where
+    // the sweep walks a chain of N / 64 dependent blocks twice and k_wide_grad_mc fills batch / 16 CUs.  MCD_SPLIT as above.
+    const char* env = getenv("MCD_SPLIT");
+    const int force = env ? atoi(env) : -1;
+    if (effective_form(M) != 0 || M.split == nullptr || batch < 1 || batch > kSplitMaxBatch || force == 0) return false;
+    if (force == 1) return true;
+    return M.n > 256 || (M.n > 240 && batch <= 512);      // (measured: tools/gpu/grad_prof.sh; at N = 224 the sweeps are level or ahead)
+}
+
 bool use_wide_grad(const MvnDev& M, int64_t batch)
 {
     // N <= 256: z and y stay in one LDS chunk (k_wide_grad.hip); above they pass through the output buffer (k_wide_grad_mc.hip)

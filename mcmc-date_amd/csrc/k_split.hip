@@ -140,8 +140,20 @@ constexpr int split_threads()
 {
     return 64 * (SP_NW + (NC == 1 ? 1 : 0));
 }
-template <int NC, bool TREE>
-__global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(MvnDev M, SplitSched S, WideSrc A, int64_t batch, int flags,
+// MODE 0: ln density.  MODE 1: ln density, and the z tiles are written to G_.zt (first half of the gradient).  MODE 2: second
+// half of the gradient: the chain vectors are the z rows of G_.zt in REVERSED order and S is the schedule of J W^T J (J = the
+// reversal: lower triangular like W), so the same walk computes J y = (J W^T J)(J z), y = W^T z = Sigma^-1 (x - mu); the y
+// tiles leave as d ll / d x = -y in the caller's rows (G_.t == 0) or as they are in the tile-major scratch (G_.t == 1: tree
+// states, k_split_tree_chain applies the chain rule).  No sum, no hand-over in MODE 2.
+struct SplitGrad {
+    double* zt;        // [tile][16 NB][16 chains] z rows, tile-major (a z tile = 256 consecutive doubles: coalesced both ways)
+    double* out;       // MODE 2: G [batch][ldo] (t == 0) or the y scratch, laid out like zt (t == 1)
+    int64_t ldo;
+    int t;
+};
+
+template <int NC, bool TREE, int MODE>
+__global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(MvnDev M, SplitSched S, WideSrc A, SplitGrad G_, int64_t batch, int flags,
                                                                         double* __restrict__ ll, double* scratch, unsigned* counter)
 {
     constexpr int LD = NC * 256 + 2;                       // LDS row stride in doubles: = 4 dwords (mod 64 banks)
@@ -178,12 +190,14 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     // whose answer travels while the chain vectors are staged; and which row blocks are cut between waves.  Both go to LDS.
     auto ticket_and_cuts = [&]() {
         unsigned ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(&counter[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (MODE != 2) {
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&counter[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         int ncut = 0, cuts[SP_NW - 1] = {0, 0, 0, 0, 0, 0, 0};
-        sp_for_each_cut(NB, G, grp, sg, [&](int wf, int wl) {
+        sp_for_each_cut(NB, G, grp, sg, [&](int wf, int wl, int blk) {
 #pragma unroll
             for (int x = 0; x < SP_NW - 1; ++x)
-                if (ncut == x) cuts[x] = wf | (wl << 4);
+                if (ncut == x) cuts[x] = wf | (wl << 4) | (blk << 8);
             ++ncut;
         });
         if (lane == 0) {
@@ -242,7 +256,30 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     }
 
     // ---- stage the residuals
-    if constexpr (!TREE) {
+    const int NR = 16 * NB;                                // rows of a tile in the tile-major scratch
+    if constexpr (MODE == 2) {
+        // the z rows of this tile, reversed: rs[ch][k] = z[n - 1 - k][ch]; thread = (row, chain), chains fastest (128-byte rows).
+        // Chains beyond the batch hold exact zeros already (their residuals were zeros), rows beyond N are forced to zero.
+        const double* __restrict__ zt = G_.zt + (int64_t)tile * NR * 16;
+        const int ch = tid & 15, k0 = (tid & 511) >> 4;    // (the helper wave never comes here)
+        const int nlast = M.n - 1;
+#pragma unroll 1
+        for (int it = 0; it < NC; ++it) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = (it * 8 + i) * 32 + k0;
+                const int kc = k < nlast ? k : nlast;
+                v[i] = zt[(nlast - kc) * 16 + ch];
+            }
+            if (!HELPER && wave == 0 && it == 0) ticket_and_cuts();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = (it * 8 + i) * 32 + k0;
+                if (k < ncols) rs[ch * LD + k] = (k < M.n) ? v[i] : 0.0;
+            }
+        }
+    } else if constexpr (!TREE) {
         // thread = column ((tid & 255) + 256 c), every second chain.  Every load is unconditional on a clamped address (a load
         // behind a condition costs a branch and its own wait each); padding is then forced to exact zeros by the select.  The
         // groups of a tile start on different chains, so that they do not ask one L2 channel for the same line at the same time.
@@ -363,10 +400,34 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     // are known at compile time once its phase (group index mod SP_RING / 2) is: split_run is instantiated per starting phase
     double ss = 0.0;                                       // sum of squares of the blocks this wave holds completely
     SP_T(2);
-    auto flush = [&](d4& acc, int kind) {                  // a segment ends: square a whole block, park a partial z tile
-        if (kind == 0) {
+    // a finished z tile (block blk) leaves the workgroup (MODE 1, 2): lane = (chain col, row quarter kq), rows kq + 4 q
+    auto emit = [&](const d4& z, int blk) {
+        if constexpr (MODE == 1) {
+            double* p = G_.zt + ((int64_t)tile * NR + 16 * blk) * 16 + lane;       // (kq + 4 q) * 16 + col = lane + 64 q
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ss = fma(acc[q], acc[q], ss);
+            for (int q = 0; q < 4; ++q) p[64 * q] = z[q];
+        } else if constexpr (MODE == 2) {
+            if (G_.t) {
+                double* p = G_.out + ((int64_t)tile * NR + 16 * blk) * 16 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p[64 * q] = z[q];
+            } else if (b0 + col < batch) {
+                double* p = G_.out + (b0 + col) * G_.ldo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jr = 16 * blk + kq + 4 * q;                          // row of J y
+                    if (jr < M.n) p[M.n - 1 - jr] = -z[q];                         // d ll / d x = -Sigma^-1 (x - mu)
+                }
+            }
+        }
+    };
+    auto flush = [&](d4& acc, int kind, int blk) {         // a segment ends: square a whole block, park a partial z tile
+        if (kind == 0) {
+            if constexpr (MODE != 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ss = fma(acc[q], acc[q], ss);
+            }
+            emit(acc, blk);
         } else {
             double* zs = zsum + (kind == 1 ? 2 * wave - 1 : 2 * wave) * SP_Z;
 #pragma unroll
@@ -396,7 +457,7 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * g].y, b[g][1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * g + 1].x, b[g][2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * g + 1].y, b[g][3], acc, 0, 0, 0);
-                    if (ge[g] >= 0) flush(acc, ge[g]);
+                    if (ge[g] >= 0) flush(acc, ge[g], gk[g] >> 2);          // (a whole block's last group starts at k = 4 blk)
                 }
             }
             SP_T(12);
@@ -416,12 +477,14 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
             }
             jp += 2 * ng;
             ph = (ph + ng) & (SP_RING / 2 - 1);
-            flush(acc, kind);
+            flush(acc, kind, (nt >> 2) - 1);               // (kind 0: the segment is the whole block, 4 (blk + 1) tiles)
         });
     }
     SP_T(3);
-    if constexpr (NC >= 4) __syncthreads();
-    part[wave * 64 + lane] = ss;                           // the blocks this wave squared itself: lane = (chain, row quarter)
+    if constexpr (MODE != 2) {
+        if constexpr (NC >= 4) __syncthreads();
+        part[wave * 64 + lane] = ss;                       // the blocks this wave squared itself: lane = (chain, row quarter)
+    }
     __syncthreads();
 
     // ---- everything else happens in wave 0 (one barrier instead of three): lane = (chain col, row quarter kq), the layout of
@@ -433,7 +496,7 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     }
     SP_T(13);
     double tot = 0.0;
-    {
+    if constexpr (MODE != 2) {
         double pv[SP_NW];
 #pragma unroll
         for (int x = 0; x < SP_NW; ++x) pv[x] = part[x * 64 + lane];
@@ -443,8 +506,8 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     const int ncut = aux[1];
 #pragma unroll 1
     for (int ci = 0; ci < ncut; ++ci) {
-        const int cw = aux[2 + ci], wf = cw & 15, wl = cw >> 4;
-        double z[4];
+        const int cw = aux[2 + ci], wf = cw & 15, wl = (cw >> 4) & 15;
+        d4 z;
         const double* z0 = zsum + 2 * wf * SP_Z + kq * 16 + col;
 #pragma unroll
         for (int q = 0; q < 4; ++q) z[q] = z0[64 * q];
@@ -456,10 +519,17 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
 #pragma unroll
             for (int q = 0; q < 4; ++q) z[q] += t[q];
         }
+        if constexpr (MODE != 2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tot = fma(z[q], z[q], tot);
+            for (int q = 0; q < 4; ++q) tot = fma(z[q], z[q], tot);
+        }
+        emit(z, cw >> 8);
     }
     SP_T(14);
+    if constexpr (MODE == 2) {
+        SP_T_FLUSH();
+        return;
+    }
     // the four row quarters of a chain sit on the lanes col, col + 16, col + 32, col + 48
     tot += __shfl_xor(tot, 16);
     tot += __shfl_xor(tot, 32);
@@ -516,6 +586,71 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     }
 }
 
+// Chain rule from g = d ll / d distances (by slot, = -y) to the tree state (as k_tree_grad.hip):
+// d ll / d r_v = s g t_v, d ll / d h_v = s (sum over children c of g_c r_c - g_v r_v), d ll / d tH = g.d / tH, d ll / d rMu = g.d / rMu.
+// One workgroup per chain; y comes from the tile-major scratch MODE 2 wrote (rows of J y: slot j is row n - 1 - j);
+// e_v = s g r_v is exchanged through LDS by node id.
+__global__ void __launch_bounds__(1024) k_split_tree_chain(int n, int NR, TreeDev T, const double* __restrict__ H, const double* __restrict__ Rt,
+                                                           int64_t lds, const double* __restrict__ tH, const double* __restrict__ rMu,
+                                                           const double* __restrict__ yt, double* __restrict__ gH, double* __restrict__ gR,
+                                                           double* __restrict__ gtH, double* __restrict__ grMu)
+{
+    // (as many threads as slots where possible -- the launcher picks 256, 512 or 1024: the kernel is a chain of dependent
+    // loads, slot -> node -> height, node -> children -> e, and one trip through it costs the same for 1 or 4 slots per thread)
+    extern __shared__ double smem[];
+    double* e = smem;                                      // [n_nodes]
+    double* red = smem + T.n_nodes_pad;                    // [16]
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x;
+    const double* __restrict__ y = yt + ((b >> 4) * NR) * 16 + (b & 15);
+    const double* __restrict__ h = H + b * lds;
+    const double* __restrict__ r = Rt + b * lds;
+    const double s = tH[b] * rMu[b];
+    // this thread's first node: its children are looked up now, under the latency of the slot loads
+    const int v0 = tid < T.n_nodes ? tid : T.n_nodes - 1;
+    const int p0 = T.child_ptr[v0], p1 = T.child_ptr[v0 + 1];
+    const int c0 = p1 > p0 ? T.child_idx[p0] : 0, c1 = p1 > p0 + 1 ? T.child_idx[p0 + 1] : 0;
+    double gd = 0.0;
+    for (int j = tid; j < n; j += nt) {
+        const int a = T.slot_node[j], pa = T.slot_parent[j];
+        const double g = -y[(n - 1 - j) * 16];
+        const double t = h[pa] - h[a], ra = r[a], sg = s * g;
+        gR[b * lds + a] = sg * t;
+        e[a] = sg * ra;
+        gd += g * ((t * ra) * s);
+    }
+    if (tid == 0) {                                        // the second root branch shares slot 0; the root has no branch
+        const int rr = T.root_right;
+        const double r2 = r[rr], t2 = h[0] - h[rr], g0 = -y[(n - 1) * 16], sg = s * g0;
+        gR[b * lds + rr] = sg * t2;
+        gR[b * lds] = 0.0;                                 // stem rate: unused by the likelihood
+        e[rr] = sg * r2;
+        e[0] = 0.0;
+        gd += g0 * ((t2 * r2) * s);
+    }
+    gd = wd_wave_sum(gd);
+    if (lane == 0) red[wave] = gd;
+    __syncthreads();
+    if (tid == 0) {
+        double gdot = 0.0;
+        for (int w = 0; w < (nt >> 6); ++w) gdot += red[w];
+        gtH[b] = gdot / tH[b];
+        grMu[b] = gdot / rMu[b];
+    }
+    if (tid < T.n_nodes) {
+        double acc = (tid == 0) ? 0.0 : -e[tid];
+        if (p1 > p0) acc += e[c0];
+        if (p1 > p0 + 1) acc += e[c1];
+        for (int ci = p0 + 2; ci < p1; ++ci) acc += e[T.child_idx[ci]];
+        gH[b * lds + tid] = acc;
+    }
+    for (int v = tid + nt; v < T.n_nodes; v += nt) {
+        double acc = -e[v];
+        for (int ci = T.child_ptr[v]; ci < T.child_ptr[v + 1]; ++ci) acc += e[T.child_idx[ci]];
+        gH[b * lds + v] = acc;
+    }
+}
+
 __global__ void k_split_poison(unsigned long long* slots, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,10 +663,14 @@ __global__ void k_split_poison(unsigned long long* slots, size_t n)
 struct SplitHost {
     int n = 0, device = 0;
     SplitSched sched[3] = {};                              // G = 8, 16, 32 (G = 0: not built for this N)
+    SplitSched sched_b[3] = {};                            // the same for J W^T J (second half of the gradient)
+    size_t zt_doubles = 0;                                 // kSplitMaxBatch chains x 16 NB rows
     std::vector<void*> dev_allocs;
     struct Set {
         double* partials = nullptr;
         unsigned* counters = nullptr;
+        double* zt = nullptr;                              // gradient: z rows, tile-major
+        double* yt = nullptr;                              // gradient of tree states: y rows, tile-major
     };
     std::mutex mu;
     std::vector<Set> spare;                                // zeroed, unassigned
@@ -547,6 +686,8 @@ static hipError_t new_set(SplitHost* s, SplitHost::Set& out)
     (void)hipThreadExchangeStreamCaptureMode(&mode);
     hipError_t e = hipMalloc((void**)&out.partials, kSplitScratchDoubles * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&out.counters, kSplitCounters * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&out.zt, s->zt_doubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&out.yt, s->zt_doubles * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(out.counters, 0, kSplitCounters * sizeof(unsigned), s->init_stream);
     if (e == hipSuccess) {                                 // every slot starts as "no partial sum yet"
         static_assert(sizeof(unsigned long long) == sizeof(double), "");
@@ -563,7 +704,10 @@ template <int NC, bool TREE>
 static hipError_t split_allow_lds()
 {
     if (split_lds_bytes<NC>() <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute((const void*)k_split<NC, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes<NC>());
+    if (hipError_t e = hipFuncSetAttribute((const void*)k_split<NC, TREE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes<NC>())) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)k_split<NC, TREE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes<NC>())) return e;
+    if (!TREE) return hipFuncSetAttribute((const void*)k_split<NC, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes<NC>());
+    return hipSuccess;
 }
 
 SplitHost* split_host_create(int n, const double* W_rowmajor, hipError_t* err)
@@ -579,24 +723,30 @@ SplitHost* split_host_create(int n, const double* W_rowmajor, hipError_t* err)
     if (hipError_t e = hipGetDevice(&s->device)) return fail(e);
     if (hipError_t e = hipStreamCreateWithFlags(&s->init_stream, hipStreamNonBlocking)) return fail(e);
     const int NB = (n + 15) / 16;
+    s->zt_doubles = (size_t)kSplitMaxBatch * 16 * NB;
     const std::vector<double> W(W_rowmajor, W_rowmajor + (size_t)n * n);
+    std::vector<double> Wb((size_t)n * n, 0.0);            // J W^T J: element (i, j) = W(n - 1 - j, n - 1 - i), lower triangular again
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) Wb[(size_t)i * n + j] = W[(size_t)(n - 1 - j) * n + (n - 1 - i)];
     const int Gs[3] = {8, 16, 32};
     for (int v = 0; v < 3; ++v) {
         const int G = Gs[v];
         if (v > 0 && (int64_t)NB * (NB + 1) < 32 * (int64_t)G) continue;   // fewer than 16 tiles per wave: not worth a variant
-        SplitScheduleHost h;
-        build_split_schedule(n, G, W, h);
-        if (h.nc > 4) continue;
-        void* dW = nullptr;
-        if (hipError_t e = hipMalloc(&dW, h.Ws.size() * sizeof(double))) return fail(e);
-        s->dev_allocs.push_back(dW);
-        if (hipError_t e = hipMemcpy(dW, h.Ws.data(), h.Ws.size() * sizeof(double), hipMemcpyHostToDevice)) return fail(e);
-        SplitSched& S = s->sched[v];
-        S.G = G;
-        S.nc = h.nc;
-        S.NB = h.NB;
-        S.Ws = (const double*)dW;
-        for (int g = 0; g < G; ++g) S.base[g] = h.base[g];
+        for (int back = 0; back < 2; ++back) {
+            SplitScheduleHost h;
+            build_split_schedule(n, G, back ? Wb : W, h);
+            if (h.nc > 4) continue;
+            void* dW = nullptr;
+            if (hipError_t e = hipMalloc(&dW, h.Ws.size() * sizeof(double))) return fail(e);
+            s->dev_allocs.push_back(dW);
+            if (hipError_t e = hipMemcpy(dW, h.Ws.data(), h.Ws.size() * sizeof(double), hipMemcpyHostToDevice)) return fail(e);
+            SplitSched& S = back ? s->sched_b[v] : s->sched[v];
+            S.G = G;
+            S.nc = h.nc;
+            S.NB = h.NB;
+            S.Ws = (const double*)dW;
+            for (int g = 0; g < G; ++g) S.base[g] = h.base[g];
+        }
     }
     // more than 64 KiB of dynamic LDS has to be allowed once per kernel and device, outside any stream capture
     if (hipError_t e = split_allow_lds<2, false>()) return fail(e);
@@ -617,14 +767,14 @@ void split_host_destroy(SplitHost* s)
 {
     if (!s) return;
     for (void* p : s->dev_allocs) (void)hipFree(p);
-    for (auto& x : s->spare) {
+    auto free_set = [](SplitHost::Set& x) {
         if (x.partials) (void)hipFree(x.partials);
         if (x.counters) (void)hipFree(x.counters);
-    }
-    for (auto& kv : s->assigned) {
-        if (kv.second.partials) (void)hipFree(kv.second.partials);
-        if (kv.second.counters) (void)hipFree(kv.second.counters);
-    }
+        if (x.zt) (void)hipFree(x.zt);
+        if (x.yt) (void)hipFree(x.yt);
+    };
+    for (auto& x : s->spare) free_set(x);
+    for (auto& kv : s->assigned) free_set(kv.second);
     if (s->init_stream) (void)hipStreamDestroy(s->init_stream);
     delete s;
 }
@@ -669,13 +819,16 @@ static int pick_variant(const SplitHost* s, int64_t batch)
     return best;
 }
 
-template <bool TREE>
-static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, hipStream_t st)
+// MODE 0: ll.  MODE 1: ll + gradient: the z pass, the y pass (schedule of J W^T J) and, for tree states, the chain rule.
+template <bool TREE, int MODE>
+static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, double* G, int64_t ldg, double* gR, double* gtH,
+                               double* grMu, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
     SplitHost* s = const_cast<SplitHost*>(M.split);
     if (s == nullptr || batch > kSplitMaxBatch) return hipErrorInvalidValue;
-    const SplitSched& S = s->sched[pick_variant(s, batch)];
+    const int v = pick_variant(s, batch);
+    const SplitSched& S = s->sched[v];
     if (S.G == 0) return hipErrorInvalidValue;
     SplitHost::Set set;
     if (hipError_t e = scratch_for(s, st, set)) return e;
@@ -688,15 +841,38 @@ static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch,
 
     const int64_t tiles = (batch + 15) / 16;
     const unsigned grid = (scatter & 1) ? (unsigned)(tiles * S.G) : (unsigned)(((tiles + 7) / 8) * 8 * S.G);
-    
-#define MCD_SPLIT_LAUNCH(NC_) \
-    hipLaunchKernelGGL((k_split<NC_, TREE>), dim3(grid), dim3(tiles * S.G <= 256 ? split_threads<NC_>() : 64 * SP_NW), split_lds_bytes<NC_>(), st, M, S, A, batch, scatter, ll, set.partials, set.counters)
+    SplitGrad Gr{set.zt, nullptr, 0, 0};
+#define MCD_SPLIT_LAUNCH(NC_, TREE_, MODE_, S_) \
+    hipLaunchKernelGGL((k_split<NC_, TREE_, MODE_>), dim3(grid), dim3(tiles * S.G <= 256 ? split_threads<NC_>() : 64 * SP_NW), split_lds_bytes<NC_>(), st, M, S_, A, Gr, batch, scatter, ll, set.partials, set.counters)
     switch (S.nc) {
-    case 1: MCD_SPLIT_LAUNCH(1); break;
-    case 2: MCD_SPLIT_LAUNCH(2); break;
-    case 3: MCD_SPLIT_LAUNCH(3); break;
-    case 4: MCD_SPLIT_LAUNCH(4); break;
+    case 1: MCD_SPLIT_LAUNCH(1, TREE, MODE, S); break;
+    case 2: MCD_SPLIT_LAUNCH(2, TREE, MODE, S); break;
+    case 3: MCD_SPLIT_LAUNCH(3, TREE, MODE, S); break;
+    case 4: MCD_SPLIT_LAUNCH(4, TREE, MODE, S); break;
     default: return hipErrorInvalidValue;
+    }
+    if (hipError_t e = hipGetLastError()) return e;
+    if constexpr (MODE == 1) {
+        const SplitSched& Sb = s->sched_b[v];
+        if (Sb.G != S.G || Sb.nc != S.nc) return hipErrorInvalidValue;
+        Gr.out = TREE ? set.yt : G;
+        Gr.ldo = ldg;
+        Gr.t = TREE ? 1 : 0;
+        switch (S.nc) {
+        case 1: MCD_SPLIT_LAUNCH(1, false, 2, Sb); break;
+        case 2: MCD_SPLIT_LAUNCH(2, false, 2, Sb); break;
+        case 3: MCD_SPLIT_LAUNCH(3, false, 2, Sb); break;
+        case 4: MCD_SPLIT_LAUNCH(4, false, 2, Sb); break;
+        default: return hipErrorInvalidValue;
+        }
+        if (hipError_t e = hipGetLastError()) return e;
+        if constexpr (TREE) {
+            const size_t lds_bytes = (size_t)(A.T.n_nodes_pad + 16) * sizeof(double);
+            if (lds_bytes > 64 * 1024) return hipErrorInvalidValue;
+            const int nthr = A.T.n_nodes > 512 ? 1024 : A.T.n_nodes > 256 ? 512 : 256;
+            hipLaunchKernelGGL(k_split_tree_chain, dim3((unsigned)batch), dim3(nthr), lds_bytes, st, M.n, 16 * S.NB, A.T, A.H, A.Rt, A.lds, A.tH, A.rMu,
+                               (const double*)set.yt, G, gR, gtH, grMu);
+        }
     }
 #undef MCD_SPLIT_LAUNCH
     return hipGetLastError();
@@ -707,7 +883,17 @@ hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, in
     WideSrc A{};
     A.X = X;
     A.ldx = ldx;
-    return launch_split<false>(M, A, batch, ll, st);
+    return launch_split<false, 0>(M, A, batch, ll, nullptr, 0, nullptr, nullptr, nullptr, st);
+}
+
+// ll and d ll / d x = -Sigma^-1 (x - mu) as two triangular products on the row-split schedule (G may be X: the first launch
+// has read every x before the second writes)
+hipError_t launch_grad_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, hipStream_t st)
+{
+    WideSrc A{};
+    A.X = X;
+    A.ldx = ldx;
+    return launch_split<false, 1>(M, A, batch, ll, G, ldg, nullptr, nullptr, nullptr, st);
 }
 
 hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
@@ -721,7 +907,20 @@ hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const dou
     A.tH = tH;
     A.rMu = rMu;
     A.logjac = logjac;
-    return launch_split<true>(M, A, batch, ll, st);
+    return launch_split<true, 0>(M, A, batch, ll, nullptr, 0, nullptr, nullptr, nullptr, st);
+}
+
+hipError_t launch_tree_grad_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                  const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu, hipStream_t st)
+{
+    WideSrc A{};
+    A.T = T;
+    A.H = H;
+    A.Rt = Rt;
+    A.lds = lds;
+    A.tH = tH;
+    A.rMu = rMu;
+    return launch_split<true, 1>(M, A, batch, ll, gH, lds, gR, gtH, grMu, st);
 }
 
 }  // namespace mcd

@@ -138,6 +138,8 @@ hipError_t launch_tree_grad(const MvnDev& M, const TreeDev& T, const double* H, 
                             double* gtH, double* grMu, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (use_split_grad(M, batch) && (const double*)gH != Rt && (const double*)gR != H)   // (either output may be its own input, not the other's)
+        return launch_tree_grad_split(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
     if (use_wide_grad(M, batch)) {
         if (M.n <= 256) return launch_tree_grad_wide(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
         if ((const double*)gH != H && (const double*)gH != Rt)      // (the height-gradient rows double as scratch above 256)

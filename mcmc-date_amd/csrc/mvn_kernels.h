@@ -149,6 +149,10 @@ bool use_split(const MvnDev& M, int64_t batch);
 hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
 hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                     const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st);
+hipError_t launch_grad_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, hipStream_t st);
+hipError_t launch_tree_grad_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                  const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu, hipStream_t st);
+bool use_split_grad(const MvnDev& M, int64_t batch);
 int effective_form(const MvnDev& M);   // MCD_FORM_* in force for this handle
 hipError_t prepare_wide();            // per-device attribute set-up of the multiply-form kernels (current device)
 hipError_t prepare_wide_grad();

@@ -75,7 +75,7 @@ SP_HD void sp_for_each_segment(int NB, int G, int g, const SpGroup& q, int wave,
     }
 }
 
-// f(wf, wl) for every block of group `g` that is cut between waves: its partial z tiles sit in the slot 2 wf of wave wf (the
+// f(wf, wl, b) for every block b of group `g` that is cut between waves: its partial z tiles sit in the slot 2 wf of wave wf (the
 // block ends that wave's run) and in the slots 2 w - 1 of the waves wf < w <= wl (their runs begin inside it); wave order
 template <class F>
 SP_HD void sp_for_each_cut(int NB, int G, int g, const SpGroup& q, F&& f)
@@ -86,7 +86,7 @@ SP_HD void sp_for_each_cut(int NB, int G, int g, const SpGroup& q, F&& f)
         if (b >= NB) continue;
         const int e = s + 4 * (b + 1);
         const int wf = sp_wave_of(q, s), wl = sp_wave_of(q, e - 1);
-        if (wl > wf) f(wf, wl);
+        if (wl > wf) f(wf, wl, b);
         s = e;
     }
 }

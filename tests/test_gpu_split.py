@@ -2,6 +2,7 @@
 
 * parity with the oracle (bound of tests/test_gpu_parity.py) and with the column sweep over every staging shape (1 .. 4 chunks of
   256 columns), every number of row groups (G = 8 / 16 / 32), ragged tiles, padded rows;
+* both gradients on the same schedule (two triangular products, the second over the reversed rows; chain rule for tree states);
 * BASELINE config 5's per-GPU share at size: N = 1024 x 512 chains (raw x, 1023-node tree, both gradients);
 * the cross-workgroup hand-over under stress: > 10^6 back-to-back launches with ALTERNATING inputs, every result compared, a
   memory-heavy kernel running beside them, the row groups of a tile on one XCD and spread over all eight;
@@ -131,6 +132,93 @@ def test_row_split_tree_states(gpu, leaves, batch):
     ll_d, lj_d = tl.loglik(sd)
     torch.cuda.synchronize()
     assert np.array_equal(ll_d.cpu().numpy(), ll) and np.array_equal(lj_d.cpu().numpy(), lj)
+
+
+@pytest.mark.parametrize("n,batch", [(200, 40), (256, 512), (257, 9), (300, 64), (384, 512), (513, 100), (769, 17), (1000, 130), (1023, 1), (1024, 1000)])
+def test_row_split_gradient(gpu, n, batch):
+    """ll and d ll / d x = -Sigma^-1 (x - mu) as two triangular products on the row-split schedule (z = W r, then J y = (J W^T J)(J z)
+    over the reversed rows): against the oracle and the sweeps; every number of row groups; in place; padded rows untouched."""
+    import torch
+
+    mu, sigma, P, logdet, X, lik, ref, tol = problem(n, batch, seed=n)
+    kappa = np.linalg.cond(sigma)
+    ll, G = lik.grad(X)
+    assert np.array_equal(ll, lik.logpdf(X))                 # the same first product, the same bits
+    Gref = O.grad_full_batch(mu, P, X[:32])
+    gtol = 64 * n * EPS * kappa * np.abs(Gref).max() * 4
+    assert np.max(np.abs(G[:32] - Gref)) <= gtol, (np.max(np.abs(G[:32] - Gref)), gtol)
+    lik.set_form("sweep")
+    ll_s, G_s = lik.grad(X)
+    lik.set_form("auto")
+    assert np.max(np.abs(G_s - G)) <= gtol and np.all(np.abs(ll_s - ll) <= tol)
+    assert not np.array_equal(G_s, G)                        # really another kernel
+    for Gn in (8, 16, 32):
+        with env(MCD_SPLIT_G=Gn):
+            a = lik.grad(X)
+            with env(MCD_SPLIT_SCATTER=1):
+                b = lik.grad(X)
+        assert np.max(np.abs(a[1] - G_s)) <= gtol and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]), Gn
+    # device-resident, padded leading dimensions with NaN in the padding; then in place (G = X)
+    ld = n + 3
+    Xd = torch.full((batch, ld), np.nan, dtype=torch.float64, device=gpu)
+    Xd[:, :n] = torch.as_tensor(X, device=gpu)
+    Gp = torch.full((batch, n + 5), -7.0, dtype=torch.float64, device=gpu)
+    llp = torch.empty(batch, dtype=torch.float64, device=gpu)
+    lib = M._capi.lib()
+    M._capi.check(lib.mcd_mvn_grad_batch(lik._h, Xd.data_ptr(), ld, batch, 1, None, llp.data_ptr(), Gp.data_ptr(), n + 5))
+    torch.cuda.synchronize()
+    assert np.array_equal(Gp[:, :n].cpu().numpy(), G) and bool((Gp[:, n:] == -7.0).all()) and np.array_equal(llp.cpu().numpy(), ll)
+    M._capi.check(lib.mcd_mvn_grad_batch(lik._h, Xd.data_ptr(), ld, batch, 1, None, llp.data_ptr(), Xd.data_ptr(), ld))
+    torch.cuda.synchronize()
+    assert np.array_equal(Xd[:, :n].cpu().numpy(), G) and bool(torch.isnan(Xd[:, n:]).all()) and np.array_equal(llp.cpu().numpy(), ll)
+    _, G0 = lik.grad(mu[None, :])
+    assert np.all(G0 == 0.0)
+
+
+@pytest.mark.parametrize("leaves,batch", [(98, 512), (129, 96), (130, 512), (200, 33), (257, 100), (400, 512), (512, 512), (513, 7)])
+def test_row_split_tree_gradient(gpu, leaves, batch):
+    """The gradient wrt a tree state: the two products as above, y parked tile-major, then the chain rule (one workgroup per
+    chain): oracle values per chain, the sweeps' values for all; outputs may be their own inputs."""
+    import torch
+
+    topo = S.random_topology(leaves, seed=leaves)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=leaves)
+    P = np.linalg.inv(sigma)
+    logdet = np.linalg.slogdet(sigma)[1]
+    st = S.random_states(topo, batch, seed=leaves + 3)
+    tl = M.MvnLikelihood(M.Full(mu, P, logdet)).bind_tree(topo)
+    out = tl.grad(st)
+    ll, _ = tl.loglik(st)
+    assert np.array_equal(out[0], ll)
+    for b in sorted({0, batch // 2, batch - 1}):
+        gH, gR, gt, gm = O.tree_grad_full(topo.parent, st.heights[b], st.rates[b], st.time_height[b], st.rate_mean[b], mu, P)
+        sc = max(np.abs(gH).max(), np.abs(gR).max())
+        assert np.max(np.abs(out[1][b] - gH)) <= 1e-9 * sc and np.max(np.abs(out[2][b] - gR)) <= 1e-9 * sc
+        assert abs(out[3][b] - gt) <= 1e-9 * abs(gt) and abs(out[4][b] - gm) <= 1e-9 * abs(gm)
+    tl.mvn.set_form("sweep")
+    sw = tl.grad(st)
+    tl.mvn.set_form("auto")
+    sc = max(np.abs(sw[1]).max(), np.abs(sw[2]).max())
+    assert np.max(np.abs(sw[1] - out[1])) <= 1e-10 * sc and np.max(np.abs(sw[2] - out[2])) <= 1e-10 * sc
+    assert np.max(np.abs(sw[3] - out[3]) / np.abs(sw[3])) <= 1e-9 and np.max(np.abs(sw[4] - out[4]) / np.abs(sw[4])) <= 1e-9
+    assert not np.array_equal(sw[1], out[1])
+    with env(MCD_SPLIT_G=16, MCD_SPLIT_SCATTER=1):
+        og = tl.grad(st)
+    assert np.max(np.abs(og[1] - out[1])) <= 1e-10 * sc and np.max(np.abs(og[2] - out[2])) <= 1e-10 * sc
+    # device-resident; then the height gradient over the heights and the rate gradient over the rates
+    sd = st.to(gpu)
+    out_d = tl.grad(sd)
+    for a, b in zip(out, out_d):
+        assert np.array_equal(a, b.cpu().numpy())
+    H, R = sd.heights.clone(), sd.rates.clone()
+    llp = torch.empty(batch, dtype=torch.float64, device=gpu)
+    gt = torch.empty(batch, dtype=torch.float64, device=gpu)
+    gm = torch.empty(batch, dtype=torch.float64, device=gpu)
+    M._capi.check(M._capi.lib().mcd_tree_grad_batch(tl._t, H.data_ptr(), R.data_ptr(), H.stride(0), sd.time_height.data_ptr(), sd.rate_mean.data_ptr(),
+                                                    batch, 1, None, llp.data_ptr(), H.data_ptr(), R.data_ptr(), gt.data_ptr(), gm.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(H.cpu().numpy(), out[1]) and np.array_equal(R.cpu().numpy(), out[2]) and np.array_equal(gt.cpu().numpy(), out[3])
 
 
 def test_config5_share_of_one_gpu(gpu):
