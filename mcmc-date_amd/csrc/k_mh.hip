@@ -27,6 +27,16 @@
 
 namespace mcd {
 
+// diagnostic build (make stamp_mhstep): s_memtime ticks (shader cycles) per phase of wave 0 of workgroup 0, summed per proposal
+// kind; read back with mcd_mhstep_debug_stamps (tools/microbench/mhstep_stamps.py)
+#ifdef MCD_MHSTEP_STAMP
+__device__ unsigned long long g_mhs_acc[32 * 10];
+__device__ unsigned long long g_mhs_cnt[32];
+#define MHS_T(i) do { mhs[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MHS_T(i) do { } while (0)
+#endif
+
 // One launch between two likelihood launches: ACCEPT the pending step (proposal p_acc; its proposed state, ln prior, ln
 // likelihood and ln jacobianRootBranch are in H1/R1/sc1/post1) and PROPOSE the next one (proposal p_prop, its table row
 // passed by value) together with the ln prior of its proposed state.  Either half is skipped with a negative proposal
@@ -52,6 +62,10 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
     double* Hs = Rc + n;
     double* Rs = Hs + n;
     bool ok = false;
+#ifdef MCD_MHSTEP_STAMP
+    unsigned long long mhs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    MHS_T(0);
     if (p_acc >= 0) {
         const int p = p_acc;
         const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
@@ -69,6 +83,7 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
             if (trace_accept) trace_accept[b] = ok ? 1 : 0;
         }
     }
+    MHS_T(1);
     // the current state after the decision, into LDS (and back to global memory when it changed)
     const double* Hsrc = (ok ? M.H1 : M.H) + b * M.ld;
     const double* Rsrc = (ok ? M.R1 : M.R) + b * M.ld;
@@ -106,6 +121,7 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
     }
     if (p_prop < 0) return;
     __builtin_amdgcn_wave_barrier();
+    MHS_T(2);
     const double t = M.tune[b * M.n_prop + p_prop];
     // the state-independent draws of this step were computed by k_mh_draws, one thread per (step, chain)
     const double* dw = M.draws + ((size_t)draw_slot * B + b) * 5;
@@ -116,6 +132,7 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
     for (int i = 0; i < 5; ++i) sc0[i] = sc[i];
     const double lnqj = mh_propose_wave(M, row_prop, t, dr, lane, sc, Hc, Rc, Hs, Rs);
     __builtin_amdgcn_wave_barrier();
+    MHS_T(3);
     // re-evaluate only the blocks of the ln prior whose inputs the proposal moved (as k_mh_chain.hip does)
     bool dH = false, dR = false;
     for (int w0 = 0; w0 < n; w0 += 64) {
@@ -124,11 +141,15 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
         dH = dH || (__builtin_amdgcn_ballot_w64(in && Hs[in ? w : 0] != Hc[in ? w : 0]) != 0);
         dR = dR || (__builtin_amdgcn_ballot_w64(in && Rs[in ? w : 0] != Rc[in ? w : 0]) != 0);
     }
+    MHS_T(4);
     const double c0p = (dH || sc[2] != sc0[2]) ? prior_nodes_wave(P, lane, sc[2], Hs) : M.pcomp[b * 3 + 0];
+    MHS_T(5);
     const double c1p = (dH || sc[0] != sc0[0] || sc[1] != sc0[1]) ? prior_bd_wave(P, lane, sc[0], sc[1], Hs) : M.pcomp[b * 3 + 1];
+    MHS_T(6);
     const double c2p = (dR || sc[3] != sc0[3] || sc[4] != sc0[4] || (dH && P.clock_model >= 2)) ? prior_clock_wave(P, lane, sc[3], sc[4], Hs, Rs)
                                                                                              : M.pcomp[b * 3 + 2];
     const double lp1 = c0p + c1p + c2p;
+    MHS_T(7);
     if (lane == 0) {
         M.pcomp1[b * 3 + 0] = c0p;
         M.pcomp1[b * 3 + 1] = c1p;
@@ -149,6 +170,15 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
         M.lnqj[b] = lnqj;
         M.post1[b] = lp1;
     }
+#ifdef MCD_MHSTEP_STAMP
+    __builtin_amdgcn_s_waitcnt(0);
+    MHS_T(8);
+    if (b == 0 && lane == 0) {
+        const int k = row_prop.kind & 31;
+        for (int i = 0; i < 8; ++i) g_mhs_acc[k * 10 + i] += mhs[i + 1] - mhs[i];
+        g_mhs_cnt[k] += 1;
+    }
+#endif
 }
 
 // The state-independent draws (gamma multipliers with ratio and logarithm, the uniforms) of up to 64 consecutive steps: one
@@ -214,3 +244,11 @@ hipError_t launch_mh_tune(const MhDev& M, hipStream_t st)
 }
 
 }  // namespace mcd
+
+#ifdef MCD_MHSTEP_STAMP
+extern "C" int mcd_mhstep_debug_stamps(unsigned long long* acc, unsigned long long* cnt)
+{
+    if (hipMemcpyFromSymbol(acc, HIP_SYMBOL(mcd::g_mhs_acc), sizeof(unsigned long long) * 320)) return 1;
+    return (int)hipMemcpyFromSymbol(cnt, HIP_SYMBOL(mcd::g_mhs_cnt), sizeof(unsigned long long) * 32);
+}
+#endif
