@@ -72,27 +72,37 @@ __device__ unsigned long long g_split_dbg[2 * SP_NW * 16];
 #define SP_T(i) do { } while (0)
 #define SP_T_FLUSH() do { } while (0)
 #endif
-constexpr int SP_RING = 8;                                 // tile PAIRS in flight per wave (8 KiB)
+// tile PAIRS in flight per wave.  N <= 256: 8 (a wave's whole run: at most 4 groups of 4 tiles).  Far above, a wave streams hundreds
+// of tiles and what bounds it is the data in flight: a CU takes in 33-41 B/clk from L2 / Infinity Cache at
+// a latency of some 3 000 cycles, i.e. ~115 KB have to be under way per CU to keep that rate; 8 waves x 8 pairs are 64 KB,
+// 16 pairs 128 KB.  Measured (tools/gpu/ring2.sh, HIP events, 512 chains): N = 1024 21.3 -> 20.0 us, its gradient 42.2 -> 40.4;
+// N = 384 ... 768 and the tree states level or 1-4 % slower with 16 (more registers, a longer prologue): 16 only at NC = 4.
+template <int NC>
+constexpr int split_ring()
+{
+    return NC == 4 ? 16 : 8;
+}
 
 // One group: 4 tiles = the ring slots 2 PH and 2 PH + 1 against the four B operands in `bc`.  Software pipeline, written out
 // because the compiler's own ordering (every load as early as possible) makes a refilled slot overlap the value still waiting
 // for its MFMA, which costs a register copy and a full vmcnt drain at every loop end: the group first refills the two slots
-// the PREVIOUS group consumed (dead by now: the refill lands in the same registers) with the pairs 6 and 7 ahead, reads the
-// NEXT group's B operands from LDS into `bn`, then issues its own four MFMAs, whose operands were requested three groups
-// (A) and one group (B) ago; nothing moves across the group boundary.
-template <int PH>
-__device__ __forceinline__ void split_group(const d2* __restrict__ w, d2 (&ring)[SP_RING], int jp, int lastp, const double* rk_next,
+// the PREVIOUS group consumed (dead by now: the refill lands in the same registers) with the pairs RING - 2 and RING - 1 ahead,
+// reads the NEXT group's B operands from LDS into `bn`, then issues its own four MFMAs, whose operands were requested
+// RING / 2 - 1 groups (A) and one group (B) ago; nothing moves across the group boundary.
+template <int RING, int PH>
+__device__ __forceinline__ void split_group(const d2* __restrict__ w, d2 (&ring)[RING], int jp, int lastp, const double* rk_next,
                                             const double (&bc)[4], double (&bn)[4], d4& acc)
 {
-    constexpr int NP = SP_RING / 2, PR = (PH + NP - 1) % NP;
-    if (jp + SP_RING - 1 <= lastp) {                       // wave-uniform: no request past the end of the run (the loop end waits
+    constexpr int NP = RING / 2, PR = (PH + NP - 1) % NP;
+    if (jp + RING - 1 <= lastp) {                          // wave-uniform: no request past the end of the run (the loop end waits
 #pragma unroll                                             // for everything in flight: a useless load would cost a round trip)
-        for (int p = 0; p < 2; ++p) ring[2 * PR + p] = w[(jp + SP_RING - 2 + p) * 64];
+        for (int p = 0; p < 2; ++p) ring[2 * PR + p] = w[(jp + RING - 2 + p) * 64];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) bn[i] = rk_next[i * 4];
-    // one accumulator: a wave issues a v_mfma_f64_16x16x4_f64 every 64 cycles whether or not it depends on the one before
-    // (tools/microbench/mfma64: 1, 2 or 4 chains alike), and two waves of a SIMD each keep that rate
+    // one accumulator: a SIMD completes one v_mfma_f64_16x16x4_f64 per 64 cycles (26.9 ns: 77.9 TFLOP/s over the chip, the fp64
+    // matrix peak) whether the instructions depend on each other or not and whether one wave or two issue them
+    // (tools/microbench/mfma64, wall clock)
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH].x, bc[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH].y, bc[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[2 * PH + 1].x, bc[2], acc, 0, 0, 0);
@@ -102,32 +112,54 @@ __device__ __forceinline__ void split_group(const d2* __restrict__ w, d2 (&ring)
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // 4 MFMAs
 }
 
+// the groups K .. COUNT - 1 of one trip round the ring (phases PH + K, compile time), B operands alternating between b0 and b1
+template <int RING, int PH, int K, int COUNT>
+__device__ __forceinline__ void split_round(const d2* __restrict__ w, d2 (&ring)[RING], int jp, int lastp, const double* rk, double (&b0)[4],
+                                            double (&b1)[4], d4& acc)
+{
+    if constexpr (K < COUNT) {
+        constexpr int NP = RING / 2;
+        if constexpr (K % 2 == 0)
+            split_group<RING, (PH + K) % NP>(w, ring, jp + 2 * K, lastp, rk + 16 * (K + 1), b0, b1, acc);
+        else
+            split_group<RING, (PH + K) % NP>(w, ring, jp + 2 * K, lastp, rk + 16 * (K + 1), b1, b0, acc);
+        split_round<RING, PH, K + 1, COUNT>(w, ring, jp, lastp, rk, b0, b1, acc);
+    }
+}
+// the last `left` < RING / 2 groups of a run
+template <int RING, int PH, int K>
+__device__ __forceinline__ void split_tail(const d2* __restrict__ w, d2 (&ring)[RING], int jp, int lastp, int left, const double* rk,
+                                           double (&b0)[4], double (&b1)[4], d4& acc)
+{
+    constexpr int NP = RING / 2;
+    if constexpr (K < NP - 1) {
+        if (K < left) {
+            if constexpr (K % 2 == 0)
+                split_group<RING, (PH + K) % NP>(w, ring, jp + 2 * K, lastp, rk + 16 * (K + 1), b0, b1, acc);
+            else
+                split_group<RING, (PH + K) % NP>(w, ring, jp + 2 * K, lastp, rk + 16 * (K + 1), b1, b0, acc);
+            split_tail<RING, PH, K + 1>(w, ring, jp, lastp, left, rk, b0, b1, acc);
+        }
+    }
+}
+
 // ng groups starting at phase PH (compile time); jp = pair index of the first group; rk = this lane's B operand of the first
 // k tile.  The B operands one group past the end of the run are read and dropped (LDS behind rs is the kernel's own).
-template <int PH>
-__device__ __forceinline__ void split_run(const d2* __restrict__ w, d2 (&ring)[SP_RING], int jp, int lastp, int ng, const double* rk, d4& acc)
+template <int RING, int PH>
+__device__ __forceinline__ void split_run(const d2* __restrict__ w, d2 (&ring)[RING], int jp, int lastp, int ng, const double* rk, d4& acc)
 {
-    constexpr int NP = SP_RING / 2;
+    constexpr int NP = RING / 2;
     double b0[4], b1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) b0[i] = rk[i * 4];
     __builtin_amdgcn_sched_barrier(0);
     int g = 0;
     for (; g + NP <= ng; g += NP) {
-        split_group<PH>(w, ring, jp, lastp, rk + 16, b0, b1, acc);
-        split_group<(PH + 1) % NP>(w, ring, jp + 2, lastp, rk + 32, b1, b0, acc);
-        split_group<(PH + 2) % NP>(w, ring, jp + 4, lastp, rk + 48, b0, b1, acc);
-        split_group<(PH + 3) % NP>(w, ring, jp + 6, lastp, rk + 64, b1, b0, acc);
-        jp += 8;
-        rk += 64;
+        split_round<RING, PH, 0, NP>(w, ring, jp, lastp, rk, b0, b1, acc);
+        jp += 2 * NP;
+        rk += 16 * NP;
     }
-    if (g < ng) {
-        split_group<PH>(w, ring, jp, lastp, rk + 16, b0, b1, acc);
-        if (g + 1 < ng) {
-            split_group<(PH + 1) % NP>(w, ring, jp + 2, lastp, rk + 32, b1, b0, acc);
-            if (g + 2 < ng) split_group<(PH + 2) % NP>(w, ring, jp + 4, lastp, rk + 48, b0, b1, acc);
-        }
-    }
+    if (g < ng) split_tail<RING, PH, 0>(w, ring, jp, lastp, ng - g, rk, b0, b1, acc);
 }
 
 // grid = ceil(tiles / 8) * 8 * G; block = 576 threads: 8 working waves (two per SIMD) and a helper wave, which takes the
@@ -193,18 +225,10 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
         if constexpr (MODE != 2) {
             if (lane == 0) ticket = __hip_atomic_fetch_add(&counter[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        int ncut = 0, cuts[SP_NW - 1] = {0, 0, 0, 0, 0, 0, 0};
-        sp_for_each_cut(NB, G, grp, sg, [&](int wf, int wl, int blk) {
-#pragma unroll
-            for (int x = 0; x < SP_NW - 1; ++x)
-                if (ncut == x) cuts[x] = wf | (wl << 4) | (blk << 8);
-            ++ncut;
-        });
-        if (lane == 0) {
+        if (lane == 0) {                                   // the cut blocks come with the schedule (kernel argument)
             aux[0] = (int)ticket;
-            aux[1] = ncut;
 #pragma unroll
-            for (int x = 0; x < SP_NW - 1; ++x) aux[2 + x] = cuts[x];
+            for (int x = 0; x < SP_NW; ++x) aux[1 + x] = S.cuts[grp][x];
         }
     };
     if (HELPER && wave == SP_NW) {                         // the helper wave
@@ -228,16 +252,17 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     const d2* __restrict__ w = reinterpret_cast<const d2*>(S.Ws) + (int64_t)((S.base[grp] + lo) >> 1) * 64 + lane;
     // (N <= 256, where a microsecond counts.  Above, the staging needs the registers -- a ring kept alive across it gets
     // spilled, and reloaded inside the multiply loop -- and the first tiles are requested once the staging loads are done.)
-    d2 ring[SP_RING];
+    constexpr int RING = split_ring<NC>();
+    d2 ring[RING];
     if constexpr (NC == 1) {
 #pragma unroll
-        for (int p = 0; p < SP_RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
+        for (int p = 0; p < RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
     }
 
     // a run that fits the ring (at most 4 groups of 4 tiles: N <= 352 with 8 row groups) is multiplied by straight-line code
     // with the ring slots as they stand; what each group needs -- its first k tile, and whether it ends a segment and how --
     // is worked out here, under the latency of the loads above
-    const bool fits = npair <= SP_RING;
+    const bool fits = NC == 1 && npair <= RING;            // (above N = 256 the general walk serves short runs as well)
     int gk[4] = {0, 0, 0, 0}, ge[4] = {-1, -1, -1, -1};
     if (fits && T > 0) {
         int gi = 0;
@@ -389,15 +414,15 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
     }
     if constexpr (NC > 1) {
 #pragma unroll
-        for (int p = 0; p < SP_RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
+        for (int p = 0; p < RING; ++p) ring[p] = w[(p < lastp ? p : lastp) * 64];
     }
     SP_T(1);
     __syncthreads();
     if (flags & 8) return;                                 // timing probe: launch + staging
 
     // ---- this wave's run of tiles: z tile += W tile x R tile, segment after segment.  A segment (a run of k tiles inside
-    // one row block) is a whole number of groups of 4 tiles = 2 ring slots; the ring has SP_RING slots, so a group's slots
-    // are known at compile time once its phase (group index mod SP_RING / 2) is: split_run is instantiated per starting phase
+    // one row block) is a whole number of groups of 4 tiles = 2 ring slots; the ring has RING slots, so a group's slots
+    // are known at compile time once its phase (group index mod RING / 2) is: split_run is instantiated per starting phase
     double ss = 0.0;                                       // sum of squares of the blocks this wave holds completely
     SP_T(2);
     // a finished z tile (block blk) leaves the workgroup (MODE 1, 2): lane = (chain col, row quarter kq), rows kq + 4 q
@@ -469,14 +494,27 @@ __global__ void __launch_bounds__(split_threads<NC>(), NC == 1 ? 3 : 2) k_split(
             const int ng = nt >> 2;
             d4 acc = d4{0.0, 0.0, 0.0, 0.0};
             const double* rk = rb + k0 * 4;
-            switch (ph) {
-            case 0: split_run<0>(w, ring, jp, lastp, ng, rk, acc); break;
-            case 1: split_run<1>(w, ring, jp, lastp, ng, rk, acc); break;
-            case 2: split_run<2>(w, ring, jp, lastp, ng, rk, acc); break;
-            default: split_run<3>(w, ring, jp, lastp, ng, rk, acc); break;
+            if constexpr (RING == 8) {
+                switch (ph) {
+                case 0: split_run<RING, 0>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 1: split_run<RING, 1>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 2: split_run<RING, 2>(w, ring, jp, lastp, ng, rk, acc); break;
+                default: split_run<RING, 3>(w, ring, jp, lastp, ng, rk, acc); break;
+                }
+            } else {
+                switch (ph) {
+                case 0: split_run<RING, 0>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 1: split_run<RING, 1>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 2: split_run<RING, 2>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 3: split_run<RING, 3>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 4: split_run<RING, 4 % (RING / 2)>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 5: split_run<RING, 5 % (RING / 2)>(w, ring, jp, lastp, ng, rk, acc); break;
+                case 6: split_run<RING, 6 % (RING / 2)>(w, ring, jp, lastp, ng, rk, acc); break;
+                default: split_run<RING, 7 % (RING / 2)>(w, ring, jp, lastp, ng, rk, acc); break;
+                }
             }
             jp += 2 * ng;
-            ph = (ph + ng) & (SP_RING / 2 - 1);
+            ph = (ph + ng) & (RING / 2 - 1);
             flush(acc, kind, (nt >> 2) - 1);               // (kind 0: the segment is the whole block, 4 (blk + 1) tiles)
         });
     }
@@ -745,7 +783,17 @@ SplitHost* split_host_create(int n, const double* W_rowmajor, hipError_t* err)
             S.nc = h.nc;
             S.NB = h.NB;
             S.Ws = (const double*)dW;
-            for (int g = 0; g < G; ++g) S.base[g] = h.base[g];
+            for (int g = 0; g < G; ++g) {
+                S.base[g] = h.base[g];
+                const SpGroup q = sp_group(h.NB, G, g);
+                int ncut = 0;
+                sp_for_each_cut(h.NB, G, g, q, [&](int wf, int wl, int blk) {
+                    if (ncut < SP_NW - 1) S.cuts[g][1 + ncut] = wf | (wl << 4) | (blk << 8);
+                    ++ncut;
+                });
+                if (ncut > SP_NW - 1) return fail(hipErrorInvalidValue);     // (a run is contiguous: at most SP_NW - 1 cuts)
+                S.cuts[g][0] = ncut;
+            }
         }
     }
     // more than 64 KiB of dynamic LDS has to be allowed once per kernel and device, outside any stream capture

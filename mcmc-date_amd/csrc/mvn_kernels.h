@@ -33,6 +33,8 @@ struct SplitSched {
     int NB;                 // row blocks of 16 rows
     const double* Ws;       // tile streams of all groups (device)
     int base[32];           // first tile of group g's stream
+    int cuts[32][8];        // group g's row blocks that are cut between waves: [0] = how many, then wf | wl << 4 | block << 8
+                            // (sp_for_each_cut, worked out on the host: hundreds of scalar instructions per workgroup otherwise)
 };
 
 // Topology tables of the time/rate trees (pre-order node ids, root = 0).

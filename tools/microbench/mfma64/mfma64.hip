@@ -41,8 +41,39 @@ void run(int threads, int n)
     hipFree(cyc);
 }
 
+// wall clock (HIP events) of a long run: ns per MFMA per SIMD, whatever s_memtime counts
+template <int NACC>
+void wall(int threads, int n)
+{
+    double* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, 256 * 512 * 8);
+    hipMalloc(&cyc, 256 * 8 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<NACC>, dim3(256), dim3(threads), 0, 0, out, cyc, n, 1.0, 2.0);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k<NACC>, dim3(256), dim3(threads), 0, 0, out, cyc, n, 1.0, 2.0);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[8];
+    hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+    const double per_simd = (double)n * (threads / 256);
+    printf("wall: acc chains %d, waves/SIMD %d, %d MFMAs per wave: %.3f ms -> %.2f ns per MFMA per SIMD = %.1f TFLOP/s fp64 on 1024 SIMDs; s_memtime ticks per ns %.3f\n",
+           NACC, threads / 256, n, ms, 1e6 * ms / per_simd, 2048.0 * per_simd * 1024 / (ms * 1e-3) * 1e-12, (double)h[0] / (1e6 * ms));
+    hipFree(out);
+    hipFree(cyc);
+}
+
 int main()
 {
+    for (int threads : {256, 512}) {
+        wall<1>(threads, 400000);
+        wall<4>(threads, 400000);
+    }
     for (int n : {12, 48, 480}) {
         for (int threads : {256, 512}) {
             run<1>(threads, n);
