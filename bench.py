@@ -290,7 +290,7 @@ def main():
         form = args.form
     else:
         form = "multiply" if ((n >= 96 and B >= 2048) or (n >= 32 and B >= 8192)) else "sweep"
-        if (args.kind in ("logpdf", "tree") and B <= 1024 and (n > 256 or (n > 192 and B <= 32))) or \
+        if (args.kind in ("logpdf", "tree") and B <= 1024 and (n > 256 or (n > 240 and B <= 128))) or \
                 (has_grad and B <= 1024 and (n > 256 or (n > 240 and B <= 512))):
             form = "split"                               # k_split.hip: W's row blocks over 8-32 workgroups per chain tile
     # hipGraph replay hides the per-launch dispatch cost of the few-microsecond sweep launches; the multiply form's launches

@@ -61,7 +61,7 @@ const char* mcd_last_error(void);
 /*
  * Which form of the log-density kernels a launch uses (results agree to rounding, not bit for bit):
  *   MCD_FORM_AUTO     (default) by dimension and batch size: the column sweep up to N = 256 at a sampler's usual batch; for
- *                     N > 256 and up to 1024 chains (192 < N <= 256: up to 32) a row-split variant of the multiply form
+ *                     N > 256 and up to 1024 chains (240 < N <= 256: up to 128) a row-split variant of the multiply form
  *                     (k_split.hip: the row blocks of L^-1 dealt to 8-32 workgroups per 16-chain tile, partial sums handed over
  *                     through a per-stream scratch owned by the handle), raw x and tree states alike; the multiply form from
  *                     2048 chains at N >= 96, from 8192 at N >= 32;

@@ -120,18 +120,18 @@ bool use_wide(const MvnDev& M, int64_t batch)
 
 bool use_split(const MvnDev& M, int64_t batch)
 {
-    // measured window (tools/gpu/window.sh, profiles/r02_split_window.jsonl; raw x and tree states alike): above N = 256 -- five
-    // or more 64-row blocks in the sweep's dependent chain -- the row split wins for every batch from 1 to 1024 chains, by 1.6x at
-    // N = 384 to 6.5x at N = 1024; at 192 < N <= 256 only while a handful of CUs would carry the sweep (up to 32 chains: 6.5
-    // against 7.3 us), from 64 chains the sweep's single launch-to-result path is shorter (7.7 against 8.1 us at 512 chains: the
-    // split pays two memory round trips for handing partial sums over); at N <= 192 the sweep wins everywhere; from 2048 chains
-    // k_wide takes over
+    // measured window (tools/gpu/window.sh, window2.sh; profiles/r02_split_window.jsonl, r02_split_window_240.jsonl; raw x and
+    // tree states alike): above N = 256 -- five or more 64-row blocks in the sweep's dependent chain -- the row split wins for every
+    // batch from 1 to 1024 chains, by 1.6x at N = 384 to 6.5x at N = 1024; at 240 < N <= 256 up to 128 chains (6.95-7.25 against
+    // 7.4-7.5 us); from 256 chains the sweep's single launch-to-result path is shorter (7.7 against 7.9 us at 512 chains: the split
+    // pays about two memory round trips for handing the partial sums over); at N = 200 and 224 (13 / 14 row blocks over 8 groups:
+    // uneven) and below the sweep wins everywhere; from 2048 chains k_wide takes over
     const char* env = getenv("MCD_SPLIT");                 // tests and tuning: 1 = wherever possible, 0 = never (read per launch)
     const int force = env ? atoi(env) : -1;
     if (effective_form(M) != 0 || M.split == nullptr || batch < 1 || batch > kSplitMaxBatch || force == 0) return false;
     if (force == 1) return true;
     if (M.n > 256) return true;
-    return M.n > 192 && batch <= 32;
+    return M.n > 240 && batch <= 128;
 }
 
 bool use_split_grad(const MvnDev& M, int64_t batch)

@@ -160,7 +160,7 @@ def test_synthetic_logpdf_and_grad(gpu, n, batch):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ll)
     ll2, G = lik.grad(X)
-    split_ll = (n > 256 and batch <= 1024) or (192 < n <= 256 and batch <= 32)      # use_split (csrc/k_logpdf.hip)
+    split_ll = (n > 256 and batch <= 1024) or (240 < n <= 256 and batch <= 128)     # use_split (csrc/k_logpdf.hip)
     split_grad = batch <= 1024 and (n > 256 or (n > 240 and batch <= 512))          # use_split_grad
     if split_ll == split_grad:
         assert np.array_equal(ll2, ll)                       # the same forward product, the same bits

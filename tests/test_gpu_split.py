@@ -44,7 +44,7 @@ class env:
 
 @pytest.fixture(autouse=True)
 def split_wherever_possible():
-    """The automatic choice takes the row split above N = 256 (192 < N <= 256: up to 32 chains); these tests exercise it over
+    """The automatic choice takes the row split above N = 256 (240 < N <= 256: up to 128 chains); these tests exercise it over
     its whole range (N > 128, up to 1024 chains): MCD_SPLIT=1, read per launch."""
     with env(MCD_SPLIT=1):
         yield
