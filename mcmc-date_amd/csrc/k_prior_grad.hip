@@ -4,7 +4,7 @@
 //
 //   d ln priorFunction ht md cb cs bs x / d (birth, death, tH, heights, rMu, rVar, rates)        (app/Probability.hs:127-150)
 //
-// Mapping as k_prior.hip: one wave per chain, lanes = nodes.  Every per-node term of the birth-death block depends on
+// Mapping: one workgroup per chain, threads = nodes (see the kernel).  Every per-node term of the birth-death block depends on
 // (la, mu, h_v, h_parent), every per-node term of the clock block on (r_v, rVar, h_v, h_parent): they are evaluated
 // with FORWARD-MODE DUAL NUMBERS carrying four tangents, with exactly the value formulas of prior_device.hpp, so the
 // derivative code cannot drift from the value code.  The contribution to the parent's height goes through LDS and is
@@ -132,7 +132,12 @@ __device__ __forceinline__ D4 d_ln_lognormal_prime(const D4& v, const D4& x)
 
 }  // namespace
 
-__global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __restrict__ birth, const double* __restrict__ death,
+// One WORKGROUP per chain (1 .. 4 waves: a thread per node up to 256 nodes).  With one wave per chain the kernel was a chain of
+// four trips through the dual-number exponentials / logarithms for a 255-node tree, and a fifth and sixth through the value
+// formulas (23 us for 512 chains, rocprofv3; the largest part of a leapfrog step).  Every per-node quantity goes to LDS; wave 0
+// adds them up in the order the one-wave kernel used -- lane by lane over v = lane + 64 it for the tangents, over
+// v = 1 + lane + 64 it for the values (prior_bd_wave / prior_clock_wave) -- so the results are the same bits.
+__global__ void __launch_bounds__(256, 2) k_prior_grad(PriorDev P, const double* __restrict__ birth, const double* __restrict__ death,
                                                     const double* __restrict__ tH, const double* __restrict__ H,
                                                     const double* __restrict__ rMu, const double* __restrict__ rVar,
                                                     const double* __restrict__ Rt, int64_t lds, int64_t batch,
@@ -142,20 +147,24 @@ __global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __
                                                     double* __restrict__ g_rVar, double* __restrict__ g_R)
 {
     extern __shared__ double sh[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (b >= batch) return;                                   // wave-uniform; no workgroup barriers in this kernel
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.x;
     const int n = P.n_nodes;
-    double* gh = sh + (size_t)wave * 2 * n;                   // [n] d/d h_v
+    double* gh = sh;                                          // [n] d/d h_v
     double* ep = gh + n;                                      // [n] contribution of node v's terms to its parent's height
+    double* a_la = ep + n;                                    // [n] per-node tangents wrt birth, death, rate variance
+    double* a_mu = a_la + n;
+    double* a_va = a_mu + n;
+    double* vb = a_va + n;                                    // [n] per-node summands of the VALUE (birth-death, clock)
+    double* vc = vb + n;
+    double* bc = vc + n;                                      // [2] wave 0 -> all: inside the support?
     const double* h = H + b * lds;
     const double* r = Rt + b * lds;
     const double la = birth[b], mu = death[b], th = tH[b], rm = rMu[b], va = rVar[b];
-    const bool near = 1e-6 > fabs(la - mu);
+    const bool near = prior_bd_near(la, mu);
     const double la_d = near ? mu + ((la >= mu) ? 1e-6 : -1e-6) : la;     // see the note on the near-critical regime above
-    double bd = 0.0, clock = 0.0, s_la = 0.0, s_mu = 0.0, s_va = 0.0;
-    for (int v = lane; v < n; v += 64) {
+    for (int v = tid; v < n; v += nthr) {
         if (v == 0) {
             gh[0] = 0.0;
             ep[0] = 0.0;
@@ -198,18 +207,25 @@ __global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __
                 default: term_ck = d_ln_lognormal_prime(dva * br2, rate); break;
             }
         }
-        bd += term_bd.v;
-        clock += term_ck.v;
-        s_la += term_bd.d[0];
-        s_mu += term_bd.d[1];
-        s_va += term_ck.d[1];
+        a_la[v] = term_bd.d[0];
+        a_mu[v] = term_bd.d[1];
+        a_va[v] = term_ck.d[1];
         gh[v] = term_bd.d[2] + term_ck.d[2];
         ep[v] = term_bd.d[3] + term_ck.d[3];
         g_R[b * lds + v] = term_ck.d[0];
     }
-    __builtin_amdgcn_wave_barrier();
+    // the value is the one of mcd_prior_logprior_batch (same code); the dual values above only carry the tangents.  (A loop of
+    // its own: in one loop with the duals the two do not fit the registers of two waves per SIMD.)
+    ClockCache cc;
+    prior_clock_scalars(va, cc);
+    for (int v = tid; v < n; v += nthr) {
+        if (v == 0) continue;
+        vb[v] = prior_bd_term(P, v, near, la, mu, h);
+        vc[v] = prior_clock_term(P, v, va, cc.lg_k, cc.log_t, h, r);
+    }
+    __syncthreads();
     // gather the children's contributions (pre-order: first child = v + 1, the second follows the first one's sub tree)
-    for (int v = lane; v < n; v += 64) {
+    for (int v = tid; v < n; v += nthr) {
         double acc = gh[v];
         const int nc = P.n_children[v];
         if (nc > 0) {
@@ -217,12 +233,14 @@ __global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __
             acc += ep[c1];
             if (nc > 1) acc += ep[P.second_child[v]];
         }
-        gh[v] = acc;
+        gh[v] = acc;                                          // (only this thread reads or writes gh[v] here; ep is read-only)
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    double total = 0.0, gla = 0.0, gmu = 0.0, gva = 0.0, s_th = 0.0;
+    bool ok = false;
+    if (wave == 0) {
     // ---- soft node priors: value lane-parallel (as prior_nodes_wave), derivative added by lane 0 in table order ----
     const double c0 = prior_nodes_wave(P, lane, th, h);
-    double s_th = 0.0;
     if (lane == 0) {
         const double x = 1.0 / th;
         for (int i = 0; i < P.n_cal; ++i) {
@@ -274,19 +292,33 @@ __global__ void __launch_bounds__(256) k_prior_grad(PriorDev P, const double* __
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    const double gla = pr_wave_sum(s_la), gmu = pr_wave_sum(s_mu), gva = pr_wave_sum(s_va);
-    // the value is the one of mcd_prior_logprior_batch (same code); the dual values above only carry the tangents
-    const double total = c0 + prior_bd_wave(P, lane, la, mu, h) + prior_clock_wave(P, lane, rm, va, h, r);
-    const bool ok = total == total && total > kNegInf;            // inside the support
-    (void)bd;
-    (void)clock;
-    const double bad = __builtin_nan("");
+    // the sums, lane by lane in the one-wave kernel's order: tangents over v = lane + 64 it (v = 0 carries none) ...
+    double s_la = 0.0, s_mu = 0.0, s_va = 0.0;
     for (int v = lane; v < n; v += 64) {
+        if (v == 0) continue;
+        s_la += a_la[v];
+        s_mu += a_mu[v];
+        s_va += a_va[v];
+    }
+    gla = pr_wave_sum(s_la);
+    gmu = pr_wave_sum(s_mu);
+    gva = pr_wave_sum(s_va);
+    // ... values over v = 1 + lane + 64 it, closed as prior_bd_wave / prior_clock_wave close them
+    double bd = 0.0, clock = 0.0;
+    for (int v = 1 + lane; v < n; v += 64) bd += vb[v];
+    for (int v = 1 + lane; v < n; v += 64) clock += vc[v];
+    total = c0 + prior_bd_finish(pr_wave_sum(bd), la, mu) + prior_clock_finish(P, pr_wave_sum(clock), rm, va, cc.hyper);
+    ok = total == total && total > kNegInf;                   // inside the support
+    if (lane == 0) bc[0] = ok ? 1.0 : 0.0;
+    }
+    __syncthreads();                                          // lane 0's additions to gh, the verdict
+    ok = bc[0] != 0.0;
+    const double bad = __builtin_nan("");
+    for (int v = tid; v < n; v += nthr) {
         g_H[b * lds + v] = ok ? gh[v] : bad;
         if (!ok) g_R[b * lds + v] = bad;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         lp[b] = total;
         g_birth[b] = ok ? gla - 1.0 : bad;                    // d/d la [ln exponential 1 la] = -1
         g_death[b] = ok ? gmu - 1.0 : bad;
@@ -302,12 +334,17 @@ hipError_t launch_prior_grad(const PriorDev& P, const double* birth, const doubl
                              hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
-    const size_t per_wave = sizeof(double) * 2 * (size_t)P.n_nodes;
-    int wpb = 4;
-    while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;
-    if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
-    const unsigned grid = (unsigned)((batch + wpb - 1) / wpb);
-    hipLaunchKernelGGL(k_prior_grad, dim3(grid), dim3(64 * wpb), per_wave * wpb, st, P, birth, death, tH, H, rMu, rVar, Rt, lds, batch, lp,
+    const size_t bytes = sizeof(double) * (7 * (size_t)P.n_nodes + 2);
+    if (bytes > 64 * 1024) return hipErrorInvalidValue;
+    // waves per chain: as many as the tree has 64-node slices (at most 4) while the whole batch is resident at once (2 waves
+    // per SIMD: 2048 on the chip); beyond that more waves per chain only add rounds (4096 chains x 255 nodes: 115 us with one
+    // wave per chain, 143 with four)
+    int waves = (P.n_nodes + 63) / 64;
+    const int64_t fit = 2048 / batch;
+    waves = waves > 4 ? 4 : waves;
+    waves = waves > fit ? (int)fit : waves;
+    waves = waves < 1 ? 1 : waves;
+    hipLaunchKernelGGL(k_prior_grad, dim3((unsigned)batch), dim3(64 * waves), bytes, st, P, birth, death, tH, H, rMu, rVar, Rt, lds, batch, lp,
                        g_birth, g_death, g_tH, g_H, g_rMu, g_rVar, g_R);
     return hipGetLastError();
 }

@@ -133,49 +133,60 @@ __device__ __forceinline__ double prior_nodes_wave(const PriorDev& P, int lane, 
     return c0;
 }
 
-__device__ __forceinline__ double prior_bd_wave(const PriorDev& P, int lane, double la, double mu, const double* h)
+// The birth-death and the clock blocks are sums over the nodes v = 1 .. n_nodes - 1, taken lane by lane over v = 1 + lane + 64 it
+// (it ascending) and then over the wave.  The summand of one node and the closing scalar terms are functions of their own, so
+// that a caller may deal the nodes to several waves and add the summands up in the same order (k_prior_grad.hip): the same
+// function values, the same order, the same bits.
+__device__ __forceinline__ double prior_bd_term(const PriorDev& P, int v, bool near, double la, double mu, const double* h)
 {
-    const bool near = 1e-6 > fabs(la - mu);                    // epsNearCritical, BirthDeath.hs:117-118
-    double bd = 0.0;
-    for (int v = 1 + lane; v < P.n_nodes; v += 64) {
-        const int pv = P.parent[v];
-        const double br = h[pv] - h[v];                        // heightTreeToLengthTree
-        // E at the bottom of v's branch
-        double e_bottom = 0.0;
-        const int nc = P.n_children[v];
-        if (nc > 0 && !near) {
-            const double xx = exp(-(la - mu) * h[v]);
-            e_bottom = mu * (1.0 - xx) / (la - mu * xx);
-        } else if (nc > 0) {   // near-critical: compose branch by branch like the reference, tip first
-            int u = P.first_child[v];
-            int depth = 1;
-            while (P.n_children[u] > 0) { u = P.first_child[u]; ++depth; }
-            double e = 0.0;                                    // below a tip: E = 0 with the tip's sampling rate
-            for (int i = 0; i < depth; ++i) {                  // u climbs from the tip to first_child[v]
-                const double bu = h[P.parent[u]] - h[u];
-                if (bu <= 0) {
-                    e = 1.0;                                   // `| br <= 0 = (0.0, 1.0)`
-                } else {
-                    double dd, ee;
-                    compute_de(near, la, mu, 1.0, bu, e, dd, ee);   // rho = 1 everywhere in priorFunctionBirthDeath
-                    e = ee;
-                }
-                u = P.parent[u];
+    const int pv = P.parent[v];
+    const double br = h[pv] - h[v];                            // heightTreeToLengthTree
+    // E at the bottom of v's branch
+    double e_bottom = 0.0;
+    const int nc = P.n_children[v];
+    if (nc > 0 && !near) {
+        const double xx = exp(-(la - mu) * h[v]);
+        e_bottom = mu * (1.0 - xx) / (la - mu * xx);
+    } else if (nc > 0) {   // near-critical: compose branch by branch like the reference, tip first
+        int u = P.first_child[v];
+        int depth = 1;
+        while (P.n_children[u] > 0) { u = P.first_child[u]; ++depth; }
+        double e = 0.0;                                        // below a tip: E = 0 with the tip's sampling rate
+        for (int i = 0; i < depth; ++i) {                      // u climbs from the tip to first_child[v]
+            const double bu = h[P.parent[u]] - h[u];
+            if (bu <= 0) {
+                e = 1.0;                                       // `| br <= 0 = (0.0, 1.0)`
+            } else {
+                double dd, ee;
+                compute_de(near, la, mu, 1.0, bu, e, dd, ee);   // rho = 1 everywhere in priorFunctionBirthDeath
+                e = ee;
             }
-            e_bottom = e;
+            u = P.parent[u];
         }
-        if (br <= 0) {
-            bd += kNegInf;
-        } else {
-            double dT, eT;
-            compute_de(near, la, mu, 1.0, br, e_bottom, dT, eT);
-            bd += log(dT * ((nc == 2) ? la : 1.0));            // internal node: dT * la; tip / unary: dT * rho, rho = 1
-        }
+        e_bottom = e;
     }
-    double c1 = pr_wave_sum(bd);
+    if (br <= 0) return kNegInf;
+    double dT, eT;
+    compute_de(near, la, mu, 1.0, br, e_bottom, dT, eT);
+    return log(dT * ((nc == 2) ? la : 1.0));                   // internal node: dT * la; tip / unary: dT * rho, rho = 1
+}
+
+__device__ __forceinline__ bool prior_bd_near(double la, double mu) { return 1e-6 > fabs(la - mu); }   // epsNearCritical, BirthDeath.hs:117-118
+
+// c1 from the wave sum of the summands
+__device__ __forceinline__ double prior_bd_finish(double c1, double la, double mu)
+{
     if (la < 0 || mu < 0) c1 = __builtin_nan("");              // birthDeath: `error` on negative rates
     c1 += ln_exponential(1.0, la) + ln_exponential(1.0, mu);   // app/Probability.hs:72-73
     return c1;
+}
+
+__device__ __forceinline__ double prior_bd_wave(const PriorDev& P, int lane, double la, double mu, const double* h)
+{
+    const bool near = prior_bd_near(la, mu);
+    double bd = 0.0;
+    for (int v = 1 + lane; v < P.n_nodes; v += 64) bd += prior_bd_term(P, v, near, la, mu, h);
+    return prior_bd_finish(pr_wave_sum(bd), la, mu);
 }
 
 // Wave-uniform pieces of the clock block that depend on the rate variance only: lgamma and two logarithms.  A caller
@@ -185,46 +196,52 @@ struct ClockCache {
     double va, lg_k, log_t, hyper;    // lgamma(1 / va), log(va), ln gamma(3/2, 1/6)(va)
 };
 
-__device__ __forceinline__ double prior_clock_wave(const PriorDev& P, int lane, double rm, double va, const double* h,
-                                                   const double* r, ClockCache* cache = nullptr)
+__device__ __forceinline__ void prior_clock_scalars(double va, ClockCache& c)
 {
-    double lg_k, log_t, hyper;
-    if (cache != nullptr && cache->va == va) {
-        lg_k = cache->lg_k;
-        log_t = cache->log_t;
-        hyper = cache->hyper;
-    } else {
-        lg_k = lgamma(1.0 / va);
-        log_t = log(va);
-        hyper = ln_gamma_pdf(1.5, 1.0 / 6.0, va);                         // app/Probability.hs:108-111
-        if (cache != nullptr) {
-            cache->va = va;
-            cache->lg_k = lg_k;
-            cache->log_t = log_t;
-            cache->hyper = hyper;
-        }
+    c.va = va;
+    c.lg_k = lgamma(1.0 / va);
+    c.log_t = log(va);
+    c.hyper = ln_gamma_pdf(1.5, 1.0 / 6.0, va);                            // app/Probability.hs:108-111
+}
+
+__device__ __forceinline__ double prior_clock_term(const PriorDev& P, int v, double va, double lg_k, double log_t, const double* h, const double* r)
+{
+    const double br = h[P.parent[v]] - h[v];                   // heightTreeToLengthTree
+    // relaxed molecular clock, branchesWith WithoutStem (Prior/Branch.hs:23-25)
+    const double rate = r[v];
+    double term;
+    switch (P.clock_model) {
+        case 0: {                                              // uncorrelatedGamma 1.0 va = gamma (1 / va) va
+            const double k = 1.0 / va;
+            term = (rate <= 0) ? kNegInf : log(rate) * (k - 1.0) - (rate / va) - lg_k - log_t * k;
+        } break;
+        case 1: term = ln_lognormal_prime(1.0, va, rate); break;                      // uncorrelatedLogNormal
+        case 2: { const double v2 = va / br; term = ln_gamma_pdf(1.0 / v2, v2, rate); } break;   // white noise
+        default: term = ln_lognormal_prime(1.0, va * br, rate); break;                // autocorrelatedLogNormal
     }
-    double clock = 0.0;
-    for (int v = 1 + lane; v < P.n_nodes; v += 64) {
-        const double br = h[P.parent[v]] - h[v];               // heightTreeToLengthTree
-        // relaxed molecular clock, branchesWith WithoutStem (Prior/Branch.hs:23-25)
-        const double rate = r[v];
-        double term;
-        switch (P.clock_model) {
-            case 0: {                                          // uncorrelatedGamma 1.0 va = gamma (1 / va) va
-                const double k = 1.0 / va;
-                term = (rate <= 0) ? kNegInf : log(rate) * (k - 1.0) - (rate / va) - lg_k - log_t * k;
-            } break;
-            case 1: term = ln_lognormal_prime(1.0, va, rate); break;                      // uncorrelatedLogNormal
-            case 2: { const double v2 = va / br; term = ln_gamma_pdf(1.0 / v2, v2, rate); } break;   // white noise
-            default: term = ln_lognormal_prime(1.0, va * br, rate); break;                // autocorrelatedLogNormal
-        }
-        clock += term;
-    }
-    double c2 = pr_wave_sum(clock);
+    return term;
+}
+
+__device__ __forceinline__ double prior_clock_finish(const PriorDev& P, double c2, double rm, double va, double hyper)
+{
     if (va <= 0) c2 = __builtin_nan("");                       // the reference calls `error` (variance <= 0)
     c2 += ln_exponential(P.ht, rm) + hyper;                    // :105-111
     return c2;
+}
+
+__device__ __forceinline__ double prior_clock_wave(const PriorDev& P, int lane, double rm, double va, const double* h,
+                                                   const double* r, ClockCache* cache = nullptr)
+{
+    ClockCache c;
+    if (cache != nullptr && cache->va == va) {
+        c = *cache;
+    } else {
+        prior_clock_scalars(va, c);
+        if (cache != nullptr) *cache = c;
+    }
+    double clock = 0.0;
+    for (int v = 1 + lane; v < P.n_nodes; v += 64) clock += prior_clock_term(P, v, va, c.lg_k, c.log_t, h, r);
+    return prior_clock_finish(P, pr_wave_sum(clock), rm, va, c.hyper);
 }
 
 // ln prior of one chain; c_out (may be null): node priors, birth-death block, clock block

@@ -101,6 +101,42 @@ def test_prior_large_tree(gpu):
         assert close(lp, ref)
 
 
+def test_prior_gradient_large_tree_same_bits_whatever_the_batch(gpu):
+    """The gradient kernel gives a chain 1 .. 4 waves (threads = nodes) depending on the batch; every per-node quantity is added
+    up in the order of the one-wave form, so value and gradient of a chain are the same bits in a batch of 40 (four waves per
+    chain), 700 (two) and 3000 (one), the value is the one of the value kernel, and central differences of the value agree."""
+    from mcmc_date_amd import synthetic as S
+
+    topo = S.random_topology(129, seed=9)
+    B = 3000
+    st = S.random_states(topo, B, seed=9)
+    rng = np.random.default_rng(9)
+    birth, death, rvar = np.exp(0.3 * rng.standard_normal(B)), np.exp(0.3 * rng.standard_normal(B)), 0.2 + rng.random(B)
+    cal = [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025), M.Calibration("n", 5, 0.2, 0.025, None, 0.0)]
+    con = [M.Constraint("k", 7, 3, 0.025)]
+    full = M.StateBatch(st.heights, st.rates, st.time_height, st.rate_mean, birth, death, rvar)
+    for model in MODELS:
+        pf = M.PriorFunction(1.0, model, cal, con, [], topo)
+        lp, g = pf.grad(full)
+        assert np.array_equal(lp, pf.logprior(full))
+        for nb in (40, 700):
+            lp_s, g_s = pf.grad(full.slice(0, nb))
+            assert np.array_equal(lp_s, lp[:nb])
+            for k in g_s:
+                assert np.array_equal(np.asarray(g_s[k]), np.asarray(g[k])[:nb]), (model, nb, k)
+        # one chain, a few coordinates, against differences of the value kernel
+        b, eps = 3, 1e-6
+        for v in (0, 1, 17, 128, 256):
+            Hp, Hm = st.heights[b:b + 1].copy(), st.heights[b:b + 1].copy()
+            Hp[0, v] += eps
+            Hm[0, v] -= eps
+            one = lambda Hx: pf.logprior(M.StateBatch(Hx, st.rates[b:b + 1], st.time_height[b:b + 1], st.rate_mean[b:b + 1], birth[b:b + 1],
+                                                      death[b:b + 1], rvar[b:b + 1]))[0]
+            fd = (one(Hp) - one(Hm)) / (2 * eps)
+            gh = np.asarray(g["heights"])[b, v]
+            assert abs(fd - gh) <= 1e-4 * max(1.0, abs(gh)), (model, v, fd, gh)
+
+
 @pytest.mark.parametrize("name", ["12-leaves-variable-rate", "24-leaves-braces"])
 @pytest.mark.parametrize("model", MODELS)
 def test_prior_gradient_against_differences_of_the_oracle(gpu, golden, name, model):
