@@ -24,6 +24,7 @@
 
 #include "mh_device.hpp"
 #include "prior_device.hpp"
+#include "mh_prior_role.hpp"
 
 namespace mcd {
 
@@ -48,7 +49,7 @@ __device__ unsigned long long g_mhs_cnt[32];
 //   propose: writes sc1, H1, R1, lnqj (ln q-ratio * Jacobian without the root-branch factor), post1[0] = ln prior
 __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc, int jac_root_acc, int p_prop, PropRow row_prop,
                                                  int draw_slot, uint64_t step_acc, uint64_t seed, int accumulate_now,
-                                                 double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
+                                                 double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int prior_inline)
 {
     extern __shared__ double sh[];
     const int lane = threadIdx.x & 63;
@@ -142,6 +143,28 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
         dR = dR || (__builtin_amdgcn_ballot_w64(in && Rs[in ? w : 0] != Rc[in ? w : 0]) != 0);
     }
     MHS_T(4);
+    const bool f0 = dH || sc[2] != sc0[2];
+    const bool f1 = dH || sc[0] != sc0[0] || sc[1] != sc0[1];
+    const bool f2 = dR || sc[3] != sc0[3] || sc[4] != sc0[4] || (dH && P.clock_model >= 2);
+    if (!prior_inline) {
+        // the ln prior of the proposed state is evaluated beside its ln likelihood (mh_prior_role.hpp): leave what that needs
+        for (int w = lane; w < n; w += 64) {
+            M.H1[b * M.ld + w] = Hs[w];
+            M.R1[b * M.ld + w] = Rs[w];
+        }
+        if (lane < 5) {
+            double mine = sc[0];
+#pragma unroll
+            for (int i = 1; i < 5; ++i)
+                if (lane == i) mine = sc[i];
+            M.sc1[lane * B + b] = mine;
+        }
+        if (lane == 0) {
+            M.lnqj[b] = lnqj;
+            M.pflags[b] = (f0 ? 1 : 0) | (f1 ? 2 : 0) | (f2 ? 4 : 0);
+        }
+        return;
+    }
     const double c0p = (dH || sc[2] != sc0[2]) ? prior_nodes_wave(P, lane, sc[2], Hs) : M.pcomp[b * 3 + 0];
     MHS_T(5);
     const double c1p = (dH || sc[0] != sc0[0] || sc[1] != sc0[1]) ? prior_bd_wave(P, lane, sc[0], sc[1], Hs) : M.pcomp[b * 3 + 1];
@@ -179,6 +202,17 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
         g_mhs_cnt[k] += 1;
     }
 #endif
+}
+
+// the prior role as a launch of its own (where the likelihood launch cannot carry it: row-split and multiply forms)
+__global__ __launch_bounds__(256) void k_mh_prior(MhDev M, PriorDev P)
+{
+    extern __shared__ double sh[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= M.batch) return;
+    double* hs = sh + (size_t)wave * 2 * M.n_nodes;
+    mh_prior_role(M, P, b, lane, hs, hs + M.n_nodes);
 }
 
 // The state-independent draws (gamma multipliers with ratio and logarithm, the uniforms) of up to 64 consecutive steps: one
@@ -225,7 +259,8 @@ hipError_t launch_mh_draws(const MhDev& M, const int32_t* sched, int64_t idx0, i
     return hipGetLastError();
 }
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, int draw_slot,
-                          uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
+                          uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
+                          hipStream_t st)
 {
     const size_t per_wave = sizeof(double) * 4 * (size_t)M.n_nodes;
     int wpb = 4;
@@ -233,7 +268,16 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
     if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
     const PropRow row{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
     hipLaunchKernelGGL(k_mh_step, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, p_acc, jac_root_acc, p_prop,
-                       row, draw_slot, step_acc, seed, accumulate_now, trace_alpha, trace_accept);
+                       row, draw_slot, step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline);
+    return hipGetLastError();
+}
+hipError_t launch_mh_prior(const MhDev& M, const PriorDev& P, hipStream_t st)
+{
+    const size_t per_wave = sizeof(double) * 2 * (size_t)M.n_nodes;
+    int wpb = 4;
+    while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;
+    if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_mh_prior, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P);
     return hipGetLastError();
 }
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st)

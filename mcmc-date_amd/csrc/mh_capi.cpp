@@ -223,7 +223,8 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
         (rc = dev_alloc(m.get(), &D.tune, BP, false)) || (rc = dev_alloc(m.get(), &D.acc, BP, true)) ||
         (rc = dev_alloc(m.get(), &D.tried, BP, true)) || (rc = dev_alloc(m.get(), &D.age_sum, BN, true)) ||
         (rc = dev_alloc(m.get(), &D.age_sq, BN, true)) || (rc = dev_alloc(m.get(), &D.pcomp, 3 * B, true)) ||
-        (rc = dev_alloc(m.get(), &D.pcomp1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.draws, 64 * 5 * B, true)))
+        (rc = dev_alloc(m.get(), &D.pcomp1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.draws, 64 * 5 * B, true)) ||
+        (rc = dev_alloc(m.get(), &D.pflags, B, true)))
         return rc;
     // trees of at most 64 nodes: the whole schedule runs in one launch with the factor staged in LDS (k_mh_chain.hip).
     // MCD_MH_PER_PHASE=1 (diagnostic) keeps the two-launches-per-step path that larger trees use.
@@ -367,17 +368,29 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
             return MCD_OK;
         };
         if (int rc = draws_for(0)) return rc;
-        MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr, m->stream));
+        // The ln prior of a proposed state depends on the proposal only, like its ln likelihood: where the sweep serves the
+        // likelihood launch, that launch carries the prior as workgroups of a second role (k_tree_logpdf.hip, mh_prior_role.hpp)
+        // and k_mh_step leaves it out; elsewhere (row-split / multiply form) k_mh_step evaluates it as before.  Same functions
+        // on the same numbers either way: the same chains.  MCD_MH_PRIOR=0 keeps it inside the step everywhere (tests, timing).
+        const char* env_prior = getenv("MCD_MH_PRIOR");
+        const bool beside = !(env_prior && atoi(env_prior) == 0) && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
+        const int prior_inline = beside ? 0 : 1;
+        MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr,
+                                     prior_inline, m->stream));
         for (int64_t gs = 0; gs < total; ++gs) {
-            MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
-                                             D.post1 + D.batch, D.post1 + 2 * D.batch, m->stream));
+            if (beside)
+                MHIP_TRY(mcd::launch_tree_logpdf_with_prior(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
+                                                            D.post1 + D.batch, D.post1 + 2 * D.batch, D, *m->prior, m->stream));
+            else
+                MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
+                                                 D.post1 + D.batch, D.post1 + 2 * D.batch, m->stream));
             const bool closes = ((gs + 1) % S) == 0;
             const int pa = schedule[gs], pn = (gs + 1 < total) ? schedule[gs + 1] : -1;
             if (pn >= 0)
                 if (int rc = draws_for(gs + 1)) return rc;
             MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, (int)((gs + 1) & 63), m->step,
                                          m->seed, (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
-                                         trace ? m->d_trace_accept + gs * B : nullptr, m->stream));
+                                         trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, m->stream));
             m->step += 1;
             if (accumulate && closes) m->n_samples += 1;
         }

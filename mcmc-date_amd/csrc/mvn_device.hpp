@@ -580,11 +580,16 @@ __device__ __forceinline__ void finish_ll(const double (&d)[R][BT], const MvnDev
 // workgroup takes part in every barrier, also compute waves whose chains lie beyond the batch
 // (they work on clamped inputs and store nothing): no early exits before the last barrier.
 // ---------------------------------------------------------------------------------------
+// (MCD_BID: the workgroup's index among the likelihood workgroups; a kernel that puts workgroups of another role in front of
+// them -- k_tree_logpdf.hip -- defines it before including this header)
+#ifndef MCD_BID
+#define MCD_BID blockIdx.x
+#endif
 #define MCD_KERNEL_HEAD                                                         \
     __shared__ d2 ring[2 * Cfg<R>::SU * 64];                                    \
     const int lane = threadIdx.x & 63;                                          \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          \
-    const int64_t b0 = ((int64_t)blockIdx.x * CW + wave) * BT;                   \
+    const int64_t b0 = ((int64_t)MCD_BID * CW + wave) * BT;                      \
     const int ncols = M.ncols;   /* swept columns: N rounded up to whole chunks (host: sweep_chunk_columns) */
 
 // launch geometry by batch size (host side)

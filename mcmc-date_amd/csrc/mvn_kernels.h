@@ -92,6 +92,7 @@ struct MhDev {
     // [batch][3], and the state-independent draws of a block of 64 steps, [64][batch][5] (k_mh_draws)
     double *pcomp, *pcomp1;
     double* draws;
+    int32_t* pflags;           // [batch] which blocks of the ln prior the pending proposal moved (bit 0 nodes, 1 birth-death, 2 clock)
 };
 
 // Workspace of the device leapfrog (k_hmc.hip); all pointers are device memory.
@@ -194,8 +195,17 @@ struct MhRow {
 };
 // accept the pending step of proposal p_acc (< 0: none) and propose proposal p_prop (< 0: none) with the ln prior of its proposed state
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& row_prop, int draw_slot,
-                          uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, hipStream_t st);
+                          uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
+                          hipStream_t st);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
+// ln prior of the proposed states from pflags / pcomp (what launch_mh_step leaves when asked not to evaluate it itself): as a
+// launch of its own, or as extra workgroups of the sweep's tree-likelihood launch (k_tree_logpdf.hip) -- the ln prior and the
+// ln likelihood of a proposal depend on nothing but the proposal
+hipError_t launch_mh_prior(const MhDev& M, const PriorDev& P, hipStream_t st);
+bool tree_logpdf_can_carry_prior(const MvnDev& M, int64_t batch, int n_nodes);
+hipError_t launch_tree_logpdf_with_prior(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                         const double* rMu, int64_t batch, double* ll, double* logjac, const MhDev& J, const PriorDev& JP,
+                                         hipStream_t st);
 // state-independent draws of the steps [idx0, idx0 + count) of the schedule (count <= 64), one thread per (step, chain)
 hipError_t launch_mh_draws(const MhDev& M, const int32_t* sched, int64_t idx0, int count, uint64_t step0, uint64_t seed, hipStream_t st);
 // whole schedule in one launch (k_mh_chain.hip); needs n_nodes <= 64 and mh_chain_lds_bytes(...) <= 64 KB

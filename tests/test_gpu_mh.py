@@ -122,6 +122,45 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(fused.age_sums()[:2], phased.age_sums()[:2]))
 
 
+@pytest.mark.parametrize("n_leaves,B", [(12, 10), (70, 6), (129, 512), (129, 700)])
+def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, monkeypatch):
+    """Two-launch path: by default the likelihood launch carries the ln prior of the proposed states as workgroups of a second
+    role (k_tree_logpdf.hip PRIOR variant, mh_prior_role.hpp); MCD_MH_PRIOR=0 evaluates it inside k_mh_step as before.  The same
+    wave-level functions on the same numbers: bit-identical acceptance ratios, decisions, states, posteriors, age sums -- with
+    calibrations, constraints and every clock model's blocks in play (257 nodes: 512 chains = two compute waves per
+    workgroup, 700 = four)."""
+    from mcmc_date_amd import synthetic as S
+
+    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")              # (the 23-node tree would otherwise run the whole-schedule kernel)
+    topo = S.random_topology(n_leaves, seed=21)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=21)
+    s0 = S.random_states(topo, B, seed=22)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    cal = [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025), M.Calibration("n", 5, 0.2, 0.025, None, 0.0)]
+    con = [M.Constraint("k", 7, 3, 0.025)]
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :300]
+    for model in ("UncorrelatedGamma", "AutocorrelatedLogNormal"):
+        runs = []
+        for inside in (False, True):
+            if inside:
+                monkeypatch.setenv("MCD_MH_PRIOR", "0")
+            else:
+                monkeypatch.delenv("MCD_MH_PRIOR", raising=False)
+            lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+            smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, [], topo), ps, B, seed=13)
+            smp.set_state(s0)
+            a, k = smp.run_schedule(sched, accumulate=True, trace=True)
+            runs.append((a, k, smp.state(), smp.posterior(), smp.age_sums()[:2]))
+        monkeypatch.delenv("MCD_MH_PRIOR", raising=False)
+        (a1, k1, s1, p1, g1), (a2, k2, s2, p2, g2) = runs
+        assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
+        for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
+            assert np.array_equal(getattr(s1, f), getattr(s2, f)), (model, f)
+        assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
+
+
 @pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150), (70, 2100, 24)])
 def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
     """Synthetic trees beyond 64 nodes (70 leaves: 139 nodes, N = 137, three row blocks; 128 leaves: 255 nodes, N = 253,
