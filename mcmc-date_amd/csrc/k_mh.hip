@@ -24,7 +24,6 @@
 
 #include "mh_device.hpp"
 #include "prior_device.hpp"
-#include "mh_prior_role.hpp"
 
 namespace mcd {
 
@@ -204,17 +203,6 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
 #endif
 }
 
-// the prior role as a launch of its own (where the likelihood launch cannot carry it: row-split and multiply forms)
-__global__ __launch_bounds__(256) void k_mh_prior(MhDev M, PriorDev P)
-{
-    extern __shared__ double sh[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (b >= M.batch) return;
-    double* hs = sh + (size_t)wave * 2 * M.n_nodes;
-    mh_prior_role(M, P, b, lane, hs, hs + M.n_nodes);
-}
-
 // The state-independent draws (gamma multipliers with ratio and logarithm, the uniforms) of up to 64 consecutive steps: one
 // THREAD per (step, chain) instead of one wave per chain, so the transcendental work is not repeated on 64 lanes.
 __global__ __launch_bounds__(256) void k_mh_draws(MhDev M, const int32_t* __restrict__ sched, int64_t idx0, int count, uint64_t step0,
@@ -269,15 +257,6 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
     const PropRow row{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
     hipLaunchKernelGGL(k_mh_step, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P, p_acc, jac_root_acc, p_prop,
                        row, draw_slot, step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline);
-    return hipGetLastError();
-}
-hipError_t launch_mh_prior(const MhDev& M, const PriorDev& P, hipStream_t st)
-{
-    const size_t per_wave = sizeof(double) * 2 * (size_t)M.n_nodes;
-    int wpb = 4;
-    while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;
-    if (per_wave * wpb > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_mh_prior, dim3((unsigned)((M.batch + wpb - 1) / wpb)), dim3(64 * wpb), per_wave * wpb, st, M, P);
     return hipGetLastError();
 }
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st)

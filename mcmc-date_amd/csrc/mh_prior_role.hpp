@@ -3,7 +3,7 @@
 // k_mh_step (k_mh.hip) proposes; when asked not to evaluate the prior itself it leaves, per chain, the proposed state (H1, R1,
 // sc1) and which blocks of the ln prior the proposal moved (pflags).  The ln prior and the ln likelihood of the proposal
 // depend on nothing else, so they can be evaluated side by side: this role runs as extra workgroups of the tree-likelihood
-// launch (k_tree_logpdf.hip, PRIOR variant) or as a launch of its own (k_mh_prior, k_mh.hip).  One wave per chain, the same
+// launch (k_tree_logpdf.hip, PRIOR variant).  One wave per chain, the same
 // wave-level functions (prior_device.hpp) on the same numbers as the in-step evaluation: the same bits.
 #pragma once
 #include "mvn_kernels.h"
@@ -40,13 +40,14 @@ __device__ __forceinline__ void mh_prior_role(const MhDev& M, const PriorDev& P,
     }
 }
 
-// The same with TWO waves per chain (a sampler's usual batch: every workgroup of both roles is resident at once, the launch
+// The same with WPC = 2 or 4 waves per chain (a sampler's usual batch: every workgroup of both roles is resident at once, the launch
 // lasts as long as its slowest wave): the chain's waves share the staging and deal the 64-node iterations of the birth-death
 // and the clock block between them; the per-node summands go to LDS and the chain's first wave adds them lane by lane in the
 // order of the iterations, then over the wave, exactly as prior_bd_wave / prior_clock_wave do alone -- the same bits.
 // All waves of the workgroup call this (two workgroup barriers inside); `valid` = the chain exists.
 // LDS of the chain: hs[n], rs[n], tb[NIT * 64], tc[NIT * 64], bc[8] with NIT = ceil((n - 1) / 64).
-__device__ __forceinline__ void mh_prior_role2(const MhDev& M, const PriorDev& P, int64_t b, bool valid, int sub, int lane, double* lds)
+template <int WPC>
+__device__ __forceinline__ void mh_prior_role_n(const MhDev& M, const PriorDev& P, int64_t b, bool valid, int sub, int lane, double* lds)
 {
     const int n = M.n_nodes, NIT = (n - 1 + 63) >> 6;
     const int64_t B = M.batch;
@@ -62,7 +63,7 @@ __device__ __forceinline__ void mh_prior_role2(const MhDev& M, const PriorDev& P
 #pragma unroll
     for (int i = 0; i < 3; ++i) pc[i] = M.pcomp[b * 3 + i];
     if (flags != 0) {
-        for (int w = sub * 64 + lane; w < n; w += 128) {
+        for (int w = sub * 64 + lane; w < n; w += 64 * WPC) {
             hs[w] = M.H1[b * M.ld + w];
             rs[w] = M.R1[b * M.ld + w];
         }
@@ -70,7 +71,7 @@ __device__ __forceinline__ void mh_prior_role2(const MhDev& M, const PriorDev& P
     __syncthreads();                                       // the proposed state is in LDS
     if (flags & 2) {
         const bool near = prior_bd_near(sc[0], sc[1]);
-        for (int it = sub; it < NIT; it += 2) {
+        for (int it = sub; it < NIT; it += WPC) {
             const int v = 1 + lane + 64 * it;
             if (v < n) tb[it * 64 + lane] = prior_bd_term(P, v, near, sc[0], sc[1], hs);
         }
@@ -78,12 +79,12 @@ __device__ __forceinline__ void mh_prior_role2(const MhDev& M, const PriorDev& P
     ClockCache cc{0.0, 0.0, 0.0, 0.0};
     if (flags & 4) {
         prior_clock_scalars(sc[4], cc);
-        for (int it = sub; it < NIT; it += 2) {
+        for (int it = sub; it < NIT; it += WPC) {
             const int v = 1 + lane + 64 * it;
             if (v < n) tc[it * 64 + lane] = prior_clock_term(P, v, sc[4], cc.lg_k, cc.log_t, hs, rs);
         }
     }
-    if ((flags & 1) && sub == 1) {                         // the node priors: the second wave (the first closes the sums)
+    if ((flags & 1) && sub == WPC - 1) {                   // the node priors: the chain's last wave (the first closes the sums)
         const double c0 = prior_nodes_wave(P, lane, sc[2], hs);
         if (lane == 0) bc[0] = c0;
     }
@@ -111,7 +112,12 @@ __device__ __forceinline__ void mh_prior_role2(const MhDev& M, const PriorDev& P
     }
 }
 
-// doubles of LDS per chain for mh_prior_role2
+__device__ __forceinline__ void mh_prior_role2(const MhDev& M, const PriorDev& P, int64_t b, bool valid, int sub, int lane, double* lds)
+{
+    mh_prior_role_n<2>(M, P, b, valid, sub, lane, lds);
+}
+
+// doubles of LDS per chain for mh_prior_role_n
 __host__ __device__ inline size_t mh_prior_role2_doubles(int n_nodes) { return 2 * (size_t)n_nodes + 2 * (size_t)((n_nodes - 1 + 63) / 64) * 64 + 8; }
 
 }  // namespace mcd

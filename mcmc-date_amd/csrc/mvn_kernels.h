@@ -198,10 +198,9 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
                           uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
                           hipStream_t st);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
-// ln prior of the proposed states from pflags / pcomp (what launch_mh_step leaves when asked not to evaluate it itself): as a
-// launch of its own, or as extra workgroups of the sweep's tree-likelihood launch (k_tree_logpdf.hip) -- the ln prior and the
-// ln likelihood of a proposal depend on nothing but the proposal
-hipError_t launch_mh_prior(const MhDev& M, const PriorDev& P, hipStream_t st);
+// ln prior of the proposed states from pflags / pcomp (what launch_mh_step leaves when asked not to evaluate it itself) as extra
+// workgroups of the sweep's tree-likelihood launch (k_tree_logpdf.hip): the ln prior and the ln likelihood of a proposal depend
+// on nothing but the proposal
 bool tree_logpdf_can_carry_prior(const MvnDev& M, int64_t batch, int n_nodes);
 hipError_t launch_tree_logpdf_with_prior(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                          const double* rMu, int64_t batch, double* ll, double* logjac, const MhDev& J, const PriorDev& JP,

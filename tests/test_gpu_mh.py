@@ -122,13 +122,14 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(fused.age_sums()[:2], phased.age_sums()[:2]))
 
 
-@pytest.mark.parametrize("n_leaves,B", [(12, 10), (70, 6), (129, 512), (129, 700)])
+@pytest.mark.parametrize("n_leaves,B", [(12, 10), (70, 6), (129, 512), (129, 700), (200, 40), (513, 96)])
 def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, monkeypatch):
     """Two-launch path: by default the likelihood launch carries the ln prior of the proposed states as workgroups of a second
     role (k_tree_logpdf.hip PRIOR variant, mh_prior_role.hpp); MCD_MH_PRIOR=0 evaluates it inside k_mh_step as before.  The same
     wave-level functions on the same numbers: bit-identical acceptance ratios, decisions, states, posteriors, age sums -- with
     calibrations, constraints and every clock model's blocks in play (257 nodes: 512 chains = two compute waves per
-    workgroup, 700 = four)."""
+    workgroup, 700 = four).  Above N = 256 (399 and 1025 nodes here) the likelihood is the row-split kernel and the prior
+    stays inside the step: both settings are then the same launches."""
     from mcmc_date_amd import synthetic as S
 
     monkeypatch.setenv("MCD_MH_PER_PHASE", "1")              # (the 23-node tree would otherwise run the whole-schedule kernel)
