@@ -57,7 +57,14 @@ __global__ void __launch_bounds__(64 * (CW + LW)) k_tree_logpdf(MvnDev M, TreeDe
         return;
     }
     double d[R][BT], dist[R][BT];
-    load_tree<R, BT>(d, dist, M, T, H, Rt, lds, tH, rMu, b0, batch, lane);
+    // a sampler's batch (two compute waves per workgroup) on trees up to 258 nodes: the state rows go through LDS (10 KiB beside
+    // the ring: two workgroups still fit a CU); elsewhere the gather from global memory
+    constexpr bool STAGED = (R <= 4 && BT == 1 && CW == 2);
+    __shared__ double tstage[STAGED ? CW * 2 * (64 * R + 64) : 1];
+    if constexpr (STAGED)
+        load_tree_staged<R>(d, dist, M, T, H, Rt, lds, tH, rMu, b0, batch, lane, tstage + (size_t)wave * 2 * (64 * R + 64));
+    else
+        load_tree<R, BT>(d, dist, M, T, H, Rt, lds, tH, rMu, b0, batch, lane);
     if (logjac != nullptr && lane == 0) {
 #pragma unroll
         for (int c = 0; c < BT; ++c)

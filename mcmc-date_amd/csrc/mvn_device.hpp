@@ -561,6 +561,61 @@ __device__ __forceinline__ void load_tree(double (&d)[R][BT], double (&dist)[R][
     }
 }
 
+// The same with the chain's height and rate rows passed through LDS (`stage`: 2 (64 R + 64) doubles private to the wave): the
+// rows are read contiguously, side by side with the slot tables -- one round trip -- and the gather by node id happens in LDS,
+// where load_tree gathers from global memory once the tables have arrived: two dependent round trips and a line per lane.
+// Same arithmetic, same bits.  One chain per wave (BT = 1).
+template <int R>
+__device__ __forceinline__ void load_tree_staged(double (&d)[R][1], double (&dist)[R][1], const MvnDev& M, const TreeDev& T,
+                                                 const double* __restrict__ H, const double* __restrict__ Rt, int64_t lds,
+                                                 const double* __restrict__ tH, const double* __restrict__ rMu, int64_t b0,
+                                                 int64_t batch, int lane, double* stage)
+{
+    constexpr int NP = 64 * R + 64;
+    const int64_t b = (b0 < batch) ? b0 : batch - 1;
+    const double* __restrict__ h = H + b * lds;
+    const double* __restrict__ r = Rt + b * lds;
+    const int nn = T.n_nodes;                              // <= 64 R + 2
+    double hv[R + 1], rv[R + 1], m[R], iv[R];
+    int a[R], pa[R];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) {
+        const int v = 64 * i + lane;
+        const int vc = v < nn ? v : nn - 1;
+        hv[i] = h[vc];
+        rv[i] = r[vc];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int row = 64 * k + lane;
+        m[k] = M.mu[row];
+        iv[k] = M.invdiag[row];
+        a[k] = T.slot_node[row];           // -1 for padded rows
+        pa[k] = T.slot_parent[row];        // 0 for padded rows
+    }
+    const double s = tH[b] * rMu[b];       // :205-207  (tH * rMu)
+    const int rr = T.root_right;
+#pragma unroll
+    for (int i = 0; i <= R; ++i) {
+        stage[64 * i + lane] = hv[i];
+        stage[NP + 64 * i + lane] = rv[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the rows are in LDS (one wave: LDS operations complete in order)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int row = 64 * k + lane;
+        double v = 0.0;
+        if (a[k] >= 0) {
+            v = (stage[pa[k]] - stage[a[k]]) * stage[NP + a[k]];                           // zipWith (*) times rates
+            if (row == 0) v = v + (stage[0] - stage[rr]) * stage[NP + rr];                 // sumFirstTwo
+            v = v * s;                                                                      // map (* (tH * rMu))
+        }
+        dist[k][0] = v;
+        d[k][0] = (v - m[k]) * iv[k];
+    }
+}
+
 template <int R, int BT>
 __device__ __forceinline__ void finish_ll(const double (&d)[R][BT], const MvnDev& M, int64_t b0, int64_t batch,
                                           double* __restrict__ ll, int lane)
