@@ -26,7 +26,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-from .likelihood import Full, LikelihoodData, NoData, Univariate, write_data_file
+from .likelihood import Full, LikelihoodData, NoData, Sparse, Univariate, write_data_file
 from .tree import Topology, TreeError, get_branches, read_newick_file, sum_first_two
 
 
@@ -163,10 +163,81 @@ def prepare(tree_list_path: str, rooted_tree_path: str, likelihood_spec: str = "
         lhd = Univariate(mu, variances.copy())                            # :278-281
     elif likelihood_spec == "NoLikelihood":
         lhd = NoData()                                                    # :282-284
+    elif likelihood_spec.startswith("SparseMultivariateNormal"):
+        # app/Main.hs:257-276: centre and scale the columns (Statistics.Covariance.scale), graphical lasso with penalty rho on the
+        # correlation matrix, scale covariance and precision back, ln det of the sparse covariance, association list
+        parts = likelihood_spec.split()
+        rho = float(parts[1]) if len(parts) > 1 else 0.1                  # scripts/run:137 passes 0.1
+        sd = np.sqrt(variances)
+        corr = sigma / np.outer(sd, sd)
+        w_n, theta_n = graphical_lasso(corr, rho, penalize_diagonal=GLASSO_PENALIZE_DIAGONAL)
+        sigma_s = w_n * np.outer(sd, sd)                                  # rescaleSWith
+        prec_s = theta_n / np.outer(sd, sd)                               # rescalePWith
+        sign, logdet = np.linalg.slogdet(sigma_s)
+        if sign != 1.0:
+            raise ValueError("prepare: Determinant of sparse covariance matrix is negative?")
+        n = len(mu)
+        assoc = [((i, j), float(prec_s[i, j])) for i in range(n) for j in range(n) if prec_s[i, j] != 0.0]
+        lhd = Sparse(mu, assoc, float(logdet))
     else:
-        # SparseMultivariateNormal needs the graphical lasso (glasso, Fortran, third party): not restated.
         raise NotImplementedError(f"prepare: likelihood specification {likelihood_spec!r} is not available")
     return Prepared(lhd, mu, sigma, topo, mean_lengths, n_trees, n_burn)
+
+
+# The reference calls glasso (Friedman, Hastie, Tibshirani 2008; the Fortran code behind the Haskell packages `glasso` and
+# `covariance`, neither vendored) with its default flags; whether its binding penalises the diagonal (R's wrapper does by
+# default) is not visible from the reference's sources.  The posterior samples the reference commits for the mtCDNApri analysis
+# decide (tests/test_gpu_mh.py::test_posterior_node_ages_against_the_references_own_samples, tools/post_samples_check.py).
+GLASSO_PENALIZE_DIAGONAL = True
+
+
+def graphical_lasso(S: np.ndarray, rho: float, penalize_diagonal: bool = True, tol: float = 1e-10, max_iter: int = 10000):
+    """Graphical lasso: maximise ln det Theta - tr(S Theta) - rho ||Theta||_1 (the l1 norm over all entries, or over the
+    off-diagonal ones).  Block coordinate descent over the columns of W = Theta^-1 with the lasso sub-problem solved by
+    coordinate descent (Friedman, Hastie, Tibshirani, Biostatistics 9 (2008), section 2); the optimum is unique, so this
+    agrees with any other solver to the tolerance.  Returns (W, Theta)."""
+    S = np.asarray(S, float)
+    p = S.shape[0]
+    if rho < 0:
+        raise ValueError("graphical_lasso: negative penalty")
+    W = S.copy()
+    if penalize_diagonal:
+        W[np.diag_indices(p)] += rho
+    if p == 1:
+        return W, 1.0 / W
+    B = np.zeros((p, p))                                                  # lasso coefficients per column
+    idx = np.arange(p)
+    for _ in range(max_iter):
+        W_old = W.copy()
+        for j in range(p):
+            rest = idx != j
+            W11 = W[np.ix_(rest, rest)]
+            s12 = S[rest, j]
+            beta = B[rest, j].copy()
+            for _ in range(max_iter):                                     # coordinate descent on 1/2 b'W11 b - b's12 + rho |b|_1
+                delta = 0.0
+                for k in range(p - 1):
+                    r = s12[k] - W11[k] @ beta + W11[k, k] * beta[k]
+                    nb = np.sign(r) * max(abs(r) - rho, 0.0) / W11[k, k]
+                    delta = max(delta, abs(nb - beta[k]))
+                    beta[k] = nb
+                if delta <= tol:
+                    break
+            B[rest, j] = beta
+            w12 = W11 @ beta
+            W[rest, j] = w12
+            W[j, rest] = w12
+        if np.abs(W - W_old).max() <= tol * max(1.0, np.abs(S - np.diag(np.diag(S))).mean()):
+            break
+    Theta = np.zeros((p, p))
+    for j in range(p):
+        rest = idx != j
+        t22 = 1.0 / (W[j, j] - W[rest, j] @ B[rest, j])
+        Theta[j, j] = t22
+        Theta[rest, j] = -B[rest, j] * t22
+    Theta = 0.5 * (Theta + Theta.T)
+    Theta[np.abs(Theta) < 1e-14] = 0.0
+    return W, Theta
 
 
 def write_prepared(name: str, p: Prepared) -> None:

@@ -516,6 +516,52 @@ def test_prior_only_node_ages_against_the_references_own_samples(gpu, tmp_path):
     assert np.all(dev[False] <= dev[True] + 0.002), (dev[False], dev[True])   # the reference's samples side with its own Jacobians
 
 
+def test_posterior_node_ages_against_the_references_own_samples(gpu, tmp_path):
+    """The reference's own POSTERIOR output pins the whole path -- prepare (with the graphical lasso), likelihood, prior, proposal
+    cycle, Jacobians: the node ages of its six chains WITH data on the 7-taxon mtCDNApri analysis
+    (`./run -s -f analysis.conf -c ul s r`: SparseMultivariateNormal 0.1, bench/comparison_with_mcmctree/README.md:615-632;
+    summary statistics in tests/golden/mtCDNApri_post_samples.json, generator make_post_sample_summary.py; the inputs are in the
+    prior-only fixture).  The device sampler runs the same analysis with 128 chains: every node age -- the root included --
+    within 1 % of the reference's pooled mean (north_star's bar; measured 0.1 .. 0.5 %), the 2.5 % / 97.5 % quantiles within 3 %
+    (measured up to 1.7 %).  With `exact_jacobians=True` the root's upper quantile drifts by 2.9 %: the reference's samples side
+    with its own Jacobians here as in the prior-only runs (tools/post_samples_check.py, profiles/r02_post_samples_variants.jsonl)."""
+    import json
+    import os
+
+    from mcmc_date_amd import monitor as MO
+    from mcmc_date_amd.prepare import prepare
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    fx = json.load(open(os.path.join(here, "mtCDNApri_prior_samples.json")))
+    post = json.load(open(os.path.join(here, "mtCDNApri_post_samples.json")))
+    paths = {}
+    for k in ("rooted_tree", "calibration_tree", "tree_list"):
+        paths[k] = str(tmp_path / k)
+        open(paths[k], "w").write(fx["inputs"][k])
+    prep = prepare(paths["tree_list"], paths["rooted_tree"], "SparseMultivariateNormal 0.1")
+    assert isinstance(prep.lhd, M.Sparse) and len(prep.lhd.sigma_inv_assoc) < len(prep.mu) ** 2      # really sparse
+    topo = prep.topology
+    cal = M.load_calibrations_from_tree(topo, paths["calibration_tree"])
+    ht = M.get_mean_root_height(cal)
+    lik = M.MvnLikelihood(prep.lhd).bind_tree(topo)
+    pf = M.PriorFunction(ht, "UncorrelatedLogNormal", cal, [], [], topo)
+    ps, missing = M.proposals(topo, [], calibrations_available=True)
+    assert missing == []
+    smp = M.Sampler(lik, pf, ps, 128, seed=21)
+    x0 = M.init_with(topo, prep.mean_lengths)
+    x0.time_height = ht
+    smp.set_initial_state(x0)
+    smp.burn_in()
+    tr = MO.collect(smp, 8000, period=20)
+    ages = tr.ages()[:, :, post["nodes"]].reshape(-1, len(post["nodes"]))
+    ref = {k: np.array(v) for k, v in post["pooled"].items()}
+    dev = np.abs(ages.mean(axis=0) - ref["mean"]) / ref["mean"]
+    assert np.all(dev <= 0.01), dev
+    q = np.quantile(ages, [0.025, 0.975], axis=0)
+    assert np.all(np.abs(q[0] - ref["q025"]) <= 0.03 * ref["q025"]), (q[0], ref["q025"])
+    assert np.all(np.abs(q[1] - ref["q975"]) <= 0.03 * ref["q975"]), (q[1], ref["q975"])
+
+
 def test_shard_allgather_through_rccl(gpu, golden):
     """The path's one exchange step on hardware: the C ABI's all-gather (mcd_shard_*: RCCL loaded at run time,
     communicator made from a unique id, ncclAllGather on the sampler's stream) of the device-resident per-chain ln posterior of

@@ -80,8 +80,10 @@ def test_prepare_other_specs(tmp_path):
     u = PP.prepare(a, b, "UnivariateNormal")
     assert isinstance(u.lhd, M.Univariate) and np.allclose(u.lhd.vs, np.diag(u.sigma))
     assert isinstance(PP.prepare(a, b, "NoLikelihood").lhd, M.NoData)
+    sp = PP.prepare(a, b, "SparseMultivariateNormal 0.1")
+    assert isinstance(sp.lhd, M.Sparse) and np.array_equal(sp.lhd.mu, u.mu)
     with pytest.raises(NotImplementedError):
-        PP.prepare(a, b, "SparseMultivariateNormal 0.1")
+        PP.prepare(a, b, "SomethingElse")
 
 
 def test_node_prior_loaders_match_fixtures(golden):
@@ -100,3 +102,60 @@ def test_node_prior_loaders_match_fixtures(golden):
     assert [b.nodes for b in br] == [[int(n) for n in fx["brace_nodes"]]] and br[0].sd == 1e-4
     assert cals[0].name == "CladeRoot" and cals[0].node == 0
     assert M.get_mean_root_height(cals[1:]) is None
+
+
+def test_graphical_lasso_optimality_conditions():
+    """`prepare` with SparseMultivariateNormal (app/Main.hs:257-276) needs the graphical lasso, third-party Fortran in the
+    reference; ours is checked against the conditions that characterise the unique optimum (Friedman et al. 2008, eq. 2.4):
+    W Theta = I; W_ij - S_ij = rho sign(Theta_ij) where Theta_ij != 0, |W_ij - S_ij| <= rho where it is 0; W_ii = S_ii (+ rho);
+    and against scikit-learn's solver where that is installed."""
+    from mcmc_date_amd.prepare import graphical_lasso
+
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((9, 11))                       # fewer samples than dimensions, as in the mtCDNApri analysis
+    X[:, 3] += X[:, 2]
+    X[:, 7] -= 0.7 * X[:, 1]
+    S = np.corrcoef(X, rowvar=False)
+    for rho in (0.05, 0.1, 0.3):
+        for pen in (True, False):
+            W, T = graphical_lasso(S, rho, penalize_diagonal=pen)
+            assert np.abs(W @ T - np.eye(11)).max() <= 1e-8
+            assert np.abs(np.diag(W) - np.diag(S) - (rho if pen else 0.0)).max() <= 1e-12
+            off = ~np.eye(11, dtype=bool)
+            nz = (T != 0) & off
+            assert np.abs((W - S)[nz] - rho * np.sign(T[nz])).max() <= 1e-7
+            assert np.all(np.abs((W - S)[off & ~nz]) <= rho + 1e-9)
+            assert np.linalg.eigvalsh(T).min() > 0
+        try:
+            from sklearn.covariance import graphical_lasso as sk
+        except Exception:
+            continue
+        cov, prec = sk(S, alpha=rho, tol=1e-10, max_iter=5000)
+        W, T = graphical_lasso(S, rho, penalize_diagonal=False)
+        assert np.abs(W - cov).max() <= 1e-8 and np.abs(T - prec).max() <= 1e-7
+    assert (graphical_lasso(S, 0.3)[1] == 0).sum() > (graphical_lasso(S, 0.05)[1] == 0).sum()     # more penalty, sparser
+
+
+def test_prepare_sparse_on_the_references_mtcdnapri_trees(tmp_path):
+    """`./run ... s p` on the ten PhyloBayes trees of the reference's mtCDNApri analysis (nine after the burn-in: fewer than
+    the eleven branches, the sample covariance is singular and only the penalised estimate exists)."""
+    import json
+    import os
+
+    from mcmc_date_amd.likelihood import Sparse
+    from mcmc_date_amd.prepare import prepare
+
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mtCDNApri_prior_samples.json")))
+    paths = {}
+    for k in ("rooted_tree", "tree_list"):
+        paths[k] = str(tmp_path / k)
+        open(paths[k], "w").write(fx["inputs"][k])
+    p = prepare(paths["tree_list"], paths["rooted_tree"], "SparseMultivariateNormal 0.1")
+    assert isinstance(p.lhd, Sparse) and len(p.mu) == 11
+    n = 11
+    P = np.zeros((n, n))
+    for (i, j), v in p.lhd.sigma_inv_assoc:
+        P[i, j] = v
+    assert np.allclose(P, P.T) and np.linalg.eigvalsh(P).min() > 0 and 40 < len(p.lhd.sigma_inv_assoc) < 121
+    assert abs(np.linalg.slogdet(np.linalg.inv(P))[1] - p.lhd.logdet_sigma) <= 1e-6 * abs(p.lhd.logdet_sigma)
+    assert np.linalg.matrix_rank(p.sigma, tol=1e-12) < n                     # the sample covariance itself is singular
