@@ -310,7 +310,8 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  * proposal and propose the next one; then ln likelihood of the proposed states, which up to 256 dimensions also carries their ln
  * prior as workgroups of a second role (both depend on the proposal only).  Environment, read per call, for tests and timing:
  * MCD_MH_PRIOR=0 evaluates the prior inside the first launch everywhere (the chains are the same bits either way),
- * MCD_MH_PER_PHASE=1 takes the two-launch path for small trees as well.
+ * MCD_MH_PER_PHASE=1 takes the two-launch path for small trees as well, MCD_MH_STEP_WG=1 / 0 forces / forbids the step kernel
+ * with a workgroup per chain (default: trees of more than 320 nodes).
  */
 int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t steps_per_iter, int accumulate,
                double* trace_alpha, int8_t* trace_accept);

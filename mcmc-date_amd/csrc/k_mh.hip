@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mh_device.hpp"
 #include "prior_device.hpp"
@@ -203,6 +204,188 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
 #endif
 }
 
+// The same step with a WORKGROUP of four waves per chain, for trees of more than 320 nodes: there one wave walks 6 .. 17 strides of
+// 64 nodes through every loop -- state copy, comparison, stores, and above all the two blocks of the ln prior, 16 trips through
+// the exponentials and logarithms each at 1025 nodes.  Wave 0 is the chain's wave: it runs the wave-level proposal code and closes
+// the sums.  All four waves copy the state and write the proposal back (threads = nodes); waves 1 .. 3 evaluate the per-node
+// summands of the birth-death and the clock block, the 64-node iterations dealt round-robin, into LDS, and wave 0 adds them lane
+// by lane in the order of the iterations and then over the wave, exactly as prior_bd_wave / prior_clock_wave do alone: the same
+// bits as k_mh_step.  (At 257 nodes the two forms take the same time -- one 64-node iteration of summands costs a wave as much
+// alone as three of four pipelined, profiles/r02_mhstep_phases.txt -- so the smaller trees keep the one-wave kernel.)
+constexpr int MHW = 4;                                     // waves per chain (two workgroups per CU at two waves per SIMD: 256 VGPRs each, no spills)
+__global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P, int p_acc, int jac_root_acc, int p_prop, PropRow row_prop,
+                                                            int draw_slot, uint64_t step_acc, uint64_t seed, int accumulate_now,
+                                                            double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
+{
+    extern __shared__ double sh[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NT = 64 * MHW, NWORK = MHW - 1;
+    const int64_t b = blockIdx.x;
+    const int n = M.n_nodes;
+    const int64_t B = M.batch;
+    const int NIT = (n - 1 + 63) >> 6;                     // iterations of v = 1 + lane + 64 it < n
+    double* Hc = sh;                                       // current state after the decision
+    double* Rc = Hc + n;
+    double* Hs = Rc + n;                                   // proposed state
+    double* Rs = Hs + n;
+    double* tb = Rs + n;                                   // [NIT][64] summands of the birth-death block
+    double* tc = tb + NIT * 64;                            // [NIT][64] summands of the clock block
+    double* bc = tc + NIT * 64;                            // [16] wave 0 -> workers: proposed scalars, flags; workers -> wave 0: c0, hyper
+    // ---- the decision (every wave for itself: the same bits)
+    bool ok = false;
+    if (p_acc >= 0) {
+        const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
+        const double lp1 = M.post1[b], ll1 = M.post1[B + b], lj1 = M.post1[2 * B + b];
+        double la = M.beta[b] * ((lp1 + ll1) - (lp + ll)) + M.lnqj[b];     // heated chains of MC3: posterior^beta; beta = 1 is exact
+        if (jac_root_acc) la += (double)jac_root_acc * (lj1 - lj);   // +1: jf(y) / jf(x); -1 (experiments): the reciprocal
+        double ua, ub;
+        philox_block(mh_rng(seed, M.chain0 + b, step_acc), 0xFFFFFFFFu, ua, ub);
+        ok = (la >= 0) || (ua < exp(la));
+        if (tid == 0) {
+            const int64_t i = b * M.n_prop + p_acc;
+            M.tried[i] += 1;
+            if (ok) M.acc[i] += 1;
+            if (trace_alpha) trace_alpha[b] = la;
+            if (trace_accept) trace_accept[b] = ok ? 1 : 0;
+        }
+    }
+    // the current state after the decision, into LDS (and back to global memory when it changed)
+    double sc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sc[i] = (ok ? M.sc1 : M.sc)[i * B + b];
+    {
+        const double* Hsrc = (ok ? M.H1 : M.H) + b * M.ld;
+        const double* Rsrc = (ok ? M.R1 : M.R) + b * M.ld;
+        for (int w = tid; w < n; w += NT) {
+            const double h = Hsrc[w], r = Rsrc[w];
+            Hc[w] = h;
+            Rc[w] = r;
+            if (ok) {
+                M.H[b * M.ld + w] = h;
+                M.R[b * M.ld + w] = r;
+            }
+            if (accumulate_now) {
+                const double a = sc[2] * h;
+                M.age_sum[b * n + w] += a;
+                M.age_sq[b * n + w] += a * a;
+            }
+        }
+    }
+    double pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pc[i] = (ok ? M.pcomp1 : M.pcomp)[b * 3 + i];
+    if (ok) {
+        if (tid < 5) {
+            double mine = sc[0];
+#pragma unroll
+            for (int i = 1; i < 5; ++i)
+                if (tid == i) mine = sc[i];
+            M.sc[tid * B + b] = mine;
+        }
+        if (tid < 3) {
+            M.post[tid * B + b] = M.post1[tid * B + b];
+            double mine = pc[0];
+            if (tid == 1) mine = pc[1];
+            if (tid == 2) mine = pc[2];
+            M.pcomp[b * 3 + tid] = mine;
+        }
+    }
+    if (p_prop < 0) return;
+    __syncthreads();                                       // the current state is in LDS
+    ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
+    double lnqj = 0.0;
+    if (wave == 0) {
+        const double t = M.tune[b * M.n_prop + p_prop];
+        const double* dw = M.draws + ((size_t)draw_slot * B + b) * 5;     // the state-independent draws of this step (k_mh_draws)
+        const StepDraws dr{dw[0], dw[1], dw[2], dw[3], dw[4]};
+        double sc0[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sc0[i] = sc[i];
+        lnqj = mh_propose_wave(M, row_prop, t, dr, lane, sc, Hc, Rc, Hs, Rs);
+        __builtin_amdgcn_wave_barrier();
+        // only the blocks of the ln prior whose inputs the proposal moved are evaluated again
+        bool dH = false, dR = false;
+        for (int w0 = 0; w0 < n; w0 += 64) {
+            const int w = w0 + lane;
+            const bool in = w < n;
+            dH = dH || (__builtin_amdgcn_ballot_w64(in && Hs[in ? w : 0] != Hc[in ? w : 0]) != 0);
+            dR = dR || (__builtin_amdgcn_ballot_w64(in && Rs[in ? w : 0] != Rc[in ? w : 0]) != 0);
+        }
+        const int f0 = (dH || sc[2] != sc0[2]) ? 1 : 0;
+        const int f1 = (dH || sc[0] != sc0[0] || sc[1] != sc0[1]) ? 2 : 0;
+        const int f2 = (dR || sc[3] != sc0[3] || sc[4] != sc0[4] || (dH && P.clock_model >= 2)) ? 4 : 0;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) bc[i] = sc[i];
+            bc[6] = (double)(f0 | f1 | f2);
+        }
+    } else {
+        prior_clock_scalars(sc[4], cc);                    // while wave 0 proposes: most proposals leave the rate variance alone
+    }
+    __syncthreads();                                       // the proposed state is in LDS
+    const int flags = (int)bc[6];
+    double scn[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) scn[i] = bc[i];
+    for (int w = tid; w < n; w += NT) {
+        M.H1[b * M.ld + w] = Hs[w];
+        M.R1[b * M.ld + w] = Rs[w];
+    }
+    if (tid < 5) {
+        double mine = scn[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i)
+            if (tid == i) mine = scn[i];
+        M.sc1[tid * B + b] = mine;
+    }
+    if (wave > 0) {
+        const int wi = wave - 1;
+        if (flags & 2) {
+            const bool near = prior_bd_near(scn[0], scn[1]);
+            for (int it = wi; it < NIT; it += NWORK) {
+                const int v = 1 + lane + 64 * it;
+                if (v < n) tb[it * 64 + lane] = prior_bd_term(P, v, near, scn[0], scn[1], Hs);
+            }
+        }
+        if (flags & 4) {
+            if (!(cc.va == scn[4])) prior_clock_scalars(scn[4], cc);
+            for (int it = wi; it < NIT; it += NWORK) {
+                const int v = 1 + lane + 64 * it;
+                if (v < n) tc[it * 64 + lane] = prior_clock_term(P, v, scn[4], cc.lg_k, cc.log_t, Hs, Rs);
+            }
+            if (wi == 0 && lane == 0) bc[8] = cc.hyper;
+        }
+        if ((flags & 1) && wi == NWORK - 1) {
+            const double c0 = prior_nodes_wave(P, lane, scn[2], Hs);
+            if (lane == 0) bc[7] = c0;
+        }
+    }
+    __syncthreads();                                       // the summands are in LDS
+    if (wave != 0) return;
+    const double c0p = (flags & 1) ? bc[7] : pc[0];
+    double c1p = pc[1], c2p = pc[2];
+    if (flags & 2) {
+        double bd = 0.0;
+        for (int it = 0; it < NIT; ++it)
+            if (1 + lane + 64 * it < n) bd += tb[it * 64 + lane];
+        c1p = prior_bd_finish(pr_wave_sum(bd), sc[0], sc[1]);
+    }
+    if (flags & 4) {
+        double clock = 0.0;
+        for (int it = 0; it < NIT; ++it)
+            if (1 + lane + 64 * it < n) clock += tc[it * 64 + lane];
+        c2p = prior_clock_finish(P, pr_wave_sum(clock), sc[3], sc[4], bc[8]);
+    }
+    if (lane == 0) {
+        M.pcomp1[b * 3 + 0] = c0p;
+        M.pcomp1[b * 3 + 1] = c1p;
+        M.pcomp1[b * 3 + 2] = c2p;
+        M.lnqj[b] = lnqj;
+        M.post1[b] = c0p + c1p + c2p;
+    }
+}
+
 // The state-independent draws (gamma multipliers with ratio and logarithm, the uniforms) of up to 64 consecutive steps: one
 // THREAD per (step, chain) instead of one wave per chain, so the transcendental work is not repeated on 64 lanes.
 __global__ __launch_bounds__(256) void k_mh_draws(MhDev M, const int32_t* __restrict__ sched, int64_t idx0, int count, uint64_t step0,
@@ -250,6 +433,18 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
                           uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
                           hipStream_t st)
 {
+    const PropRow row_{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
+    const char* env = getenv("MCD_MH_STEP_WG");            // tests, timing: 1 = the workgroup-per-chain form for every tree, 0 = never
+    const bool wg = prior_inline && (env ? atoi(env) != 0 : M.n_nodes > 320);
+    if (wg) {
+        const int NIT = (M.n_nodes - 1 + 63) / 64;
+        const size_t lds = sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 16);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(k_mh_step_wg, dim3((unsigned)M.batch), dim3(64 * MHW), lds, st, M, P, p_acc, jac_root_acc, p_prop, row_, draw_slot,
+                               step_acc, seed, accumulate_now, trace_alpha, trace_accept);
+            return hipGetLastError();
+        }
+    }
     const size_t per_wave = sizeof(double) * 4 * (size_t)M.n_nodes;
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;

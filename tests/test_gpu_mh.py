@@ -162,6 +162,40 @@ def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, mon
         assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
+@pytest.mark.parametrize("n_leaves,B", [(12, 10), (129, 64), (200, 40), (513, 96)])
+def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkeypatch):
+    """Trees of more than 320 nodes take the step kernel with a workgroup of four waves per chain (k_mh_step_wg: threads = nodes
+    for the copies, worker waves for the per-node summands of the ln prior, added up in the one-wave order); MCD_MH_STEP_WG=1 / 0
+    force it / the one-wave kernel for any tree.  Bit-identical chains: traces, states, posteriors, age sums."""
+    from mcmc_date_amd import synthetic as S
+
+    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
+    monkeypatch.setenv("MCD_MH_PRIOR", "0")                  # (the prior inside the step: the part the two kernels do differently)
+    topo = S.random_topology(n_leaves, seed=41)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=41)
+    s0 = S.random_states(topo, B, seed=42)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    cal = [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025), M.Calibration("n", 5, 0.2, 0.025, None, 0.0)]
+    con = [M.Constraint("k", 7, 3, 0.025)]
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :300]
+    for model in ("UncorrelatedGamma", "UncorrelatedWhiteNoise"):
+        runs = []
+        for wg in ("1", "0"):
+            monkeypatch.setenv("MCD_MH_STEP_WG", wg)
+            lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+            smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, [], topo), ps, B, seed=13)
+            smp.set_state(s0)
+            a, k = smp.run_schedule(sched, accumulate=True, trace=True)
+            runs.append((a, k, smp.state(), smp.posterior(), smp.age_sums()[:2]))
+        (a1, k1, s1, p1, g1), (a2, k2, s2, p2, g2) = runs
+        assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
+        for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
+            assert np.array_equal(getattr(s1, f), getattr(s2, f)), (model, f)
+        assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
+
+
 @pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150), (70, 2100, 24)])
 def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
     """Synthetic trees beyond 64 nodes (70 leaves: 139 nodes, N = 137, three row blocks; 128 leaves: 255 nodes, N = 253,
