@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
 constexpr int MHW = 4;                                     // waves per chain (two workgroups per CU at two waves per SIMD: 256 VGPRs each, no spills)
 __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P, int p_acc, int jac_root_acc, int p_prop, PropRow row_prop,
                                                             int draw_slot, uint64_t step_acc, uint64_t seed, int accumulate_now,
-                                                            double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
+                                                            double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int prior_inline)
 {
     extern __shared__ double sh[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -339,6 +339,13 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
             if (tid == i) mine = scn[i];
         M.sc1[tid * B + b] = mine;
     }
+    if (!prior_inline) {                                   // the ln prior is evaluated beside the likelihood (mh_prior_role.hpp)
+        if (tid == 0) {
+            M.lnqj[b] = lnqj;
+            M.pflags[b] = flags;
+        }
+        return;
+    }
     if (wave > 0) {
         const int wi = wave - 1;
         if (flags & 2) {
@@ -435,13 +442,13 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
 {
     const PropRow row_{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
     const char* env = getenv("MCD_MH_STEP_WG");            // tests, timing: 1 = the workgroup-per-chain form for every tree, 0 = never
-    const bool wg = prior_inline && (env ? atoi(env) != 0 : M.n_nodes > 320);
+    const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > 320);
     if (wg) {
         const int NIT = (M.n_nodes - 1 + 63) / 64;
         const size_t lds = sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 16);
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(k_mh_step_wg, dim3((unsigned)M.batch), dim3(64 * MHW), lds, st, M, P, p_acc, jac_root_acc, p_prop, row_, draw_slot,
-                               step_acc, seed, accumulate_now, trace_alpha, trace_accept);
+                               step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline);
             return hipGetLastError();
         }
     }

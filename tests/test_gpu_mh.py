@@ -170,7 +170,6 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
     from mcmc_date_amd import synthetic as S
 
     monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
-    monkeypatch.setenv("MCD_MH_PRIOR", "0")                  # (the prior inside the step: the part the two kernels do differently)
     topo = S.random_topology(n_leaves, seed=41)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=41)
@@ -180,7 +179,11 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
     con = [M.Constraint("k", 7, 3, 0.025)]
     ps, _ = M.proposals(topo, [], calibrations_available=True)
     sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :300]
-    for model in ("UncorrelatedGamma", "UncorrelatedWhiteNoise"):
+    for model, inside in (("UncorrelatedGamma", True), ("UncorrelatedWhiteNoise", True), ("UncorrelatedGamma", False)):
+        if inside:
+            monkeypatch.setenv("MCD_MH_PRIOR", "0")          # the prior inside the step: the part the two kernels do differently
+        else:
+            monkeypatch.delenv("MCD_MH_PRIOR", raising=False)   # beside the likelihood (N <= 256): the kernels only leave the flags
         runs = []
         for wg in ("1", "0"):
             monkeypatch.setenv("MCD_MH_STEP_WG", wg)
