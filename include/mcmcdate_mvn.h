@@ -92,7 +92,11 @@ int mcd_mvn_set_form(const mcd_mvn_t* h, int form);
  *   mat          [n*n] row-major Sigma or Sigma^-1 (see mat_kind); only its symmetric part is used
  *   logdet_sigma log det Sigma; used as given when mat_kind = MCD_MAT_SIGMA_INV (the .data file
  *                carries it, app/Main.hs:240); ignored for MCD_MAT_SIGMA (computed from the factor)
- * The Cholesky factor L of Sigma is computed on the host and staged on the device once.
+ * The factors are computed on the host and staged on the device once: from Sigma its Cholesky factor; from Sigma^-1 = P the
+ * factor W with P = W^T W directly (a reverse Cholesky factorisation: nothing is inverted twice) and L = W^-1 for the sweeps.
+ * Contract, stricter than the reference's: the matrix must be numerically positive definite -- MCD_ERR_NOT_SPD otherwise.  (The
+ * reference evaluates dx^T P dx with whatever P the .data file holds; `prepare` itself refuses a covariance matrix whose
+ * determinant is not positive, app/Main.hs:231, so an indefinite P only arises from a hand-made file.)
  */
 int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, int mat_kind,
                    double logdet_sigma, int device_id);
