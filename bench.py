@@ -126,7 +126,9 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3):
     return {"value": B * steps / dt, "unit": "proposal steps/s (lock steps x chains)", "us_per_lockstep": 1e6 * dt / steps,
             "n_nodes": int(topo.n_nodes), "dimension": int(nd), "chains": int(B), "lock_steps": int(steps),
             "proposals_per_iteration": int(sum(p.weight for p in ps)),
-            "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device, two launches per lock step"}
+            "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device; "
+                    + ("whole schedule in one launch, two chains per workgroup, the factor streamed once per step" if (65 <= topo.n_nodes <= 320 and B <= 512)
+                       else "two launches per lock step")}
 
 
 def main():
@@ -197,7 +199,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": f"lock-step Metropolis-Hastings, synthetic {r['n_nodes']}-node tree (dimension {nd}), {B} chains per GPU, "
                                        f"the reference's proposal cycle ({r['proposals_per_iteration']} proposals per iteration)",
-                           "n": nd, "chains_per_gpu": B, "kernel": "mh", "launch": "two launches per lock step",
+                           "n": nd, "chains_per_gpu": B, "kernel": "mh", "launch": "see mh.what",
                            "parallelism": f"chains sharded x{world}, no data-path collective"},
                 "roofline": {"bound": "hbm", "achieved": alg_b / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg_b / (elapsed / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,

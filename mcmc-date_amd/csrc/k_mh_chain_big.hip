@@ -1,0 +1,338 @@
+// k_mh_chain_big.hip -- a whole Metropolis-Hastings-Green schedule in ONE launch for trees of 65 .. 258 nodes at a sampler's
+// batch (gfx950).  SURVEY.md 8(f) row f2; the persistent form VERDICT (round 1, item 5) asked for, with the factor streamed
+// instead of resident: it does not fit (263 KB at N = 255), but it stays in L2, every workgroup streams it at the same time, and
+// what a launch per step really costs -- 1.7 us of dispatch twice per step, every chain's state, posterior terms, tuning
+// parameter and draws fetched from memory at the start of each launch and written back at its end -- disappears.
+//
+// A workgroup owns TWO chains for the complete schedule: two chain waves and two loader waves, exactly the geometry of the
+// sweep's tree-likelihood launch at this batch size (k_tree_logpdf<R, 1, 2, 2>).  Per step, with no launch in between:
+//   chain wave    propose (mh_device.hpp) -> changed blocks of the ln prior (prior_device.hpp) -> distances of the proposed state
+//                 from LDS -> forward sweep against the LDS ring (mvn_device.hpp: fwd_compute) -> accept / reject
+//   loader wave   streams the factor of Sigma through the ring once per step (fwd_loader), in step with the chain waves
+//                 through the ring's workgroup barriers
+// A chain's state (heights, rates, the five scalars, the three blocks of its ln prior, ln likelihood, ln root-branch
+// Jacobian), its tuning parameters and counters live in LDS and registers from the first step to the last; so do the tree tables
+// the proposals and the prior look up (parent, sub tree size, children).
+//
+// The arithmetic is the two-launch path's (k_mh.hip + k_tree_logpdf.hip): the same proposal and prior functions on the same
+// numbers, the same sweep templates with the same R, the same reduction -- a chain advanced by this kernel is bit-identical to
+// the same chain advanced by that path (tests/test_gpu_mh.py::test_streaming_chain_kernel_equals_two_launch_path).  Steps whose
+// proposal cannot move the likelihood (birth rate, death rate, rate variance) skip the sweep on both sides: the decision is a
+// function of the proposal row alone, so chain waves and loader waves take it alike.
+//
+// Reference: the loop this replaces is `mhg`'s iteration of `mcmc` [external] driven from app/Main.hs:460-479 with the cycle of
+// app/Definitions.hs:256-278; likelihood app/Probability.hs:166-173, 195-207; jacobianRootBranch :393-410.
+#include "mvn_device.hpp"
+#include "mh_device.hpp"
+#include "prior_device.hpp"
+
+#include <atomic>
+
+namespace mcd {
+
+// does a proposal of this row move the distances?  (MCD_PROP_SCALE_SCALAR on birth rate, death rate or rate variance does not)
+__device__ __forceinline__ bool mhb_moves_likelihood(int kind, int node)
+{
+    return !(kind == MCD_PROP_SCALE_SCALAR && (node == 0 || node == 1 || node == 4));
+}
+
+// LDS per chain (doubles): 4 state rows, tuning parameters, counters (two int32 per double)
+__host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int n_prop) { return 4 * (size_t)n_nodes + 2 * (size_t)n_prop; }
+// ... and per workgroup: the tree tables (five int32 arrays of n_nodes, rounded up to doubles)
+__host__ __device__ inline size_t mhb_table_doubles(int n_nodes) { return (5 * (size_t)n_nodes + 1) / 2 + 1; }
+
+template <int R>
+__global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, TreeDev T, PriorDev P, const int32_t* __restrict__ sched,
+                                                      int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed,
+                                                      double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
+{
+    constexpr int CW = 2, LW = Cfg<R>::LW;
+    static_assert(LW == 2, "geometry of k_tree_logpdf<R, 1, 2, 2>");
+    __shared__ d2 ring[2 * Cfg<R>::SU * 64];
+    extern __shared__ double dyn[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nn = M.n_nodes, NP = M.n_prop;
+    const int ncols = V.ncols;
+    MCD_ACC_DECL
+
+    // ---- loader waves: one pass over the factor per step that needs the likelihood
+    if (wave >= CW) {
+        const int lw = wave - CW;
+        Stage<R, LW> st;
+        int p = sched[0];
+        int kind = M.kind[p], node = M.node[p];
+        for (int64_t gs = 0; gs < n_steps; ++gs) {
+            const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
+            const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
+            if (mhb_moves_likelihood(kind, node)) {
+                fwd_loader_prologue<R, LW>(V.Ft, ring, st, lw, lane);
+                lds_barrier();
+                fwd_loader_start<R, LW>(V.Ft, st, lw, lane);
+                fwd_loader<R, LW, 0>(V.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
+            }
+            kind = kind_next;
+            node = node_next;
+        }
+        return;
+    }
+
+    // ---- chain waves
+    const int64_t B = M.batch;
+    const int64_t b_raw = (int64_t)blockIdx.x * CW + wave;
+    const bool valid = b_raw < B;                            // a chain beyond the batch works on the last chain's inputs and stores nothing
+    const int64_t b = valid ? b_raw : B - 1;
+    // tree tables in LDS, shared by the two chains (filled by both chain waves; no workgroup barrier may be used here: the
+    // loaders are already at theirs) -- each wave fills the whole table itself, the values are the same
+    int32_t* tb_parent = reinterpret_cast<int32_t*>(dyn);
+    int32_t* tb_size = tb_parent + nn;
+    int32_t* tb_first = tb_size + nn;
+    int32_t* tb_nch = tb_first + nn;
+    int32_t* tb_second = tb_nch + nn;
+    for (int v = lane; v < nn; v += 64) {
+        tb_parent[v] = M.parent[v];
+        tb_size[v] = M.size[v];
+        tb_first[v] = P.first_child[v];
+        tb_nch[v] = P.n_children[v];
+        tb_second[v] = P.second_child[v];
+    }
+    MhDev Ml = M;
+    Ml.parent = tb_parent;
+    Ml.size = tb_size;
+    PriorDev Pl = P;
+    Pl.parent = tb_parent;
+    Pl.first_child = tb_first;
+    Pl.n_children = tb_nch;
+    Pl.second_child = tb_second;
+    double* Hc = dyn + mhb_table_doubles(nn) + (size_t)wave * mhb_chain_doubles(nn, NP);
+    double* Rc = Hc + nn;
+    double* Hp = Rc + nn;
+    double* Rp = Hp + nn;
+    double* tune = Rp + nn;
+    int32_t* acc = reinterpret_cast<int32_t*>(tune + NP);
+    int32_t* tried = acc + NP;
+    for (int w = lane; w < nn; w += 64) {
+        Hc[w] = M.H[b * M.ld + w];
+        Rc[w] = M.R[b * M.ld + w];
+        Hp[w] = 0.0;
+        Rp[w] = 0.0;
+    }
+    for (int i = lane; i < NP; i += 64) {
+        tune[i] = M.tune[b * NP + i];
+        acc[i] = M.acc[b * NP + i];
+        tried[i] = M.tried[b * NP + i];
+    }
+    double sc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sc[i] = M.sc[i * B + b];
+    double ll = M.post[B + b], lj = M.post[2 * B + b];
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes have landed (one wave: in order)
+    __builtin_amdgcn_wave_barrier();
+    // the three blocks of the ln prior of the current state; a step re-evaluates only the blocks whose inputs moved
+    double c0 = prior_nodes_wave(Pl, lane, sc[2], Hc);
+    double c1 = prior_bd_wave(Pl, lane, sc[0], sc[1], Hc);
+    ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
+    double c2 = prior_clock_wave(Pl, lane, sc[3], sc[4], Hc, Rc, &cc);
+    double lp = c0 + c1 + c2;
+    // rows 64 k + lane of the solve: mean, 1 / L_ii, the node whose branch feeds the distance slot and that node's parent
+    double mu_r[R], iv_r[R];
+    int sl_a[R], sl_pa[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int row = 64 * k + lane;
+        mu_r[k] = V.mu[row];
+        iv_r[k] = V.invdiag[row];
+        sl_a[k] = T.slot_node[row];                          // -1 for padded rows
+        sl_pa[k] = T.slot_parent[row];                       // 0 for padded rows
+    }
+    const int rr = T.root_right;
+    constexpr int NAGE = 5;                                  // strides of 64 nodes: n_nodes <= 258 + room
+    double age_s[NAGE], age_q[NAGE];
+#pragma unroll
+    for (int i = 0; i < NAGE; ++i) age_s[i] = age_q[i] = 0.0;
+    const double beta = M.beta[b];
+    int p = sched[0];
+    PropRow row = mh_load_row(M, p);
+    StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
+    for (int64_t gs = 0; gs < n_steps; ++gs) {
+        const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
+        const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
+        if ((gs & 63) == 0) {
+            // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
+            // parameter (as k_mh_chain.hip, and as k_mh_draws does for the two-launch path)
+            const int64_t mine = gs + lane;
+            if (mine < n_steps) {
+                const int pl = sched[mine];
+                pre = mh_step_draws(mh_load_row(M, pl), tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
+            }
+        }
+        const int sl = (int)(gs & 63);
+        const StepDraws dr{mh_readlane64(pre.u, sl), mh_readlane64(pre.lnq, sl), mh_readlane64(pre.logu, sl), mh_readlane64(pre.U, sl),
+                           mh_readlane64(pre.Uacc, sl)};
+        double sc1[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
+        const double lnqj = mh_propose_wave(Ml, row, tune[p], dr, lane, sc1, Hc, Rc, Hp, Rp);
+        __builtin_amdgcn_wave_barrier();
+        bool dH = false, dR = false;
+        for (int w0 = 0; w0 < nn; w0 += 64) {
+            const int w = w0 + lane;
+            const bool in = w < nn;
+            dH = dH || (__builtin_amdgcn_ballot_w64(in && Hp[in ? w : 0] != Hc[in ? w : 0]) != 0);     // NaN != NaN: re-evaluated
+            dR = dR || (__builtin_amdgcn_ballot_w64(in && Rp[in ? w : 0] != Rc[in ? w : 0]) != 0);
+        }
+        ClockCache ccp = cc;                                 // refreshed only if the proposal moved rVar
+        const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
+        const double c1p = (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) ? prior_bd_wave(Pl, lane, sc1[0], sc1[1], Hp) : c1;
+        const double c2p = (dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2))
+                               ? prior_clock_wave(Pl, lane, sc1[3], sc1[4], Hp, Rp, &ccp) : c2;
+        const double lp1 = c0p + c1p + c2p;
+        // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207),
+        // the arithmetic of load_tree (mvn_device.hpp)
+        double ll1 = ll, lj1 = lj;
+        if (mhb_moves_likelihood(row.kind, row.node)) {      // (a function of the row alone: the loaders decide alike)
+            const double s = sc1[2] * sc1[3];
+            double d[R][1];
+            double dist0 = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int rw = 64 * k + lane;
+                double v = 0.0;
+                if (sl_a[k] >= 0) {
+                    v = (Hp[sl_pa[k]] - Hp[sl_a[k]]) * Rp[sl_a[k]];
+                    if (rw == 0) v = v + (Hp[0] - Hp[rr]) * Rp[rr];
+                    v = v * s;
+                }
+                if (k == 0) dist0 = v;
+                d[k][0] = (v - mu_r[k]) * iv_r[k];
+            }
+            lj1 = log(1.0 / readlane64(dist0, 0));          // jacobianRootBranch, :393-410
+            lds_barrier();
+            fwd_compute<R, 1, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
+            double sq = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) sq = fma(d[k][0], d[k][0], sq);
+            const double q = wave_sum(sq);
+            ll1 = V.c + (-0.5) * (V.logdet + q);             // :169 (finish_ll)
+        }
+        double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
+        if (row.jac_root) la += (double)row.jac_root * (lj1 - lj);
+        const bool ok = (la >= 0) || (dr.Uacc < exp(la));
+        if (ok) {
+            for (int w = lane; w < nn; w += 64) {
+                Hc[w] = Hp[w];
+                Rc[w] = Rp[w];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
+            c0 = c0p;
+            c1 = c1p;
+            c2 = c2p;
+            cc = ccp;
+            lp = lp1;
+            ll = ll1;
+            lj = lj1;
+        }
+        if (lane == 0) {
+            tried[p] += 1;
+            if (ok) acc[p] += 1;
+            if (valid) {
+                if (trace_alpha) trace_alpha[gs * B + b] = la;
+                if (trace_accept) trace_accept[gs * B + b] = ok ? 1 : 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (accumulate && (gs + 1) % S == 0) {
+#pragma unroll
+            for (int i = 0; i < NAGE; ++i) {
+                const int w = 64 * i + lane;
+                if (w < nn) {
+                    const double a = sc[2] * Hc[w];
+                    age_s[i] += a;
+                    age_q[i] += a * a;
+                }
+            }
+        }
+        p = p_next;
+        row = row_next;
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int i = 0; i < NAGE; ++i) {
+        const int w = 64 * i + lane;
+        if (w < nn) {
+            M.H[b * M.ld + w] = Hc[w];
+            M.R[b * M.ld + w] = Rc[w];
+            if (accumulate) {
+                M.age_sum[b * nn + w] += age_s[i];
+                M.age_sq[b * nn + w] += age_q[i];
+            }
+        }
+    }
+    for (int i = lane; i < NP; i += 64) {
+        M.acc[b * NP + i] = acc[i];
+        M.tried[b * NP + i] = tried[i];
+    }
+    if (lane < 5) {
+        double mine = sc[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i)
+            if (lane == i) mine = sc[i];
+        M.sc[lane * B + b] = mine;
+    }
+    if (lane == 0) {
+        M.post[b] = lp;
+        M.post[B + b] = ll;
+        M.post[2 * B + b] = lj;
+        M.pcomp[b * 3 + 0] = c0;                             // (a later run on the two-launch path continues from these)
+        M.pcomp[b * 3 + 1] = c1;
+        M.pcomp[b * 3 + 2] = c2;
+    }
+}
+
+static size_t mhb_lds_bytes(int n_nodes, int n_prop)
+{
+    return sizeof(double) * (mhb_table_doubles(n_nodes) + 2 * mhb_chain_doubles(n_nodes, n_prop));
+}
+
+// trees of 65 .. 258 + 64 nodes whose factor the sweep holds in 2 .. 4 register blocks, a batch that is resident at once (one
+// workgroup per CU: 512 chains), state + tables + the 64 KiB ring within a CU's LDS
+bool mh_chain_big_available(const MhDev& M, const MvnDev& V)
+{
+    if (V.R < 2 || V.R > 4 || M.n_nodes > 64 * 5 || M.batch > 512) return false;
+    return mhb_lds_bytes(M.n_nodes, M.n_prop) + 64 * 1024 <= 160 * 1024;
+}
+
+template <int R>
+static hipError_t launch_big_R(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const int32_t* sched, int64_t n_steps,
+                               int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
+{
+    const size_t dynb = mhb_lds_bytes(M.n_nodes, M.n_prop);
+    static std::atomic<unsigned long long> allowed{0};       // more than 64 KiB of LDS in total has to be allowed once per device
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!((allowed.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_chain_big<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) return e;
+        allowed.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k_mh_chain_big<R>, dim3((unsigned)((M.batch + 1) / 2)), dim3(256), dynb, st, M, V, T, P, sched, n_steps, S, accumulate,
+                       step0, seed, trace_alpha, trace_accept);
+    return hipGetLastError();
+}
+
+hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const int32_t* sched, int64_t n_steps,
+                               int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
+                               hipStream_t st)
+{
+    if (n_steps <= 0) return hipSuccess;
+    if (!mh_chain_big_available(M, V)) return hipErrorInvalidValue;
+    switch (V.R) {
+    case 2: return launch_big_R<2>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+    case 3: return launch_big_R<3>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+    case 4: return launch_big_R<4>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mcd

@@ -352,7 +352,25 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         m->step += steps;
         if (accumulate) m->n_samples += n_iter;
     }
-    if (!m->chain_kernel) {
+    // larger trees at a sampler's batch: the whole schedule in one launch as well, the factor streamed once per step
+    // (k_mh_chain_big.hip).  MCD_MH_PER_PHASE=1 keeps the two-launch path (tests, timing; read per call).
+    const char* per_phase_env = getenv("MCD_MH_PER_PHASE");
+    const bool streaming = !m->chain_kernel && !(per_phase_env && per_phase_env[0] == '1') && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
+                           mcd::mh_chain_big_available(D, *m->mvn);
+    if (streaming) {
+        // (launches of at most ~64 k steps, whole iterations each: a second or so of kernel time; what a launch costs -- the chains'
+        // state in, out again -- is some 20 us)
+        const int64_t per_launch = (int64_t)S * (65536 / S > 0 ? 65536 / S : 1);
+        for (int64_t done = 0; done < (int64_t)steps; done += per_launch) {
+            const int64_t now = ((int64_t)steps - done < per_launch) ? (int64_t)steps - done : per_launch;
+            MHIP_TRY(mcd::launch_mh_chain_big(D, *m->mvn, *m->tree, *m->prior, m->d_sched + done, now, S, accumulate, m->step, m->seed,
+                                              trace ? m->d_trace_alpha + done * B : nullptr, trace ? m->d_trace_accept + done * B : nullptr,
+                                              m->stream));
+            m->step += (uint64_t)now;
+        }
+        if (accumulate) m->n_samples += n_iter;
+    }
+    if (!m->chain_kernel && !streaming) {
         // two launches per step: [accept step s-1 + propose step s + ln prior] and [likelihood + root-branch Jacobian]
         const int64_t total = (int64_t)steps;
         if ((size_t)D.n_nodes * 32 > 64 * 1024) return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_run: more than 2048 nodes");

@@ -199,6 +199,52 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
         assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
+@pytest.mark.parametrize("n_leaves,B", [(40, 7), (70, 64), (129, 512), (129, 33), (100, 16)])
+def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, monkeypatch):
+    """Trees of 65 .. 320 nodes at up to 512 chains run the whole schedule in one launch, two chains per workgroup, the factor
+    streamed through the sweep's LDS ring once per step (k_mh_chain_big.hip).  The same proposal, prior and sweep code on the same
+    numbers as the two-launch path (MCD_MH_PER_PHASE=1): bit-identical traces, states, posteriors, tuning counters and age sums --
+    odd batches (a chain wave without a chain), two clock models, calibrations and a constraint, runs continued by the other
+    path."""
+    from mcmc_date_amd import synthetic as S
+
+    topo = S.random_topology(n_leaves, seed=51)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=51)
+    s0 = S.random_states(topo, B, seed=52)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    cal = [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025), M.Calibration("n", 5, 0.2, 0.025, None, 0.0)]
+    con = [M.Constraint("k", 7, 3, 0.025)]
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :260]
+    for model in ("UncorrelatedGamma", "AutocorrelatedLogNormal"):
+        runs = []
+        for phased in (False, True):
+            if phased:
+                monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
+            else:
+                monkeypatch.delenv("MCD_MH_PER_PHASE", raising=False)
+            lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+            lik.mvn.set_form("sweep")                        # (the two-launch path would take the row split at 240 < N <= 256, <= 128 chains)
+            smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, [], topo), ps, B, seed=13)
+            smp.set_state(s0)
+            a, k = smp.run_schedule(sched[:, :200], accumulate=True, trace=True)
+            # the last 60 steps by the OTHER path: what one path leaves behind, the other continues from
+            if phased:
+                monkeypatch.delenv("MCD_MH_PER_PHASE", raising=False)
+            else:
+                monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
+            a2, k2 = smp.run_schedule(sched[:, 200:], accumulate=True, trace=True)
+            runs.append((np.concatenate([a, a2]), np.concatenate([k, k2]), smp.state(), smp.posterior(), smp.tuning(), smp.age_sums()[:2]))
+        monkeypatch.delenv("MCD_MH_PER_PHASE", raising=False)
+        (a1, k1, s1, p1, t1, g1), (a2, k2, s2, p2, t2, g2) = runs
+        assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
+        for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
+            assert np.array_equal(getattr(s1, f), getattr(s2, f)), (model, f)
+        assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(t1, t2))
+        assert all(np.allclose(x, y, rtol=1e-13, atol=0) for x, y in zip(g1, g2))      # (sums formed per run, then added: not bitwise)
+
+
 @pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150), (70, 2100, 24)])
 def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
     """Synthetic trees beyond 64 nodes (70 leaves: 139 nodes, N = 137, three row blocks; 128 leaves: 255 nodes, N = 253,
