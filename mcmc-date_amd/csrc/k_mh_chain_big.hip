@@ -66,9 +66,12 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
             if (mhb_moves_likelihood(kind, node)) {
+                // chunk 0 into the ring, chunks 1 and 2 requested -- all of it while the chain waves propose and evaluate the prior
+                // (the stand-alone launch requests 1 and 2 after the barrier, out of the way of the compute waves' state loads;
+                // here nothing competes and the stream's first round trip would be exposed at every step)
                 fwd_loader_prologue<R, LW>(V.Ft, ring, st, lw, lane);
-                lds_barrier();
                 fwd_loader_start<R, LW>(V.Ft, st, lw, lane);
+                lds_barrier();
                 fwd_loader<R, LW, 0>(V.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
             }
             kind = kind_next;
@@ -151,6 +154,19 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 #pragma unroll
     for (int i = 0; i < NAGE; ++i) age_s[i] = age_q[i] = 0.0;
     const double beta = M.beta[b];
+#ifdef MCD_MHB_STAMP
+    // diagnostic build (make stamp_mhbig): s_memtime ticks per phase, summed over the run, in the first rows of trace_alpha
+    uint64_t tk[6] = {0, 0, 0, 0, 0, 0};
+#define MHB_TICK(i)                                       \
+    {                                                     \
+        const uint64_t now_ = __builtin_readcyclecounter(); \
+        tk[i] += now_ - t_last;                           \
+        t_last = now_;                                    \
+    }
+    uint64_t t_last = __builtin_readcyclecounter();
+#else
+#define MHB_TICK(i)
+#endif
     int p = sched[0];
     PropRow row = mh_load_row(M, p);
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
@@ -172,8 +188,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         double sc1[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
+        MHB_TICK(0)
         const double lnqj = mh_propose_wave(Ml, row, tune[p], dr, lane, sc1, Hc, Rc, Hp, Rp);
         __builtin_amdgcn_wave_barrier();
+        MHB_TICK(1)
         bool dH = false, dR = false;
         for (int w0 = 0; w0 < nn; w0 += 64) {
             const int w = w0 + lane;
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const double c2p = (dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2))
                                ? prior_clock_wave(Pl, lane, sc1[3], sc1[4], Hp, Rp, &ccp) : c2;
         const double lp1 = c0p + c1p + c2p;
+        MHB_TICK(2)
         // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207),
         // the arithmetic of load_tree (mvn_device.hpp)
         double ll1 = ll, lj1 = lj;
@@ -207,6 +226,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                 d[k][0] = (v - mu_r[k]) * iv_r[k];
             }
             lj1 = log(1.0 / readlane64(dist0, 0));          // jacobianRootBranch, :393-410
+            MHB_TICK(3)
             lds_barrier();
             fwd_compute<R, 1, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
             double sq = 0.0;
@@ -215,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             const double q = wave_sum(sq);
             ll1 = V.c + (-0.5) * (V.logdet + q);             // :169 (finish_ll)
         }
+        MHB_TICK(4)
         double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
         if (row.jac_root) la += (double)row.jac_root * (lj1 - lj);
         const bool ok = (la >= 0) || (dr.Uacc < exp(la));
@@ -255,7 +276,12 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         }
         p = p_next;
         row = row_next;
+        MHB_TICK(5)
     }
+#ifdef MCD_MHB_STAMP
+    if (trace_alpha && lane == 0 && valid)
+        for (int i = 0; i < 6; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // ticks: loop head, propose, prior, distances, barrier + sweep, accept
+#endif
     if (!valid) return;
 #pragma unroll
     for (int i = 0; i < NAGE; ++i) {
