@@ -168,21 +168,23 @@ def test_device_nuts_follows_the_cpu_twin(gpu, golden):
     assert len(set(depth.tolist())) >= 1 and depth.max() <= max_depth and depth.min() >= 1
 
 
-def test_device_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden):
-    """End to end in the library (mcd_hmc_nuts_run: NUTS on the device, dual averaging in the C++ host side): node-age means on
-    tests/12-leaves-variable-rate within 3 % of Metropolis-Hastings chains with the same target (every proposal lifted with
-    jacobianRootBranch); the adapted step sizes give the target acceptance statistic; a chain's draws do not depend on the batch."""
+@pytest.mark.parametrize("name,B", [("12-leaves-variable-rate", 64), ("24-leaves-braces", 128)])
+def test_device_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden, name, B):
+    """End to end in the library (mcd_hmc_nuts_run: NUTS on the device, dual averaging in the C++ host side): node-age means
+    within 3 % of Metropolis-Hastings chains with the same target (every proposal lifted with jacobianRootBranch); the adapted
+    step sizes give the target acceptance statistic; a chain's draws do not depend on the batch.  tests/12-leaves-variable-rate
+    with 64 chains, and BASELINE config 4 at its size: tests/24-leaves-braces (calibrations, constraints and braces active) with
+    the Hamiltonian proposal, 128 chains."""
     import dataclasses
 
     from mcmc_date_amd import monitor as MO
 
-    fx = golden["12-leaves-variable-rate"]
+    fx = golden[name]
     topo = M.Topology(fx["parent"])
     cal, con, br = tables(fx)
     ht = float(fx["prior_ht"])
     pf = M.PriorFunction(ht, "UncorrelatedGamma", cal, con, br, topo)
     lik = M.MvnLikelihood(M.Full(fx["mu"], fx["sigma_inv"], float(fx["logdet"]))).bind_tree(topo)
-    B = 64
     ps, _ = M.proposals(topo, br, calibrations_available=True, exact_jacobians=True)
     ps = [dataclasses.replace(p, jac_root=1) for p in ps]
     smp = M.Sampler(lik, pf, ps, B, seed=78)
