@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
 constexpr int MHW = 4;                                     // waves per chain (two workgroups per CU at two waves per SIMD: 256 VGPRs each, no spills)
 __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P, int p_acc, int jac_root_acc, int p_prop, PropRow row_prop,
                                                             int draw_slot, uint64_t step_acc, uint64_t seed, int accumulate_now,
-                                                            double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int prior_inline)
+                                                            double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int prior_inline,
+                                                            TreeDev T, int n_dim, double* __restrict__ X1, int64_t ldx)
 {
     extern __shared__ double sh[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -339,6 +340,26 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
             if (tid == i) mine = scn[i];
         M.sc1[tid * B + b] = mine;
     }
+    if (X1 != nullptr) {
+        // The distances of the proposed state, so that the likelihood launch takes them as a plain vector: the proposal is in LDS
+        // here, while the row-split kernel's tree staging gathers it from global memory a chain at a time (25.7 against 19.3 us at
+        // 1023 slots).  The arithmetic of that staging (k_split.hip) and of load_tree: ((h_parent - h_node) * rate [+ the second
+        // root branch]) * (tH * rMu); ln jacobianRootBranch from slot 0 (app/Probability.hs:201-207, 394, 409).
+        const double s = scn[2] * scn[3];
+        const int rr = T.root_right;
+        for (int j = tid; j < n_dim; j += NT) {
+            const int a = T.slot_node[j], pa = T.slot_parent[j];
+            double d = (Hs[pa] - Hs[a]) * Rs[a];
+            if (j == 0) {
+                d = d + (Hs[0] - Hs[rr]) * Rs[rr];
+                d = d * s;
+                M.post1[2 * B + b] = log(1.0 / d);
+            } else {
+                d = d * s;
+            }
+            X1[b * ldx + j] = d;
+        }
+    }
     if (!prior_inline) {                                   // the ln prior is evaluated beside the likelihood (mh_prior_role.hpp)
         if (tid == 0) {
             M.lnqj[b] = lnqj;
@@ -436,22 +457,30 @@ hipError_t launch_mh_draws(const MhDev& M, const int32_t* sched, int64_t idx0, i
     hipLaunchKernelGGL(k_mh_draws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, sched, idx0, count, step0, seed);
     return hipGetLastError();
 }
+// does launch_mh_step take the workgroup-per-chain kernel for this handle (MCD_MH_STEP_WG: 1 = for every tree, 0 = never)?
+bool mh_step_wg_active(const MhDev& M, int prior_inline)
+{
+    const char* env = getenv("MCD_MH_STEP_WG");
+    const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > 320);
+    const int NIT = (M.n_nodes - 1 + 63) / 64;
+    return wg && sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 16) <= 64 * 1024;
+}
+
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, int draw_slot,
                           uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
-                          hipStream_t st)
+                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st)
 {
     const PropRow row_{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
-    const char* env = getenv("MCD_MH_STEP_WG");            // tests, timing: 1 = the workgroup-per-chain form for every tree, 0 = never
-    const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > 320);
-    if (wg) {
+    if (mh_step_wg_active(M, prior_inline)) {
         const int NIT = (M.n_nodes - 1 + 63) / 64;
         const size_t lds = sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 16);
-        if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(k_mh_step_wg, dim3((unsigned)M.batch), dim3(64 * MHW), lds, st, M, P, p_acc, jac_root_acc, p_prop, row_, draw_slot,
-                               step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline);
-            return hipGetLastError();
-        }
+        const bool dist = T != nullptr && X1 != nullptr;
+        hipLaunchKernelGGL(k_mh_step_wg, dim3((unsigned)M.batch), dim3(64 * MHW), lds, st, M, P, p_acc, jac_root_acc, p_prop, row_, draw_slot,
+                           step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline, dist ? *T : TreeDev{}, n_dim,
+                           dist ? X1 : (double*)nullptr, ldx);
+        return hipGetLastError();
     }
+    if (X1 != nullptr) return hipErrorInvalidValue;        // (the caller asked for distances: only the workgroup kernel writes them)
     const size_t per_wave = sizeof(double) * 4 * (size_t)M.n_nodes;
     int wpb = 4;
     while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;

@@ -46,6 +46,7 @@ struct mcd_mh {
     int64_t n_samples = 0;
     bool have_state = false;
     bool chain_kernel = false;   // n_nodes <= 64: whole schedule in one launch
+    double* d_X1 = nullptr;         // [batch][n]: distances of the proposed states (large trees: written by k_mh_step_wg)
     std::vector<mcd::MhRow> rows;   // host copy of the proposal table
     const double* d_Fp = nullptr;
     hipStream_t stream = nullptr;
@@ -395,10 +396,22 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // lock step at 1025 nodes, 33.3 -> 35.4 at 513 -- the step kernel's other strided loops weigh more there; not kept.)
         const bool beside = !(env_prior && atoi(env_prior) == 0) && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
         const int prior_inline = beside ? 0 : 1;
+        // large trees: the step kernel (a workgroup per chain) leaves the proposed states' DISTANCES, the likelihood launch takes
+        // them as plain vectors (the row-split kernel's tree staging costs 6 us more at 1023 slots); same arithmetic, same bits
+        const int n_dim = m->mvn->n;
+        const bool use_x = mcd::mh_step_wg_active(D, prior_inline) && !beside && D.n_nodes > 320;
+        if (use_x && m->d_X1 == nullptr) {
+            MHIP_TRY(hipMalloc((void**)&m->d_X1, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
+            m->allocs.push_back(m->d_X1);
+        }
+        const mcd::TreeDev* Tx = use_x ? m->tree : nullptr;
+        double* X1 = use_x ? m->d_X1 : nullptr;
         MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr,
-                                     prior_inline, m->stream));
+                                     prior_inline, Tx, n_dim, X1, n_dim, m->stream));
         for (int64_t gs = 0; gs < total; ++gs) {
-            if (beside)
+            if (use_x)
+                MHIP_TRY(mcd::launch_logpdf(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, m->stream));
+            else if (beside)
                 MHIP_TRY(mcd::launch_tree_logpdf_with_prior(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
                                                             D.post1 + D.batch, D.post1 + 2 * D.batch, D, *m->prior, m->stream));
             else
@@ -410,7 +423,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 if (int rc = draws_for(gs + 1)) return rc;
             MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, (int)((gs + 1) & 63), m->step,
                                          m->seed, (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
-                                         trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, m->stream));
+                                         trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream));
             m->step += 1;
             if (accumulate && closes) m->n_samples += 1;
         }

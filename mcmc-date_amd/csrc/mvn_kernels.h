@@ -196,7 +196,10 @@ struct MhRow {
 // accept the pending step of proposal p_acc (< 0: none) and propose proposal p_prop (< 0: none) with the ln prior of its proposed state
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& row_prop, int draw_slot,
                           uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
-                          hipStream_t st);
+                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st);
+// true: launch_mh_step takes the workgroup-per-chain kernel, which can also leave the proposed states' distances in X1 [batch][ldx]
+// (T, n_dim, X1 given) for a plain-vector likelihood launch
+bool mh_step_wg_active(const MhDev& M, int prior_inline);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
 // ln prior of the proposed states from pflags / pcomp (what launch_mh_step leaves when asked not to evaluate it itself) as extra
 // workgroups of the sweep's tree-likelihood launch (k_tree_logpdf.hip): the ln prior and the ln likelihood of a proposal depend

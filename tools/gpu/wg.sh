@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 800 python -m pytest tests/test_gpu_mh.py -q -x -k "workgroup_per_chain or large_tree or beside" > gpurun_out/wg_tests.log 2>&1; echo "rc=$?" >> gpurun_out/wg_tests.log
+timeout -k 10 800 python -m pytest tests/test_gpu_mh.py -q -x -k "workgroup_per_chain or large_tree or beside or streaming" > gpurun_out/wg_tests.log 2>&1; echo "rc=$?" >> gpurun_out/wg_tests.log
 tail -6 gpurun_out/wg_tests.log
 for n in 1024 512 384; do
 for wg in 1 0; do
