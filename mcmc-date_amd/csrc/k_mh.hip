@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
     double* Rs = Hs + n;
     double* tb = Rs + n;                                   // [NIT][64] summands of the birth-death block
     double* tc = tb + NIT * 64;                            // [NIT][64] summands of the clock block
-    double* bc = tc + NIT * 64;                            // [16] wave 0 -> workers: proposed scalars, flags; workers -> wave 0: c0, hyper
+    double* bc = tc + NIT * 64;                            // [48] wave 0 -> all: proposed scalars, flags, the per-node transform; workers -> wave 0: c0, hyper
     // ---- the decision (every wave for itself: the same bits)
     bool ok = false;
     if (p_acc >= 0) {
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
     __syncthreads();                                       // the current state is in LDS
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
     double lnqj = 0.0;
+    PropApply* Ap = reinterpret_cast<PropApply*>(bc + 16);  // the per-node transform of the proposal, wave 0 -> all
     if (wave == 0) {
         const double t = M.tune[b * M.n_prop + p_prop];
         const double* dw = M.draws + ((size_t)draw_slot * B + b) * 5;     // the state-independent draws of this step (k_mh_draws)
@@ -303,29 +304,43 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
         double sc0[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc0[i] = sc[i];
-        lnqj = mh_propose_wave(M, row_prop, t, dr, lane, sc, Hc, Rc, Hs, Rs);
-        __builtin_amdgcn_wave_barrier();
-        // only the blocks of the ln prior whose inputs the proposal moved are evaluated again
-        bool dH = false, dR = false;
-        for (int w0 = 0; w0 < n; w0 += 64) {
-            const int w = w0 + lane;
-            const bool in = w < n;
-            dH = dH || (__builtin_amdgcn_ballot_w64(in && Hs[in ? w : 0] != Hc[in ? w : 0]) != 0);
-            dR = dR || (__builtin_amdgcn_ballot_w64(in && Rs[in ? w : 0] != Rc[in ? w : 0]) != 0);
-        }
-        const int f0 = (dH || sc[2] != sc0[2]) ? 1 : 0;
-        const int f1 = (dH || sc[0] != sc0[0] || sc[1] != sc0[1]) ? 2 : 0;
-        const int f2 = (dR || sc[3] != sc0[3] || sc[4] != sc0[4] || (dH && P.clock_model >= 2)) ? 4 : 0;
+        PropApply A0;
+        lnqj = mh_propose_params(M, row_prop, t, dr, lane, sc, Hc, Rc, A0);       // the scalar part: one wave's work
         if (lane == 0) {
+            *Ap = A0;
 #pragma unroll
             for (int i = 0; i < 5; ++i) bc[i] = sc[i];
-            bc[6] = (double)(f0 | f1 | f2);
+            // which blocks of the ln prior the proposed SCALARS move (the heights and rates are compared below)
+            bc[6] = (double)((sc[2] != sc0[2] ? 1 : 0) | ((sc[0] != sc0[0] || sc[1] != sc0[1]) ? 2 : 0) | ((sc[3] != sc0[3] || sc[4] != sc0[4]) ? 4 : 0));
+            bc[9] = 0.0;
+            bc[10] = 0.0;
         }
     } else {
         prior_clock_scalars(sc[4], cc);                    // while wave 0 proposes: most proposals leave the rate variance alone
     }
+    __syncthreads();                                       // the transform is in LDS
+    {
+        const PropApply A = *Ap;
+        bool mH = false, mR = false;
+        for (int w = tid; w < n; w += NT) {                // threads = nodes: the proposed state, and whether it differs
+            double h, r;
+            mh_propose_node(M, A, w, Hc, Rc, h, r);
+            Hs[w] = h;
+            Rs[w] = r;
+            mH = mH || (h != Hc[w]);                       // NaN != NaN: re-evaluated
+            mR = mR || (r != Rc[w]);
+        }
+        const bool wH = __builtin_amdgcn_ballot_w64(mH) != 0, wR = __builtin_amdgcn_ballot_w64(mR) != 0;
+        if (lane == 0) {
+            if (wH) bc[9] = 1.0;
+            if (wR) bc[10] = 1.0;
+        }
+    }
     __syncthreads();                                       // the proposed state is in LDS
-    const int flags = (int)bc[6];
+    // only the blocks of the ln prior whose inputs the proposal moved are evaluated again
+    const bool dH = bc[9] != 0.0, dR = bc[10] != 0.0;
+    const int scf = (int)bc[6];
+    const int flags = ((dH || (scf & 1)) ? 1 : 0) | ((dH || (scf & 2)) ? 2 : 0) | ((dR || (scf & 4) || (dH && P.clock_model >= 2)) ? 4 : 0);
     double scn[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) scn[i] = bc[i];
@@ -463,7 +478,7 @@ bool mh_step_wg_active(const MhDev& M, int prior_inline)
     const char* env = getenv("MCD_MH_STEP_WG");
     const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > 320);
     const int NIT = (M.n_nodes - 1 + 63) / 64;
-    return wg && sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 16) <= 64 * 1024;
+    return wg && sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 48) <= 64 * 1024;
 }
 
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, int draw_slot,
@@ -473,7 +488,7 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
     const PropRow row_{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
     if (mh_step_wg_active(M, prior_inline)) {
         const int NIT = (M.n_nodes - 1 + 63) / 64;
-        const size_t lds = sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 16);
+        const size_t lds = sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 48);
         const bool dist = T != nullptr && X1 != nullptr;
         hipLaunchKernelGGL(k_mh_step_wg, dim3((unsigned)M.batch), dim3(64 * MHW), lds, st, M, P, p_acc, jac_root_acc, p_prop, row_, draw_slot,
                            step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline, dist ? *T : TreeDev{}, n_dim,

@@ -181,11 +181,59 @@ __device__ inline StepDraws mh_step_draws(const PropRow& row, double t, const Rn
     return d;
 }
 
-// Apply the proposal `row` with tuning parameter t to the state (sc, H, R) of one chain; all 64 lanes active.
-// Writes the proposed heights / rates to H1 / R1 (global memory or LDS), updates sc in place and returns
-// ln (q-ratio * Jacobian) without the root-branch factor (NaN = invalid proposal => reject).
-__device__ __forceinline__ double mh_propose_wave(const MhDev& M, const PropRow& row, double t, const StepDraws& dr, int lane, double (&sc)[5],
-                                                  const double* H, const double* R, double* H1, double* R1)
+// What a proposal does to the nodes, as the per-node transform mh_propose_node applies: the scalar part of a proposal (random draw,
+// bounds, ratio, Jacobian) is one wave's work, the transform itself is independent per node -- a kernel with several waves per
+// chain lets all of them apply it (k_mh_step_wg).
+struct PropApply {
+    int kind;
+    int hlo, hhi, hlo2, hhi2, rlo, rhi;
+    int pt1, pt2, rp1, rp2, rp3;
+    int brace_lo, brace_hi;
+    int rate_positive_guard, h_divide;
+    double hmul, hmul2, rmul, radd, pv1, pv2, rm1, rm2, rm3, brace_delta;
+};
+
+// proposed height and rate of node w
+__device__ __forceinline__ void mh_propose_node(const MhDev& M, const PropApply& A, int w, const double* H, const double* R, double& h_out,
+                                                double& r_out)
+{
+    double h = H[w], r = R[w];
+    if (w >= A.hlo && w < A.hhi) h = A.h_divide ? h / A.hmul : h * A.hmul;
+    if (w >= A.hlo2 && w < A.hhi2) h *= A.hmul2;
+    if (w == A.pt1) h = A.pv1;
+    if (w == A.pt2) h = A.pv2;
+    if (w >= A.rlo && w < A.rhi) {
+        if (A.rate_positive_guard) {
+            r = (r - A.radd) * A.rmul + A.radd;
+            r = (r > 0) ? r : __builtin_nan("");
+        } else {
+            r *= A.rmul;
+        }
+    }
+    if (w == A.rp1) r *= A.rm1;
+    if (w == A.rp2) r *= A.rm2;
+    if (w == A.rp3) r *= A.rm3;
+    for (int i = A.brace_lo; i < A.brace_hi; ++i) {          // braced nodes: w is one of them and / or a daughter of one
+        const int x = M.brace_nodes[i];
+        const double hN = H[x];
+        if (w == x) {
+            h = hN + A.brace_delta;
+            if (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA) {
+                const double hP = H[M.parent[x]];
+                r *= (hP - hN) / (hP - hN - A.brace_delta);
+            }
+        }
+        if (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA && M.parent[w] == x) r *= (hN - H[w]) / (hN + A.brace_delta - H[w]);
+    }
+    h_out = h;
+    r_out = r;
+}
+
+// The scalar part of the proposal `row` with tuning parameter t on the state (sc, H, R) of one chain; all 64 lanes active.
+// Updates sc in place, fills the per-node transform and returns ln (q-ratio * Jacobian) without the root-branch factor (NaN =
+// invalid proposal => reject).
+__device__ __forceinline__ double mh_propose_params(const MhDev& M, const PropRow& row, double t, const StepDraws& dr, int lane, double (&sc)[5],
+                                                    const double* H, const double* R, PropApply& A)
 {
     const int n = M.n_nodes, kind = row.kind, v = row.node;
     const double p0 = row.p0;
@@ -418,39 +466,26 @@ __device__ __forceinline__ double mh_propose_wave(const MhDev& M, const PropRow&
         }
         default: lnq = __builtin_nan("");
     }
-    for (int w = lane; w < n; w += 64) {
-        double h = H[w], r = R[w];
-        if (w >= hlo && w < hhi) h = h_divide ? h / hmul : h * hmul;
-        if (w >= hlo2 && w < hhi2) h *= hmul2;
-        if (w == pt1) h = pv1;
-        if (w == pt2) h = pv2;
-        if (w >= rlo && w < rhi) {
-            if (rate_positive_guard) {
-                r = (r - radd) * rmul + radd;
-                r = (r > 0) ? r : __builtin_nan("");
-            } else {
-                r *= rmul;
-            }
-        }
-        if (w == rp1) r *= rm1;
-        if (w == rp2) r *= rm2;
-        if (w == rp3) r *= rm3;
-        for (int i = brace_lo; i < brace_hi; ++i) {      // braced nodes: w is one of them and / or a daughter of one
-            const int x = M.brace_nodes[i];
-            const double hN = H[x];
-            if (w == x) {
-                h = hN + brace_delta;
-                if (kind == MCD_PROP_SLIDE_BRACE_CONTRA) {
-                    const double hP = H[M.parent[x]];
-                    r *= (hP - hN) / (hP - hN - brace_delta);
-                }
-            }
-            if (kind == MCD_PROP_SLIDE_BRACE_CONTRA && M.parent[w] == x) r *= (hN - H[w]) / (hN + brace_delta - H[w]);
-        }
+    A = PropApply{kind, hlo, hhi, hlo2, hhi2, rlo, rhi, pt1, pt2, rp1, rp2, rp3, brace_lo, brace_hi, rate_positive_guard ? 1 : 0, h_divide ? 1 : 0,
+                  hmul, hmul2, rmul, radd, pv1, pv2, rm1, rm2, rm3, brace_delta};
+    return lnq + lnj;
+}
+
+// Apply the proposal `row` with tuning parameter t to the state (sc, H, R) of one chain; all 64 lanes active.
+// Writes the proposed heights / rates to H1 / R1 (global memory or LDS), updates sc in place and returns
+// ln (q-ratio * Jacobian) without the root-branch factor (NaN = invalid proposal => reject).
+__device__ __forceinline__ double mh_propose_wave(const MhDev& M, const PropRow& row, double t, const StepDraws& dr, int lane, double (&sc)[5],
+                                                  const double* H, const double* R, double* H1, double* R1)
+{
+    PropApply A;
+    const double lnqj = mh_propose_params(M, row, t, dr, lane, sc, H, R, A);
+    for (int w = lane; w < M.n_nodes; w += 64) {
+        double h, r;
+        mh_propose_node(M, A, w, H, R, h, r);
         H1[w] = h;
         R1[w] = r;
     }
-    return lnq + lnj;
+    return lnqj;
 }
 
 __device__ __forceinline__ double mh_optimal_rate(int dim)
