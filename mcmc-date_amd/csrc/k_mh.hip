@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_mh_step(MhDev M, PriorDev P, int p_acc,
 // The same step with a WORKGROUP of four waves per chain, for trees of more than 320 nodes: there one wave walks 6 .. 17 strides of
 // 64 nodes through every loop -- state copy, comparison, stores, and above all the two blocks of the ln prior, 16 trips through
 // the exponentials and logarithms each at 1025 nodes.  Wave 0 is the chain's wave: it runs the wave-level proposal code and closes
-// the sums.  All four waves copy the state and write the proposal back (threads = nodes); waves 1 .. 3 evaluate the per-node
+// the sums.  All four waves copy the state and write the proposal back (threads = nodes) and evaluate the per-node
 // summands of the birth-death and the clock block, the 64-node iterations dealt round-robin, into LDS, and wave 0 adds them lane
 // by lane in the order of the iterations and then over the wave, exactly as prior_bd_wave / prior_clock_wave do alone: the same
 // bits as k_mh_step.  (At 257 nodes the two forms take the same time -- one 64-node iteration of summands costs a wave as much
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
     extern __shared__ double sh[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NT = 64 * MHW, NWORK = MHW - 1;
+    constexpr int NT = 64 * MHW;
     const int64_t b = blockIdx.x;
     const int n = M.n_nodes;
     const int64_t B = M.batch;
@@ -382,24 +382,24 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
         }
         return;
     }
-    if (wave > 0) {
-        const int wi = wave - 1;
+    {                                                      // every wave takes its share of the 64-node iterations (wave 0 as well:
+        const int wi = wave;                               // it would only wait)
         if (flags & 2) {
             const bool near = prior_bd_near(scn[0], scn[1]);
-            for (int it = wi; it < NIT; it += NWORK) {
+            for (int it = wi; it < NIT; it += MHW) {
                 const int v = 1 + lane + 64 * it;
                 if (v < n) tb[it * 64 + lane] = prior_bd_term(P, v, near, scn[0], scn[1], Hs);
             }
         }
         if (flags & 4) {
             if (!(cc.va == scn[4])) prior_clock_scalars(scn[4], cc);
-            for (int it = wi; it < NIT; it += NWORK) {
+            for (int it = wi; it < NIT; it += MHW) {
                 const int v = 1 + lane + 64 * it;
                 if (v < n) tc[it * 64 + lane] = prior_clock_term(P, v, scn[4], cc.lg_k, cc.log_t, Hs, Rs);
             }
-            if (wi == 0 && lane == 0) bc[8] = cc.hyper;
+            if (wi == 1 && lane == 0) bc[8] = cc.hyper;
         }
-        if ((flags & 1) && wi == NWORK - 1) {
+        if ((flags & 1) && wi == MHW - 1) {
             const double c0 = prior_nodes_wave(P, lane, scn[2], Hs);
             if (lane == 0) bc[7] = c0;
         }
