@@ -127,7 +127,7 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3):
             "n_nodes": int(topo.n_nodes), "dimension": int(nd), "chains": int(B), "lock_steps": int(steps),
             "proposals_per_iteration": int(sum(p.weight for p in ps)),
             "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device; "
-                    + ("whole schedule in one launch, two chains per workgroup, the factor streamed once per step" if (65 <= topo.n_nodes <= 320 and B <= 512)
+                    + ("whole schedule in one launch, two chains per workgroup, the factor streamed once per step" if (65 <= topo.n_nodes <= 320 and B <= 1024)
                        else "two launches per lock step")}
 
 

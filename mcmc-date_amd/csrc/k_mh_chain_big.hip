@@ -321,11 +321,11 @@ static size_t mhb_lds_bytes(int n_nodes, int n_prop)
     return sizeof(double) * (mhb_table_doubles(n_nodes) + 2 * mhb_chain_doubles(n_nodes, n_prop));
 }
 
-// trees of 65 .. 258 + 64 nodes whose factor the sweep holds in 2 .. 4 register blocks, a batch that is resident at once (one
-// workgroup per CU: 512 chains), state + tables + the 64 KiB ring within a CU's LDS
+// trees of 65 .. 258 + 64 nodes whose factor the sweep holds in 2 .. 4 register blocks, a batch of at most two rounds of workgroups
+// (one workgroup per CU: 512 chains per round), state + tables + the 64 KiB ring within a CU's LDS
 bool mh_chain_big_available(const MhDev& M, const MvnDev& V)
 {
-    if (V.R < 2 || V.R > 4 || M.n_nodes > 64 * 5 || M.batch > 512) return false;
+    if (V.R < 2 || V.R > 4 || M.n_nodes > 64 * 5 || M.batch > 1024) return false;   // (1024 chains: two rounds of workgroups, still ahead of two launches per step)
     return mhb_lds_bytes(M.n_nodes, M.n_prop) + 64 * 1024 <= 160 * 1024;
 }
 

@@ -210,7 +210,7 @@ hipError_t launch_tree_logpdf_with_prior(const MvnDev& M, const TreeDev& T, cons
                                          hipStream_t st);
 // state-independent draws of the steps [idx0, idx0 + count) of the schedule (count <= 64), one thread per (step, chain)
 hipError_t launch_mh_draws(const MhDev& M, const int32_t* sched, int64_t idx0, int count, uint64_t step0, uint64_t seed, hipStream_t st);
-// whole schedule in one launch for trees of 65 .. 320 nodes at up to 512 chains (k_mh_chain_big.hip): two chains per workgroup,
+// whole schedule in one launch for trees of 65 .. 320 nodes at up to 1024 chains (k_mh_chain_big.hip): two chains per workgroup,
 // the factor streamed through the sweep's LDS ring once per step
 bool mh_chain_big_available(const MhDev& M, const MvnDev& V);
 hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const int32_t* sched, int64_t n_steps,

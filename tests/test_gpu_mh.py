@@ -199,9 +199,9 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
         assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
-@pytest.mark.parametrize("n_leaves,B", [(40, 7), (70, 64), (129, 512), (129, 33), (100, 16)])
+@pytest.mark.parametrize("n_leaves,B", [(40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777)])
 def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, monkeypatch):
-    """Trees of 65 .. 320 nodes at up to 512 chains run the whole schedule in one launch, two chains per workgroup, the factor
+    """Trees of 65 .. 320 nodes at up to 1024 chains (777: two rounds of workgroups) run the whole schedule in one launch, two chains per workgroup, the factor
     streamed through the sweep's LDS ring once per step (k_mh_chain_big.hip).  The same proposal, prior and sweep code on the same
     numbers as the two-launch path (MCD_MH_PER_PHASE=1): bit-identical traces, states, posteriors, tuning counters and age sums --
     odd batches (a chain wave without a chain), two clock models, calibrations and a constraint, runs continued by the other
