@@ -28,6 +28,14 @@ module McmcDate.Gpu
     c_mh_tune,
     c_mh_get_state,
     c_mh_get_age_sums,
+    -- * Hamiltonian proposal: NUTS on the device (raw bindings)
+    McdHmc,
+    c_hmc_create,
+    p_hmc_destroy,
+    c_hmc_dim,
+    c_hmc_set_state,
+    c_hmc_get_state,
+    c_hmc_nuts_run,
   )
 where
 
@@ -192,3 +200,32 @@ foreign import ccall unsafe "mcd_mh_get_state"
 
 foreign import ccall unsafe "mcd_mh_get_age_sums"
   c_mh_get_age_sums :: Ptr McdMh -> Ptr CDouble -> Ptr CDouble -> Ptr Int64 -> IO CInt
+
+-- The Hamiltonian proposal (`nutsWith`, app/Hamiltonian.hs:95-105) for B chains: state in, n NUTS transitions on the device
+-- with dual averaging of the step sizes (adapt /= 0), state out.  Position layout and mask as `hstructWith` (:62-70).
+data McdHmc
+
+foreign import ccall unsafe "mcd_hmc_create"
+  c_hmc_create :: Ptr (Ptr McdHmc) -> Ptr McdTree -> Ptr McdPrior -> CInt -> Int64 -> IO CInt
+
+foreign import ccall unsafe "&mcd_hmc_destroy"
+  p_hmc_destroy :: FunPtr (Ptr McdHmc -> IO ())
+
+foreign import ccall unsafe "mcd_hmc_dim"
+  c_hmc_dim :: Ptr McdHmc -> IO CInt
+
+foreign import ccall unsafe "mcd_hmc_set_state"
+  c_hmc_set_state ::
+    Ptr McdHmc -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Int64 -> IO CInt
+
+foreign import ccall unsafe "mcd_hmc_get_state"
+  c_hmc_get_state ::
+    Ptr McdHmc -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Ptr CDouble -> Int64 -> IO CInt
+
+-- n transitions; eps [batch] in/out, inverse masses [dim], target acceptance statistic, maximal tree depth, seed, global index of
+-- chain 0, number of the first transition (the random streams are keyed by it); out: mean acceptance statistic [batch], position
+-- means and variances [dim] (may be null)
+foreign import ccall safe "mcd_hmc_nuts_run"
+  c_hmc_nuts_run ::
+    Ptr McdHmc -> CInt -> CInt -> Ptr CDouble -> Ptr CDouble -> CDouble -> CInt -> Word64 -> Int64 -> Word64 -> Ptr CDouble -> Ptr CDouble ->
+    Ptr CDouble -> IO CInt
