@@ -28,6 +28,13 @@ module McmcDate.Gpu
     c_mh_tune,
     c_mh_get_state,
     c_mh_get_age_sums,
+    -- * Form selection and the sharding exchange (raw bindings)
+    c_set_logpdf_form,
+    c_mvn_set_form,
+    c_shard_unique_id,
+    c_shard_comm_create,
+    c_shard_comm_destroy,
+    c_shard_allgather,
     -- * Hamiltonian proposal: NUTS on the device (raw bindings)
     McdHmc,
     c_hmc_create,
