@@ -47,14 +47,15 @@ def measured_traffic(key=None):
 
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not fs:
-        return None
+        return None, None
     try:
         d = json.load(open(fs[-1]))
+        src = "profiles/" + os.path.basename(fs[-1]) + (f"[{key}]" if key is not None else "") + " (committed rocprofv3 --pmc passes, not collected by this run)"
         if key is not None:
-            return float(d[key]["per_launch_bytes_corrected"])
-        return float(d["per_launch_bytes_corrected"])
+            return float(d[key]["per_launch_bytes_corrected"]), src
+        return float(d["per_launch_bytes_corrected"]), src
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
@@ -398,6 +399,9 @@ def main():
         alg_b = algorithmic_bytes_per_eval(n, B) * B
         achieved = alg_b / per_launch_s / 1e9
         flops = algorithmic_flops_per_eval(n) * (2.0 if has_grad else 1.0) * B / per_launch_s / 1e12
+        traffic, traffic_source = (measured_traffic({("logpdf", 256): "n256", ("logpdf", 1024): "n1024", ("tree", 255): "tree255",
+                                                     ("tree", 1023): "tree1023"}.get((args.kind, n)))
+                                   if B == 512 and args.form == "auto" else (None, None))
         out = {
             "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes",   # BASELINE.json:metric, verbatim
             "value": evals / elapsed,
@@ -418,8 +422,7 @@ def main():
                                        else f"chains sharded x{world} + ll all-gather every {args.swap_period} steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic({("logpdf", 256): "n256", ("logpdf", 1024): "n1024", ("tree", 255): "tree255",
-                                                      ("tree", 1021): "tree1023"}.get((args.kind, n))) if B == 512 and args.form == "auto" else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_us_per_launch": per_launch_s * 1e6,
                          "alg_bytes_per_launch": alg_b,
                          "fp64_tflops": flops, "fp64_frac": flops / FP64_PEAK_TFLOPS},
@@ -435,6 +438,7 @@ def main():
                     import glob
                     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_wide_summary.json")))
                     out["roofline"]["traffic"] = float(json.load(open(fs[-1]))["pmc_traffic_n256_b8192"]["per_launch_bytes_corrected"])
+                    out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(fs[-1]) + "[pmc_traffic_n256_b8192] (committed rocprofv3 --pmc passes)"
                 except Exception:
                     pass
         if world == 1 and args.kind == "logpdf" and not args.no_mh:

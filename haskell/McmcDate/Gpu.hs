@@ -31,6 +31,7 @@ module McmcDate.Gpu
     -- * Form selection and the sharding exchange (raw bindings)
     c_set_logpdf_form,
     c_mvn_set_form,
+    c_mvn_release_stream,
     c_shard_unique_id,
     c_shard_comm_create,
     c_shard_comm_destroy,
@@ -92,6 +93,11 @@ foreign import ccall unsafe "mcd_set_logpdf_form"
 -- | The same choice for ONE likelihood handle (0 = follow the process default); returns the previous value.
 foreign import ccall unsafe "mcd_mvn_set_form"
   c_mvn_set_form :: Ptr McdMvn -> CInt -> IO CInt
+
+-- | A host that makes short-lived HIP streams calls this before destroying one: the stream's scratch set of the row-split
+-- kernels returns to the handle's pool.
+foreign import ccall safe "mcd_mvn_release_stream"
+  c_mvn_release_stream :: Ptr McdMvn -> Ptr () -> IO CInt
 
 -- | The path's one exchange across GPUs (one process per GPU): an all-gather of per-chain values over the ranks' chain
 -- shards, RCCL behind the C ABI (no RCCL binding needed here).  Rank 0 draws the 128-byte id, every rank creates the

@@ -76,12 +76,17 @@ const char* mcd_last_error(void);
  * Stream capture: every entry point that takes a stream may be captured into a hipGraph.  The row-split form gives a stream
  * under capture a scratch set of the capture's own, so a graph may be replayed on any stream while eager calls go on on the
  * stream it was captured from; two executable graphs instantiated from ONE capture must not be replayed concurrently.
+ * A scratch set (256 KiB; gradient calls add two arrays of 1024 chains x 16 ceil(N/16) doubles, allocated at the first gradient
+ * call) stays with its stream until the handle is destroyed.  A host that makes short-lived streams calls
+ * mcd_mvn_release_stream(h, stream) before destroying one: it waits for the stream and returns its set to the handle's pool
+ * (sets of captures stay with the capture: its graph may still be replayed).  hipStreamPerThread is keyed per calling thread.
  */
 #define MCD_FORM_AUTO 0
 #define MCD_FORM_SWEEP 1
 #define MCD_FORM_MULTIPLY 2
 int mcd_set_logpdf_form(int form);
 int mcd_mvn_set_form(const mcd_mvn_t* h, int form);
+int mcd_mvn_release_stream(const mcd_mvn_t* h, void* stream /* hipStream_t */);
 
 /*
  * Build the immutable likelihood operands on GPU `device_id`.
@@ -226,7 +231,11 @@ int mcd_prior_grad_batch(const mcd_prior_t* p, const double* birth, const double
  * on its way; the host only polls a counter):
  *   mcd_hmc_nuts        one transition from the handle's state with per-chain step sizes eps[batch] and inverse masses
  *                       inv_mass[dim]; random streams: Philox (seed, chain_offset + b, transition) -- a chain's draw does not
- *                       depend on the batch it runs in; out: mean acceptance statistic alpha[batch], tree depth[batch]
+ *                       depend on the batch it runs in; out: mean acceptance statistic alpha[batch], tree depth[batch].
+ *                       The streams share the counter layout of mcd_mh_*: a host that runs both on one seed passes
+ *                       seed ^ constant here (the Python mirror: hmc.NUTS_STREAM_DOMAIN) and a transition counter that never
+ *                       restarts.  After the call the handle holds the accepted point with its value and gradient, so any
+ *                       entry point (mcd_hmc_leapfrog, mcd_hmc_get_position, another transition) may follow directly.
  *   mcd_hmc_nuts_run    n transitions; adapt != 0: dual averaging of the step sizes towards the acceptance statistic delta
  *                       (Algorithm 6; eps in: starting value, out: the averaged value); mean_alpha[batch]; q_mean / q_var[dim]:
  *                       position means and variances pooled over chains and transitions (what a mass adaptation needs:

@@ -33,6 +33,7 @@ SYMBOLS = {
     "mcd_last_error": (C.c_char_p, []),
     "mcd_set_logpdf_form": (C.c_int, [C.c_int]),
     "mcd_mvn_set_form": (C.c_int, [_vp, C.c_int]),
+    "mcd_mvn_release_stream": (C.c_int, [_vp, _vp]),
     "mcd_mvn_create": (C.c_int, [C.POINTER(_vp), C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_int]),
     "mcd_mvn_destroy": (None, [_vp]),
     "mcd_mvn_dim": (C.c_int, [_vp]),

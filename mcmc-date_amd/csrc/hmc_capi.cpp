@@ -318,6 +318,11 @@ int nuts_transition(mcd_hmc* m, int max_depth, uint64_t seed, int64_t chain0, ui
         if (active == 0) break;
     }
     HHIP_TRY(mcd::launch_nuts_end(D, m->nuts, m->stream));
+    // k_nuts_end put the accepted point into D.q / D.grad / D.value and the state arrays, but the raw outputs of the gradient
+    // kernels still belong to the LAST LEAF evaluated (another point, possibly outside the support).  mcd_hmc_leapfrog's first
+    // half kick reads those raw outputs: evaluate them at the accepted point so that every entry point may follow a transition.
+    if (int rc = eval_gradients(m)) return rc;
+    HHIP_TRY(mcd::launch_hmc_collect(D, m->stream));
     return MCD_OK;
 }
 

@@ -41,6 +41,8 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <functional>
 #include <utility>
 #include <vector>
 
@@ -712,7 +714,10 @@ struct SplitHost {
     };
     std::mutex mu;
     std::vector<Set> spare;                                // zeroed, unassigned
-    std::map<std::pair<unsigned long long, hipStream_t>, Set> assigned;   // (capture id or 0, stream)
+    // key: (capture id + 1 while the stream is being captured | 0 for eager launches | a per-thread tag for hipStreamPerThread,
+    // which is ONE handle value for as many streams as there are threads), stream
+    std::map<std::pair<unsigned long long, hipStream_t>, Set> assigned;
+    std::vector<Set> retired;                              // sets a timing probe left with tickets taken and slots unread: never reused
     hipStream_t init_stream = nullptr;
 };
 
@@ -724,8 +729,7 @@ static hipError_t new_set(SplitHost* s, SplitHost::Set& out)
     (void)hipThreadExchangeStreamCaptureMode(&mode);
     hipError_t e = hipMalloc((void**)&out.partials, kSplitScratchDoubles * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&out.counters, kSplitCounters * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&out.zt, s->zt_doubles * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&out.yt, s->zt_doubles * sizeof(double));
+    // zt / yt (2 x 1024 chains x 16 NB rows: 16 MiB each at N = 1024) only when a gradient call needs them: scratch_for(.., grad)
     if (e == hipSuccess) e = hipMemsetAsync(out.counters, 0, kSplitCounters * sizeof(unsigned), s->init_stream);
     if (e == hipSuccess) {                                 // every slot starts as "no partial sum yet"
         static_assert(sizeof(unsigned long long) == sizeof(double), "");
@@ -823,6 +827,7 @@ void split_host_destroy(SplitHost* s)
     };
     for (auto& x : s->spare) free_set(x);
     for (auto& kv : s->assigned) free_set(kv.second);
+    for (auto& x : s->retired) free_set(x);
     if (s->init_stream) (void)hipStreamDestroy(s->init_stream);
     delete s;
 }
@@ -830,13 +835,21 @@ void split_host_destroy(SplitHost* s)
 // The scratch set of a launch on `st`: launches on one stream are ordered, so they share a set; a stream being captured gets
 // a set of the capture's own (the capture id), because the graph may later be replayed on any stream, concurrently with eager
 // launches on the stream it was captured from.
-static hipError_t scratch_for(SplitHost* s, hipStream_t st, SplitHost::Set& out)
+static std::pair<unsigned long long, hipStream_t> scratch_key(hipStream_t st, hipStreamCaptureStatus status, unsigned long long id)
+{
+    if (status == hipStreamCaptureStatusActive) return {id + 1, st};
+    if (st == hipStreamPerThread)                          // distinct streams behind one sentinel value: key them by thread
+        return {0x8000000000000000ull | (unsigned long long)std::hash<std::thread::id>()(std::this_thread::get_id()), st};
+    return {0ull, st};
+}
+
+static hipError_t scratch_for(SplitHost* s, hipStream_t st, bool grad, SplitHost::Set& out)
 {
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
     unsigned long long id = 0;
     if (hipError_t e = hipStreamGetCaptureInfo(st, &status, &id)) return e;
     if (status == hipStreamCaptureStatusInvalidated) return hipErrorStreamCaptureInvalidated;
-    const std::pair<unsigned long long, hipStream_t> key(status == hipStreamCaptureStatusActive ? id + 1 : 0ull, st);
+    const auto key = scratch_key(st, status, id);
     std::lock_guard<std::mutex> lock(s->mu);
     auto it = s->assigned.find(key);
     if (it == s->assigned.end()) {
@@ -849,7 +862,44 @@ static hipError_t scratch_for(SplitHost* s, hipStream_t st, SplitHost::Set& out)
         }
         it = s->assigned.emplace(key, set).first;
     }
+    if (grad && it->second.zt == nullptr) {                // first gradient call on this stream / capture
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        hipError_t e = hipMalloc((void**)&it->second.zt, s->zt_doubles * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&it->second.yt, s->zt_doubles * sizeof(double));
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) return e;
+    }
     out = it->second;
+    return hipSuccess;
+}
+
+// A timing probe (MCD_SPLIT_PROBE) ends the kernel with tickets taken and slots unread: the set is retired, the next launch
+// on the stream draws a clean one.
+static void scratch_retire(SplitHost* s, hipStream_t st)
+{
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(st, &status, &id) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(s->mu);
+    auto it = s->assigned.find(scratch_key(st, status, id));
+    if (it == s->assigned.end()) return;
+    s->retired.push_back(it->second);
+    s->assigned.erase(it);
+}
+
+// mcd_mvn_release_stream: the caller is done with `st` (it is idle or about to be destroyed) -- its eager set goes back to the
+// pool.  The sets of captures stay: a graph instantiated from the capture may still be replayed.
+hipError_t split_release_stream(SplitHost* s, hipStream_t st)
+{
+    if (!s) return hipSuccess;
+    if (hipError_t e = hipStreamSynchronize(st)) return e;  // the last launch's reader has re-poisoned its slots and reset the counter
+    std::lock_guard<std::mutex> lock(s->mu);
+    auto it = s->assigned.find(scratch_key(st, hipStreamCaptureStatusNone, 0));
+    if (it != s->assigned.end()) {
+        s->spare.push_back(it->second);
+        s->assigned.erase(it);
+    }
     return hipSuccess;
 }
 
@@ -879,13 +929,14 @@ static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch,
     const SplitSched& S = s->sched[v];
     if (S.G == 0) return hipErrorInvalidValue;
     SplitHost::Set set;
-    if (hipError_t e = scratch_for(s, st, set)) return e;
+    if (hipError_t e = scratch_for(s, st, MODE == 1, set)) return e;
     const char* env = getenv("MCD_SPLIT_SCATTER");         // tests: a tile's row groups on different XCDs (read per launch)
     int scatter = env ? (atoi(env) & 1) : 0;
     env = getenv("MCD_SPLIT_NOROT");
     if (env && atoi(env)) scatter |= 2;
     env = getenv("MCD_SPLIT_PROBE");                       // timing probes (results are then garbage): 4 launch only, 8 + staging, 16 all but the hand-over
     if (env) scatter |= atoi(env) & 28;
+    const bool probe = (scatter & 28) != 0;
 
     const int64_t tiles = (batch + 15) / 16;
     const unsigned grid = (scatter & 1) ? (unsigned)(tiles * S.G) : (unsigned)(((tiles + 7) / 8) * 8 * S.G);
@@ -923,6 +974,7 @@ static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch,
         }
     }
 #undef MCD_SPLIT_LAUNCH
+    if (probe) scratch_retire(s, st);
     return hipGetLastError();
 }
 

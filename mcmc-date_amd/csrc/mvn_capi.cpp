@@ -314,6 +314,14 @@ int mcd_mvn_set_form(const mcd_mvn_t* h, int form)
     return __atomic_exchange_n(&h->form, form, __ATOMIC_RELAXED);
 }
 
+int mcd_mvn_release_stream(const mcd_mvn_t* h, void* stream)
+{
+    if (!h) return fail(MCD_ERR_INVALID_ARG, "mcd_mvn_release_stream: NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(mcd::split_release_stream(h->split, (hipStream_t)stream));
+    return MCD_OK;
+}
+
 int mcd_mvn_dim(const mcd_mvn_t* h) { return h ? h->n : fail(MCD_ERR_INVALID_ARG, "mcd_mvn_dim: NULL handle"); }
 int mcd_mvn_device(const mcd_mvn_t* h) { return h ? h->device : fail(MCD_ERR_INVALID_ARG, "mcd_mvn_device: NULL handle"); }
 double mcd_mvn_logdet(const mcd_mvn_t* h) { return h ? h->logdet : std::nan(""); }

@@ -148,6 +148,7 @@ constexpr size_t kSplitScratchDoubles = (kSplitMaxBatch / 16) * kSplitMaxG * 16;
 constexpr size_t kSplitCounters = kSplitMaxBatch / 16;
 SplitHost* split_host_create(int n, const double* W_rowmajor, hipError_t* err);   // W = L^-1; tile streams on the current device + scratch pool
 void split_host_destroy(SplitHost* s);
+hipError_t split_release_stream(SplitHost* s, hipStream_t st);   // the stream's eager scratch set back to the pool (mcd_mvn_release_stream)
 bool use_split(const MvnDev& M, int64_t batch);
 hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
 hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+from typing import Optional
 
 import numpy as np
 
@@ -316,23 +317,36 @@ def nuts_warmup(lf: Leapfrog, rng: np.random.Generator, n_windows: int = 3, wind
     return da.final(), inv_mass
 
 
+NUTS_STREAM_DOMAIN = 0x4E5554535F524E47          # "NUTS_RNG": keeps the NUTS streams apart from the Metropolis-Hastings streams of the same seed
+
+
 def run_cycle_with_nuts(sampler, lf: Leapfrog, rng: np.random.Generator, n_iter: int, eps, inv_mass, max_depth: int = 6,
-                        accumulate: bool = False, device: bool = True, seed: int = 0):
+                        accumulate: bool = False, device: bool = True, seed: Optional[int] = None, first_transition: Optional[int] = None,
+                        chain_offset: Optional[int] = None):
     """The reference's `--hamiltonian` mode: the Metropolis-Hastings cycle plus one NUTS proposal per iteration
     (`maybeHamiltonianProposal`, weight 1, app/Definitions.hs:272-274, 104-105 of app/Hamiltonian.hs).  The cycle runs in the lock-step
     driver, the NUTS transition on the device (`device=True`: Leapfrog.nuts, tree building in csrc/k_nuts.hip; False: the
     host-side recursion nuts_transition, kept as the reference implementation of the control flow); the states move between
     the two handles through the host once per iteration (a few KB).  The reference shuffles the NUTS proposal into the
     cycle; here it closes every iteration.
+
+    Random streams of the device transitions: Philox (seed ^ NUTS_STREAM_DOMAIN, chain_offset + b, transition).  `seed`
+    defaults to the sampler's (the domain constant keeps the draws apart from the Metropolis-Hastings draws of the same
+    (chain, step)); `chain_offset` to the sampler's first GLOBAL chain (shards.shard_sampler), so the ranks of a sharded run draw
+    different numbers; `first_transition` to the number of transitions this Leapfrog has already made through this
+    function, so a burn-in call followed by a sampling call does not replay its draws.
     Returns (mean acceptance statistic of the NUTS transitions, mean absolute node ages tH * h_v over chains and
     iterations [n_nodes] or None)."""
+    seed = int(getattr(sampler, "seed", 0) if seed is None else seed) ^ NUTS_STREAM_DOMAIN
+    chain_offset = int(getattr(sampler, "first_chain", 0) if chain_offset is None else chain_offset)
+    t0 = int(getattr(lf, "cycle_transitions_done", 0) if first_transition is None else first_transition)
     alphas = []
     ages = np.zeros(lf.topo.n_nodes) if accumulate else None
     for it in range(n_iter):
         sampler.run(1)
         lf.set_state(sampler.state())
         if device:
-            alpha, _ = lf.nuts(eps, inv_mass, max_depth=max_depth, seed=seed, transition=it)
+            alpha, _ = lf.nuts(eps, inv_mass, max_depth=max_depth, seed=seed, transition=t0 + it, chain_offset=chain_offset)
         else:
             alpha, _ = nuts_transition(lf, rng, eps, inv_mass, max_depth=max_depth)
         alphas.append(alpha.mean())
@@ -340,4 +354,5 @@ def run_cycle_with_nuts(sampler, lf: Leapfrog, rng: np.random.Generator, n_iter:
         sampler.set_state(s)
         if accumulate:
             ages += (s.time_height[:, None] * s.heights).mean(axis=0)
+    lf.cycle_transitions_done = t0 + n_iter
     return (float(np.mean(alphas)) if alphas else float("nan")), (ages / max(1, n_iter) if accumulate else None)

@@ -216,6 +216,12 @@ class MvnLikelihood:
         except Exception:
             pass
 
+    def release_stream(self, stream) -> None:
+        """mcd_mvn_release_stream: the scratch set the row-split kernels keep for `stream` (a torch.cuda.Stream or a raw
+        hipStream_t value) goes back to the handle's pool; call it before destroying a short-lived stream."""
+        raw = getattr(stream, "cuda_stream", stream)
+        _capi.check(_capi.lib().mcd_mvn_release_stream(self._h, C.c_void_p(int(raw) if raw else 0)))
+
     def set_form(self, form: str) -> str:
         """Pin the form of the log-density kernels for THIS handle ("auto": follow the process default, "sweep",
         "multiply"); mcd_mvn_set_form.  Returns the previous choice."""

@@ -211,6 +211,8 @@ class Sampler:
         self.table = list(table)
         self.topo: Topology = tree_lik.topo
         self.batch = int(batch)
+        self.seed = int(seed)
+        self.first_chain = int(first_chain)        # global index of chain 0 (shards.shard_sampler): the random-stream id
         self._keep = (tree_lik, prior)
         self._h = C.c_void_p()
         a = table_arrays(self.table)

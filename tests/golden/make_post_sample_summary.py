@@ -39,6 +39,8 @@ def main():
         "command": "./run -s -f analysis.conf -c ul s r   (calibrations, UncorrelatedLogNormal, SparseMultivariateNormal 0.1)",
         "nodes": nodes, "rows_per_run": [int(r.shape[0]) for r in runs], "pooled": stats(allr), "runs": [stats(r) for r in runs],
         "between_run_sd_of_mean": run_means.std(axis=0, ddof=1).tolist(),
+        "correlation": np.corrcoef(allr.T).tolist(),
+        "root_age_max_per_run": [float(r[:, 0].max()) for r in runs],
     }
     with open(os.path.join(HERE, "mtCDNApri_post_samples.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -166,6 +166,17 @@ def test_device_nuts_follows_the_cpu_twin(gpu, golden):
         assert np.max(np.abs(val - lp_after) / np.maximum(1.0, np.abs(val))) <= 1e-10
         assert np.max(np.abs(grad - g_after)) <= 1e-8 * np.max(np.abs(grad))
     assert len(set(depth.tolist())) >= 1 and depth.max() <= max_depth and depth.min() >= 1
+    # a plain leapfrog call may follow a transition directly: its first half kick takes the gradient of the ACCEPTED point, not
+    # of the last leaf the tree evaluated (round-2 advisor finding) -- same momenta and end point as after an explicit set_state
+    p0 = np.random.default_rng(5).normal(size=(B, lf.dim)) / np.sqrt(inv_mass)
+    lf2 = M.Leapfrog(lik, pf, True, B)
+    lf2.set_state(lf.state())                                            # the accepted points, gradients evaluated afresh
+    assert np.max(np.abs(lf2.position()[0] - q_after)) <= 1e-12 * np.max(np.abs(q_after))
+    p_direct = lf.leapfrog(p0, 0.01, inv_mass, 2)
+    q_direct = lf.position()[0]
+    p_ref = lf2.leapfrog(p0, 0.01, inv_mass, 2)
+    assert np.all(np.isfinite(p_direct)) and np.array_equal(p_direct, p_ref)
+    assert np.array_equal(q_direct, lf2.position()[0])
 
 
 @pytest.mark.parametrize("name,B", [("12-leaves-variable-rate", 64), ("24-leaves-braces", 128)])
