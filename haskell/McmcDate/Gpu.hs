@@ -28,6 +28,11 @@ module McmcDate.Gpu
     c_mh_tune,
     c_mh_get_state,
     c_mh_get_age_sums,
+    c_mh_last_path,
+    c_mh_mc3_init,
+    c_mh_mc3_swap,
+    c_mh_mc3_get,
+    c_hmc_nuts_warmup,
     -- * Form selection and the sharding exchange (raw bindings)
     c_set_logpdf_form,
     c_mvn_set_form,
@@ -214,6 +219,24 @@ foreign import ccall unsafe "mcd_mh_get_state"
 foreign import ccall unsafe "mcd_mh_get_age_sums"
   c_mh_get_age_sums :: Ptr McdMh -> Ptr CDouble -> Ptr CDouble -> Ptr Int64 -> IO CInt
 
+-- | Which launch structure the last 'c_mh_run' took (MCD_MH_PATH_*), for logs.
+foreign import ccall unsafe "mcd_mh_last_path"
+  c_mh_last_path :: Ptr McdMh -> IO CInt
+
+-- | The swap phase of @mc3 (MC3Settings (NChains n) (SwapPeriod p) (NSwaps k))@ (app/Main.hs:476-478) on the device: init once
+-- (n, ladder of reciprocal temperatures, global number of chains, seed); per period 'c_mh_run' for p iterations, then
+-- 'c_mh_mc3_swap' with k (gathered = nullPtr on one GPU; with chains sharded over GPUs the buffer 'c_shard_allgather' made of the
+-- ranks' 'c_mh_posterior_device' arrays, with the number of ranks and the chains per rank).  Monitors read the chains of rank 0
+-- from 'c_mh_mc3_get'.
+foreign import ccall unsafe "mcd_mh_mc3_init"
+  c_mh_mc3_init :: Ptr McdMh -> CInt -> Ptr CDouble -> Int64 -> Word64 -> IO CInt
+
+foreign import ccall unsafe "mcd_mh_mc3_swap"
+  c_mh_mc3_swap :: Ptr McdMh -> CInt -> Ptr CDouble -> CInt -> Int64 -> IO CInt
+
+foreign import ccall unsafe "mcd_mh_mc3_get"
+  c_mh_mc3_get :: Ptr McdMh -> Ptr Int32 -> Ptr Int64 -> Ptr Int64 -> Ptr CDouble -> IO CInt
+
 -- The Hamiltonian proposal (`nutsWith`, app/Hamiltonian.hs:95-105) for B chains: state in, n NUTS transitions on the device
 -- with dual averaging of the step sizes (adapt /= 0), state out.  Position layout and mask as `hstructWith` (:62-70).
 data McdHmc
@@ -242,3 +265,10 @@ foreign import ccall safe "mcd_hmc_nuts_run"
   c_hmc_nuts_run ::
     Ptr McdHmc -> CInt -> CInt -> Ptr CDouble -> Ptr CDouble -> CDouble -> CInt -> Word64 -> Int64 -> Word64 -> Ptr CDouble -> Ptr CDouble ->
     Ptr CDouble -> IO CInt
+
+-- | @HTuningConf HTuneLeapfrog HTuneAllMasses@ (app/Hamiltonian.hs:62-63) in the library: windows, transitions per window, step
+-- sizes [batch] (in/out), inverse masses [dim] (in/out), delta, maximal depth, seed, global index of chain 0, first transition;
+-- out: mean acceptance statistic of the closing window [batch] (may be null).
+foreign import ccall safe "mcd_hmc_nuts_warmup"
+  c_hmc_nuts_warmup ::
+    Ptr McdHmc -> CInt -> CInt -> Ptr CDouble -> Ptr CDouble -> CDouble -> CInt -> Word64 -> Int64 -> Word64 -> Ptr CDouble -> IO CInt

@@ -257,6 +257,12 @@ int mcd_hmc_nuts(mcd_hmc_t* m, const double* eps, const double* inv_mass, int ma
                  uint64_t transition, double* alpha, int32_t* depth);
 int mcd_hmc_nuts_run(mcd_hmc_t* m, int n_transitions, int adapt, double* eps, const double* inv_mass, double delta, int max_depth,
                      uint64_t seed, int64_t chain_offset, uint64_t first_transition, double* mean_alpha, double* q_mean, double* q_var);
+/* Step sizes AND masses (`HTuneLeapfrog HTuneAllMasses`, app/Hamiltonian.hs:62-63): `windows` windows of `window` transitions --
+ * dual averaging of eps[batch] inside a window, then inv_mass[dim] := pooled variance of the positions the window visited
+ * (shrunk towards 1e-3) -- and a closing window for the step sizes; uses the transitions first_transition ..
+ * first_transition + (windows + 1) window - 1 of the random streams.  eps, inv_mass: in = starting values, out = tuned. */
+int mcd_hmc_nuts_warmup(mcd_hmc_t* m, int windows, int window, double* eps, double* inv_mass, double delta, int max_depth, uint64_t seed,
+                        int64_t chain_offset, uint64_t first_transition, double* mean_alpha);
 /* One leapfrog step from ARBITRARY phase points (what a NUTS tree needs: it extends either end of a trajectory):
  * q, p, grad [batch][dim] in/out (host), value [batch] out (ln target at the new point, may be NULL).  have_grad = 0:
  * the gradient at q is evaluated first (grad is output only).  The handle's own state becomes the new point. */
@@ -319,7 +325,7 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  * n_iter iterations of steps_per_iter proposals; schedule[n_iter * steps_per_iter] = proposal row per step (host).
  * accumulate != 0: after every iteration add the absolute node ages tH * h_v to the running sums.
  * trace_alpha / trace_accept (host, may be NULL): [n_iter * steps_per_iter][batch] ln acceptance ratio / decision.
- * Trees of at most 64 nodes: the whole schedule in one launch, the factor of Sigma in LDS; up to 320 nodes and 1024 chains: the
+ * Trees of at most 64 nodes: the whole schedule in one launch, the factor of Sigma in LDS; up to 258 nodes (N <= 256) and 1024 chains: the
  * same with the factor streamed through LDS once per step.  Larger trees or batches: two launches per step -- accept the pending
  * proposal and propose the next one; then ln likelihood of the proposed states, which up to 256 dimensions also carries their ln
  * prior as workgroups of a second role (both depend on the proposal only).  Environment, read per call, for tests and timing:
@@ -329,6 +335,14 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  */
 int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t steps_per_iter, int accumulate,
                double* trace_alpha, int8_t* trace_accept);
+/* Which launch structure the last mcd_mh_run took (reporting: bench.py, tests). */
+#define MCD_MH_PATH_NONE 0
+#define MCD_MH_PATH_CHAIN_LDS 1               /* whole schedule in one launch, factor resident in LDS (<= 64 nodes) */
+#define MCD_MH_PATH_CHAIN_STREAMED 2          /* whole schedule in one launch, factor streamed once per step (k_mh_chain_big) */
+#define MCD_MH_PATH_TWO_LAUNCH_PRIOR_BESIDE 3 /* step + likelihood launch that also carries the ln prior of the proposal */
+#define MCD_MH_PATH_TWO_LAUNCH 4              /* step (prior inside) + likelihood launch */
+#define MCD_MH_PATH_STEP_WG_X 5               /* workgroup-per-chain step leaving distances + plain-vector likelihood launch */
+int mcd_mh_last_path(const mcd_mh_t* m);
 /* Auto tuning at the end of a tuning period [mcmc]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3). */
 int mcd_mh_tune(mcd_mh_t* m);
 /* tune: [batch][n_prop]; accepted / tried: counters since the last mcd_mh_tune / mcd_mh_reset_counters. */
@@ -336,9 +350,28 @@ int mcd_mh_get_tuning(const mcd_mh_t* m, double* tune, int32_t* accepted, int32_
 int mcd_mh_set_tuning(mcd_mh_t* m, const double* tune);
 int mcd_mh_reset_counters(mcd_mh_t* m);
 /* Reciprocal temperatures beta[batch] in (0, 1] (default 1): chain b accepts with (prior x likelihood)^beta[b], the
- * heated chains of Metropolis-coupled MCMC (`mc3`, app/Main.hs:476-478; package `mcmc`).  The swap step is the caller's
- * (mcmc_date_amd.sampler.MC3): it only needs mcd_mh_get_posterior and this call. */
+ * heated chains of Metropolis-coupled MCMC (`mc3`, app/Main.hs:476-478; package `mcmc`). */
 int mcd_mh_set_temperatures(mcd_mh_t* m, const double* beta);
+/*
+ * The swap phase of Metropolis-coupled MCMC on the device.  Replaces: the swap bookkeeping of `mc3 (MC3Settings (NChains 4)
+ * (SwapPeriod 2) (NSwaps 3))`, app/Main.hs:476-478 (package `mcmc`; its initial ladder and ladder tuning are not restated).
+ *   mcd_mh_mc3_init   groups of n_chains consecutive GLOBAL chains (total_chains of them over all GPUs, a multiple of n_chains;
+ *                     this handle holds [first_chain, first_chain + batch), mcd_mh_set_chain_offset), ladder betas[n_chains]
+ *                     (betas[0] = 1, decreasing); chain c starts with rank c mod n_chains; sets this handle's temperatures.
+ *   mcd_mh_mc3_swap   one phase: in every group n_swaps distinct adjacent rank pairs, in random order, exchange their
+ *                     TEMPERATURES with probability min(1, exp((beta_i - beta_j)(ln pi_j - ln pi_i))), pi = prior x likelihood
+ *                     (the states stay where they are: the same Markov chain, 8 bytes per chain on the wire).  gathered =
+ *                     device pointer [world][3][chains_per_rank], what mcd_shard_allgather makes of the ranks'
+ *                     mcd_mh_posterior_device arrays; NULL when the handle holds every chain.  Every rank evaluates all
+ *                     groups from the gathered values with Philox numbers keyed (seed, group, phase): all ranks hold the same
+ *                     table and the run does not depend on the number of GPUs.  Enqueued on the sampler's stream.
+ *   mcd_mh_mc3_get    rank[total_chains], swap counters tried / accepted[n_chains - 1] per rung, beta[batch] (any may be NULL).
+ * One period of the reference's loop = mcd_mh_run (SwapPeriod iterations) -> mcd_shard_allgather of the posterior on the
+ * sampler's stream -> mcd_mh_mc3_swap; monitors read the chains whose rank is 0.
+ */
+int mcd_mh_mc3_init(mcd_mh_t* m, int n_chains, const double* betas, int64_t total_chains, uint64_t seed);
+int mcd_mh_mc3_swap(mcd_mh_t* m, int n_swaps, const double* gathered, int world, int64_t chains_per_rank);
+int mcd_mh_mc3_get(const mcd_mh_t* m, int32_t* rank, int64_t* tried, int64_t* accepted, double* beta);
 /* age_sum / age_sq: [batch][n_nodes] running sums over *n_samples accumulated iterations; reset with the call below. */
 int mcd_mh_get_age_sums(const mcd_mh_t* m, double* age_sum, double* age_sq, int64_t* n_samples);
 int mcd_mh_reset_age_sums(mcd_mh_t* m);

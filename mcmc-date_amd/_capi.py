@@ -70,6 +70,7 @@ SYMBOLS = {
     "mcd_mh_posterior_device": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "mcd_hmc_nuts": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp, _ip]),
     "mcd_hmc_nuts_run": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp, _dp, _dp]),
+    "mcd_hmc_nuts_warmup": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp]),
     "mcd_mh_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
     "mcd_mh_destroy": (None, [_vp]),
     "mcd_mh_set_chain_offset": (C.c_int, [_vp, C.c_int64]),
@@ -82,6 +83,10 @@ SYMBOLS = {
     "mcd_mh_set_tuning": (C.c_int, [_vp, _dp]),
     "mcd_mh_reset_counters": (C.c_int, [_vp]),
     "mcd_mh_set_temperatures": (C.c_int, [_vp, _dp]),
+    "mcd_mh_last_path": (C.c_int, [_vp]),
+    "mcd_mh_mc3_init": (C.c_int, [_vp, C.c_int, _dp, C.c_int64, C.c_uint64]),
+    "mcd_mh_mc3_swap": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int64]),
+    "mcd_mh_mc3_get": (C.c_int, [_vp, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp]),
     "mcd_mh_get_age_sums": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64)]),
     "mcd_mh_reset_age_sums": (C.c_int, [_vp]),
 }

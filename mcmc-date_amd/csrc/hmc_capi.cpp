@@ -409,4 +409,30 @@ int mcd_hmc_nuts_run(mcd_hmc_t* m, int n_transitions, int adapt, double* eps, co
     return MCD_OK;
 }
 
+// Step sizes AND masses: the reference tunes both (`HTuningConf HTuneLeapfrog HTuneAllMasses`, app/Hamiltonian.hs:62-63; the
+// schedule of the package `mcmc` is not restated).  `windows` windows of `window` transitions: dual averaging of the step sizes
+// inside a window (mcd_hmc_nuts_run, adapt = 1), then the inverse masses become the pooled variance of the positions the
+// window visited, shrunk towards 1e-3 (Stan's regularisation); a closing window adapts the step sizes to the final masses.
+int mcd_hmc_nuts_warmup(mcd_hmc_t* m, int windows, int window, double* eps, double* inv_mass, double delta, int max_depth, uint64_t seed,
+                        int64_t chain_offset, uint64_t first_transition, double* mean_alpha)
+{
+    if (!m || !eps || !inv_mass) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts_warmup: NULL argument");
+    if (windows < 0 || window < 1) return hfail(MCD_ERR_INVALID_ARG, "mcd_hmc_nuts_warmup: need windows >= 0 and window >= 1");
+    const size_t B = (size_t)m->dev.batch, dim = (size_t)m->dev.dim;
+    std::vector<double> qv(dim), alpha(B);
+    uint64_t t = first_transition;
+    for (int w = 0; w < windows; ++w) {
+        if (int rc = mcd_hmc_nuts_run(m, window, 1, eps, inv_mass, delta, max_depth, seed, chain_offset, t, alpha.data(), nullptr, qv.data())) return rc;
+        t += (uint64_t)window;
+        const double n_eff = (double)B * (double)window;
+        for (size_t k = 0; k < dim; ++k) {
+            const double v = (n_eff / (n_eff + 5.0)) * qv[k] + 1e-3 * (5.0 / (n_eff + 5.0));
+            inv_mass[k] = (v > 0 && std::isfinite(v)) ? v : inv_mass[k];      // a chain outside the support leaves NaN positions: keep the mass
+        }
+    }
+    if (int rc = mcd_hmc_nuts_run(m, window, 1, eps, inv_mass, delta, max_depth, seed, chain_offset, t, alpha.data(), nullptr, nullptr)) return rc;
+    if (mean_alpha) std::copy(alpha.begin(), alpha.end(), mean_alpha);
+    return MCD_OK;
+}
+
 }  // extern "C"

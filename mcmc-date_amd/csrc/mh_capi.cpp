@@ -56,6 +56,10 @@ struct mcd_mh {
     double* d_trace_alpha = nullptr;
     int8_t* d_trace_accept = nullptr;
     size_t trace_cap = 0;
+    int last_path = MCD_MH_PATH_NONE;   // which launch structure the last mcd_mh_run took
+    // Metropolis-coupled MCMC (mcd_mh_mc3_*): temperature ranks of all GLOBAL chains, ladder, counters; phase = swap phases done
+    mcd::Mc3Dev mc3{};
+    uint64_t mc3_seed = 0, mc3_phase = 0;
 
     ~mcd_mh()
     {
@@ -315,6 +319,80 @@ int mcd_mh_posterior_device(const mcd_mh_t* cm, const double** post, void** stre
     return MCD_OK;
 }
 
+int mcd_mh_last_path(const mcd_mh_t* m) { return m ? m->last_path : mfail(MCD_ERR_INVALID_ARG, "mcd_mh_last_path: NULL handle"); }
+
+// ---- Metropolis-coupled MCMC: the swap phase (k_mc3.hip) -----------------------------------------------------------------
+int mcd_mh_mc3_init(mcd_mh_t* m, int n_chains, const double* betas, int64_t total_chains, uint64_t seed)
+{
+    if (!m || !betas) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_init: NULL argument");
+    const mcd::MhDev& D = m->dev;
+    if (n_chains < 2 || n_chains > 16) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_init: n_chains must be 2 .. 16");
+    if (total_chains <= 0 || total_chains % n_chains != 0)
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_init: the global number of chains must be a multiple of n_chains");
+    if (D.chain0 < 0 || D.chain0 + D.batch > total_chains) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_init: this handle's chains [%lld, %lld) lie outside 0 .. total_chains", (long long)D.chain0, (long long)(D.chain0 + D.batch));
+    if (betas[0] != 1.0) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_init: betas[0] must be 1 (the cold chain)");
+    for (int i = 1; i < n_chains; ++i)
+        if (!(betas[i] > 0) || !(betas[i] < betas[i - 1])) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_init: betas must decrease and stay positive");
+    MHIP_TRY(hipSetDevice(m->device));
+    MHIP_TRY(hipStreamSynchronize(m->stream));
+    mcd::Mc3Dev& C = m->mc3;
+    double* ladder = nullptr;
+    if (int rc = dev_alloc(m, &ladder, (size_t)n_chains, false)) return rc;
+    if (int rc = dev_alloc(m, &C.rank, (size_t)total_chains, false)) return rc;
+    if (int rc = dev_alloc(m, &C.tried, (size_t)n_chains, true)) return rc;
+    if (int rc = dev_alloc(m, &C.accepted, (size_t)n_chains, true)) return rc;
+    C.ladder = ladder;
+    C.n_chains = n_chains;
+    C.total = total_chains;
+    std::vector<int32_t> rank((size_t)total_chains);
+    std::vector<double> beta((size_t)D.batch);
+    for (int64_t c = 0; c < total_chains; ++c) rank[(size_t)c] = (int32_t)(c % n_chains);
+    for (int64_t b = 0; b < D.batch; ++b) beta[(size_t)b] = betas[(D.chain0 + b) % n_chains];
+    MHIP_TRY(hipMemcpy(ladder, betas, sizeof(double) * (size_t)n_chains, hipMemcpyHostToDevice));
+    MHIP_TRY(hipMemcpy(C.rank, rank.data(), sizeof(int32_t) * rank.size(), hipMemcpyHostToDevice));
+    MHIP_TRY(hipMemcpy(D.beta, beta.data(), sizeof(double) * beta.size(), hipMemcpyHostToDevice));
+    m->mc3_seed = seed;
+    m->mc3_phase = 0;
+    return MCD_OK;
+}
+
+int mcd_mh_mc3_swap(mcd_mh_t* m, int n_swaps, const double* gathered, int world, int64_t chains_per_rank)
+{
+    if (!m) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: NULL handle");
+    const mcd::MhDev& D = m->dev;
+    const mcd::Mc3Dev& C = m->mc3;
+    if (C.n_chains == 0) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: call mcd_mh_mc3_init first");
+    if (n_swaps < 1 || n_swaps > C.n_chains - 1) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: need 1 <= n_swaps <= n_chains - 1");
+    if (gathered == nullptr) {                           // one rank: the sampler's own [3][batch]
+        if (C.total != D.batch || D.chain0 != 0) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: a handle that holds a shard of the chains needs the gathered ln posteriors");
+        gathered = D.post;
+        world = 1;
+        chains_per_rank = D.batch;
+    } else if (world < 1 || chains_per_rank < 1 || (int64_t)world * chains_per_rank < C.total) {
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: world x chains_per_rank does not cover the global chains");
+    }
+    MHIP_TRY(hipSetDevice(m->device));
+    // enqueued on the sampler's stream, behind the run and the all-gather that produced `gathered`: no host synchronisation
+    MHIP_TRY(mcd::launch_mc3_swap(C, gathered, world, chains_per_rank, n_swaps, m->mc3_seed, m->mc3_phase, D.beta, D.chain0, D.batch, m->stream));
+    m->mc3_phase += 1;
+    return MCD_OK;
+}
+
+int mcd_mh_mc3_get(const mcd_mh_t* cm, int32_t* rank, int64_t* tried, int64_t* accepted, double* beta)
+{
+    if (!cm) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_get: NULL handle");
+    const mcd::Mc3Dev& C = cm->mc3;
+    if (C.n_chains == 0) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_get: call mcd_mh_mc3_init first");
+    MHIP_TRY(hipSetDevice(cm->device));
+    MHIP_TRY(hipStreamSynchronize(cm->stream));
+    if (rank) MHIP_TRY(hipMemcpy(rank, C.rank, sizeof(int32_t) * (size_t)C.total, hipMemcpyDeviceToHost));
+    static_assert(sizeof(unsigned long long) == sizeof(int64_t), "");
+    if (tried) MHIP_TRY(hipMemcpy(tried, C.tried, sizeof(int64_t) * (size_t)(C.n_chains - 1), hipMemcpyDeviceToHost));
+    if (accepted) MHIP_TRY(hipMemcpy(accepted, C.accepted, sizeof(int64_t) * (size_t)(C.n_chains - 1), hipMemcpyDeviceToHost));
+    if (beta) MHIP_TRY(hipMemcpy(beta, cm->dev.beta, sizeof(double) * (size_t)cm->dev.batch, hipMemcpyDeviceToHost));
+    return MCD_OK;
+}
+
 int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, int accumulate, double* trace_alpha,
                int8_t* trace_accept)
 {
@@ -348,6 +426,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         m->trace_cap = steps * B;
     }
     if (m->chain_kernel) {
+        m->last_path = MCD_MH_PATH_CHAIN_LDS;
         MHIP_TRY(mcd::launch_mh_chain(D, *m->mvn, *m->tree, *m->prior, m->d_Fp, m->d_sched, (int64_t)steps, S, accumulate, m->step, m->seed,
                                       trace ? m->d_trace_alpha : nullptr, trace ? m->d_trace_accept : nullptr, m->stream));
         m->step += steps;
@@ -359,6 +438,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
     const bool streaming = !m->chain_kernel && !(per_phase_env && per_phase_env[0] == '1') && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
                            mcd::mh_chain_big_available(D, *m->mvn);
     if (streaming) {
+        m->last_path = MCD_MH_PATH_CHAIN_STREAMED;
         // (launches of at most ~64 k steps, whole iterations each: a second or so of kernel time; what a launch costs -- the chains'
         // state in, out again -- is some 20 us)
         const int64_t per_launch = (int64_t)S * (65536 / S > 0 ? 65536 / S : 1);
@@ -404,6 +484,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
             MHIP_TRY(hipMalloc((void**)&m->d_X1, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
             m->allocs.push_back(m->d_X1);
         }
+        m->last_path = use_x ? MCD_MH_PATH_STEP_WG_X : beside ? MCD_MH_PATH_TWO_LAUNCH_PRIOR_BESIDE : MCD_MH_PATH_TWO_LAUNCH;
         const mcd::TreeDev* Tx = use_x ? m->tree : nullptr;
         double* X1 = use_x ? m->d_X1 : nullptr;
         MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr,

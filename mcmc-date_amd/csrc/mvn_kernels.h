@@ -95,6 +95,16 @@ struct MhDev {
     int32_t* pflags;           // [batch] which blocks of the ln prior the pending proposal moved (bit 0 nodes, 1 birth-death, 2 clock)
 };
 
+// Metropolis-coupled MCMC (k_mc3.hip): the temperature rank of every GLOBAL chain, the ladder of reciprocal temperatures and the
+// swap counters per rung; all pointers are device memory.
+struct Mc3Dev {
+    int n_chains;                           // chains per group (NChains)
+    int64_t total;                          // global number of chains (a multiple of n_chains)
+    const double* ladder;                   // [n_chains] reciprocal temperatures, ladder[0] = 1
+    int32_t* rank;                          // [total] temperature rank of every global chain
+    unsigned long long *tried, *accepted;   // [n_chains - 1] swaps between the ranks i and i + 1
+};
+
 // Workspace of the device leapfrog (k_hmc.hip); all pointers are device memory.
 struct HmcDev {
     int n_nodes, dim, root_right;
@@ -202,6 +212,8 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
 // (T, n_dim, X1 given) for a plain-vector likelihood launch
 bool mh_step_wg_active(const MhDev& M, int prior_inline);
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
+hipError_t launch_mc3_swap(const Mc3Dev& C, const double* lnpost, int world, int64_t per_rank, int n_swaps, uint64_t seed, uint64_t phase,
+                           double* beta_local, int64_t chain0, int64_t batch, hipStream_t st);
 // ln prior of the proposed states from pflags / pcomp (what launch_mh_step leaves when asked not to evaluate it itself) as extra
 // workgroups of the sweep's tree-likelihood launch (k_tree_logpdf.hip): the ln prior and the ln likelihood of a proposal depend
 // on nothing but the proposal

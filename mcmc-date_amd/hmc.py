@@ -117,6 +117,17 @@ class Leapfrog:
                                                  int(seed), int(chain_offset), int(first_transition), _p(ma), _p(qm), _p(qv)))
         return eps, ma, qm, qv
 
+    def nuts_warmup(self, eps, inv_mass, windows: int = 3, window: int = 60, delta: float = 0.65, max_depth: int = 6, seed: int = 0,
+                    first_transition: int = 0, chain_offset: int = 0):
+        """Step sizes and diagonal masses tuned in the library (mcd_hmc_nuts_warmup: `HTuneLeapfrog HTuneAllMasses`,
+        app/Hamiltonian.hs:62-63).  Returns (eps [B], inv_mass [dim], mean acceptance statistic of the closing window [B])."""
+        eps = np.array(np.broadcast_to(np.asarray(eps, np.float64), (self.batch,)), dtype=np.float64, order="C")
+        inv_mass = np.array(np.broadcast_to(np.asarray(inv_mass, np.float64), (self.dim,)), dtype=np.float64, order="C")
+        ma = np.empty(self.batch)
+        _capi.check(_capi.lib().mcd_hmc_nuts_warmup(self._h, int(windows), int(window), _p(eps), _p(inv_mass), float(delta), int(max_depth), int(seed),
+                                                    int(chain_offset), int(first_transition), _p(ma)))
+        return eps, inv_mass, ma
+
     def step_from(self, q, p, grad, eps, inv_mass, direction=None, have_grad=True):
         """One leapfrog step from the given phase points (all [B, dim]); returns (q', p', grad', ln target')."""
         q = np.array(q, dtype=np.float64, order="C")

@@ -414,6 +414,19 @@ public:
         return post;
     }
     int stepsPerIteration() const { return stepsPerIteration_; }
+    int lastPath() const { return mcd_mh_last_path(mh_.get()); }   // MCD_MH_PATH_*
+    // Metropolis-coupled MCMC: `mc3 (MC3Settings (NChains n) (SwapPeriod p) (NSwaps k))`, app/Main.hs:476-478.  mc3Init once; then
+    // per period run(p iterations) + mc3Swap(k).  A host that shards the chains over GPUs passes the all-gathered ln posteriors
+    // (mcd_shard_allgather of mcd_mh_posterior_device) to the three-argument form.
+    void mc3Init(int nChains, const Vec& betas, uint64_t seed) { detail::check(mcd_mh_mc3_init(mh_.get(), nChains, betas.data(), batch_, seed)); }
+    void mc3Swap(int nSwaps) { detail::check(mcd_mh_mc3_swap(mh_.get(), nSwaps, nullptr, 1, batch_)); }
+    void mc3Swap(int nSwaps, const double* gatheredDevice, int world) { detail::check(mcd_mh_mc3_swap(mh_.get(), nSwaps, gatheredDevice, world, batch_)); }
+    std::vector<int32_t> mc3Ranks() const
+    {
+        std::vector<int32_t> r((size_t)batch_);
+        detail::check(mcd_mh_mc3_get(mh_.get(), r.data(), nullptr, nullptr, nullptr));
+        return r;
+    }
 
 private:
     Topology topo_;
@@ -459,19 +472,13 @@ public:
             invMass_[k] = a * a > 1e-12 ? a * a : 1e-12;
         }
     }
-    // step sizes by dual averaging (Hoffman & Gelman 2014, Algorithm 6), masses = pooled position variances of a window
+    // step sizes by dual averaging (Hoffman & Gelman 2014, Algorithm 6), masses = pooled position variances of a window:
+    // `HTuningConf HTuneLeapfrog HTuneAllMasses` (app/Hamiltonian.hs:62-63), in the library (mcd_hmc_nuts_warmup)
     void warmup(int windows = 3, int window = 60, double delta = 0.65, int maxDepth = 6)
     {
-        Vec alpha((size_t)batch_), qm((size_t)dim_), qv((size_t)dim_);
-        for (int w = 0; w < windows; ++w) {
-            detail::check(mcd_hmc_nuts_run(h_.get(), window, 1, eps_.data(), invMass_.data(), delta, maxDepth, seed_, 0, transition_, alpha.data(),
-                                           qm.data(), qv.data()));
-            transition_ += (uint64_t)window;
-            const double nEff = (double)batch_ * window;
-            for (int k = 0; k < dim_; ++k) invMass_[k] = (nEff / (nEff + 5.0)) * qv[k] + 1e-3 * (5.0 / (nEff + 5.0));
-        }
-        detail::check(mcd_hmc_nuts_run(h_.get(), window, 1, eps_.data(), invMass_.data(), delta, maxDepth, seed_, 0, transition_, alpha.data(), nullptr, nullptr));
-        transition_ += (uint64_t)window;
+        Vec alpha((size_t)batch_);
+        detail::check(mcd_hmc_nuts_warmup(h_.get(), windows, window, eps_.data(), invMass_.data(), delta, maxDepth, seed_, 0, transition_, alpha.data()));
+        transition_ += (uint64_t)(windows + 1) * (uint64_t)window;
     }
     // n transitions with the tuned step sizes and masses; returns the mean acceptance statistic per chain
     Vec run(int n, int maxDepth = 6)

@@ -288,6 +288,10 @@ class Sampler:
             self.run_schedule(cycle_schedule(self.table, k, self._sched_rng), accumulate=accumulate)
             done += k
 
+    def last_path(self) -> str:
+        """Which launch structure the last run took (mcd_mh_last_path; PATHS)."""
+        return PATHS.get(int(_capi.lib().mcd_mh_last_path(self._h)), "unknown")
+
     def autotune(self):
         _capi.check(_capi.lib().mcd_mh_tune(self._h))
 
@@ -348,56 +352,154 @@ class Sampler:
 
 
 # ---- Metropolis-coupled MCMC -- `mc3 (MC3Settings (NChains 4) (SwapPeriod 2) (NSwaps 3))`, app/Main.hs:476-478 -----------
+MC3_STREAM_DOMAIN = 0x4D43335F53574150          # "MC3_SWAP": keeps the swap draws apart from the proposal draws of the same seed
+PATHS = {0: "none", 1: "whole schedule in one launch, factor resident in LDS", 2: "whole schedule in one launch, two chains per workgroup, the factor streamed once per step",
+         3: "two launches per lock step, the ln prior of the proposal beside its likelihood", 4: "two launches per lock step (prior inside the step kernel)",
+         5: "two launches per lock step: workgroup-per-chain step kernel leaving distances + plain-vector likelihood"}
+
+
+def philox4x32(counter, key):
+    """Philox4x32-10 (Salmon et al. 2011), the generator of csrc/mh_device.hpp: philox_block, restated on Python integers for the
+    host-side mirror of the swap phase (a dozen draws per group and phase)."""
+    c0, c1, c2, c3 = (int(x) & 0xFFFFFFFF for x in counter)
+    k0, k1 = (int(x) & 0xFFFFFFFF for x in key)
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def uniform_pair(seed: int, chain: int, step: int, draw: int):
+    """The two uniforms of draw `draw` in the stream (seed, chain, step): counter = (draw, chain, step lo, step hi), key = seed."""
+    x = philox4x32((draw, chain, step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF), (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    return ((((x[0] << 32) | x[1]) >> 11) + 0.5) * 2.0 ** -53, ((((x[2] << 32) | x[3]) >> 11) + 0.5) * 2.0 ** -53
+
+
+def mc3_swap_host(rank: np.ndarray, lnpi: np.ndarray, ladder: np.ndarray, n_swaps: int, seed: int, phase: int, tried=None, accepted=None):
+    """One swap phase over ALL global chains on the host -- the arithmetic of csrc/k_mc3.hip: k_mc3_swap on the same counter-based
+    draws (used where no device is involved: the CPU rehearsals of the sharded loop, and as the check of the device kernel).
+    rank [total] int (modified in place), lnpi [total] = ln prior + ln likelihood."""
+    n = len(ladder)
+    for g in range(len(rank) // n):
+        base = g * n
+        rk = rank[base:base + n]
+        at = np.empty(n, np.int64)
+        at[rk] = np.arange(n)
+        pairs = list(range(n - 1))
+        for j in range(n_swaps):
+            ua, ub = uniform_pair(seed, g, phase, j)
+            idx = min(j + int(ua * (n - 1 - j)), n - 2)
+            i = pairs[idx]
+            pairs[idx] = pairs[j]
+            pairs[j] = i
+            a, c = at[i], at[i + 1]
+            log_r = (ladder[i] - ladder[i + 1]) * (lnpi[base + c] - lnpi[base + a])
+            if tried is not None:
+                tried[i] += 1
+            if math.log(ub) < log_r:                                    # NaN compares false: no swap
+                rk[a], rk[c] = i + 1, i
+                at[i], at[i + 1] = c, a
+                if accepted is not None:
+                    accepted[i] += 1
+    return rank
+
+
 class MC3:
-    """Metropolis-coupled MCMC (Geyer 1991; Altekar et al. 2004) over the lock-step driver: the batch is cut into groups of
-    `n_chains` chains with reciprocal temperatures `betas` (rank 0 = cold, beta = 1); every `swap_period` iterations
-    `n_swaps` adjacent temperature pairs per group propose to swap, with probability
+    """Metropolis-coupled MCMC (Geyer 1991; Altekar et al. 2004) over the lock-step driver: the GLOBAL set of chains is cut into
+    groups of `n_chains` consecutive chains with reciprocal temperatures `betas` (rank 0 = cold, beta = 1); every `swap_period`
+    iterations `n_swaps` distinct adjacent temperature pairs per group, in random order, propose to swap, with probability
     min(1, exp((beta_i - beta_j) (ln pi(x_j) - ln pi(x_i)))), pi = prior x likelihood.  Temperatures move between chains
     (the states stay where they are), which is the same Markov chain as swapping states.  Only cold chains are
     reported, like the reference's monitors.  The algorithm lives in the package `mcmc` [external, not vendored]: its
     initial ladder and its tuning of the ladder are not restated (parity unpinned); the default ladder 0.97^i is this
-    build's choice.  `backend` is a `Sampler` (or anything with run / posterior / set_temperatures / state / batch)."""
+    build's choice.
+
+    `backend`: a `Sampler` -- the swap phase then runs ON THE DEVICE behind the C ABI (mcd_mh_mc3_init / mcd_mh_mc3_swap,
+    csrc/k_mc3.hip) -- or anything with run / posterior / set_temperatures / state / batch (the CPU twin in the tests), for
+    which the same phase is evaluated by `mc3_swap_host` on the same counter-based draws.  A sharded run (one process per GPU):
+    `shard` = this rank's ChainShard and `gather` = a callable that all-gathers the ranks' [3][batch] ln posterior arrays into
+    [world][3][batch] (shards.ShardComm / shards.gather_posterior); every rank evaluates all groups, so the run does not depend
+    on the number of ranks."""
 
     def __init__(self, backend, n_chains: int = 4, swap_period: int = 2, n_swaps: int = 3, betas: Optional[Sequence[float]] = None,
-                 seed: int = 0):
-        if n_chains < 2 or backend.batch % n_chains != 0:
-            raise ValueError("MC3: the batch must be a multiple of n_chains >= 2")
+                 seed: int = 0, shard=None, gather=None):
+        self.shard = shard
+        total = backend.batch if shard is None else shard.n_chains
+        if shard is not None and (shard.n_chains % shard.world != 0 or shard.size != backend.batch):
+            raise ValueError("MC3: a sharded run needs equally large shards that match the backend's batch")
+        if n_chains < 2 or total % n_chains != 0:
+            raise ValueError("MC3: the number of chains must be a multiple of n_chains >= 2")
         if swap_period < 1 or not (1 <= n_swaps <= n_chains - 1):
             raise ValueError("MC3: need swap_period >= 1 and 1 <= n_swaps <= n_chains - 1")       # mcmc's own checks
         self.backend, self.n, self.period, self.n_swaps = backend, int(n_chains), int(swap_period), int(n_swaps)
         self.ladder = np.asarray(betas if betas is not None else [0.97 ** i for i in range(n_chains)], dtype=np.float64)
         if self.ladder.shape != (n_chains,) or self.ladder[0] != 1.0 or np.any(np.diff(self.ladder) >= 0) or np.any(self.ladder <= 0):
             raise ValueError("MC3: betas must start at 1 and decrease")
-        self.groups = backend.batch // n_chains
-        self.rank = np.tile(np.arange(n_chains), self.groups)          # temperature rank of every chain
-        self.rng = np.random.default_rng([int(seed), 0x3C3])
-        self.swaps_tried = np.zeros(n_chains - 1, np.int64)
-        self.swaps_accepted = np.zeros(n_chains - 1, np.int64)
-        self.backend.set_temperatures(self.ladder[self.rank])
+        self.total = int(total)
+        self.lo = 0 if shard is None else shard.lo
+        self.gather = gather
+        if shard is not None and shard.world > 1 and gather is None:
+            raise ValueError("MC3: a sharded run needs `gather`")
+        self.seed = int(seed) ^ MC3_STREAM_DOMAIN
+        self.phase = 0
+        self.device = isinstance(backend, Sampler)
+        if self.device:
+            _capi.check(_capi.lib().mcd_mh_mc3_init(backend._h, self.n, self.ladder.ctypes.data_as(_dp), self.total, C.c_uint64(self.seed)))
+        else:
+            self._rank = (np.arange(self.total) % self.n).astype(np.int32)
+            self._tried = np.zeros(n_chains - 1, np.int64)
+            self._accepted = np.zeros(n_chains - 1, np.int64)
+            self.backend.set_temperatures(self.ladder[self._rank[self.lo:self.lo + backend.batch]])
+
+    # -- what the device holds ------------------------------------------------------------------------------------------
+    def _get(self):
+        rank = np.empty(self.total, np.int32)
+        tried = np.empty(self.n - 1, np.int64)
+        acc = np.empty(self.n - 1, np.int64)
+        _capi.check(_capi.lib().mcd_mh_mc3_get(self.backend._h, rank.ctypes.data_as(_ip), tried.ctypes.data_as(C.POINTER(C.c_int64)),
+                                               acc.ctypes.data_as(C.POINTER(C.c_int64)), None))
+        return rank, tried, acc
+
+    @property
+    def rank(self) -> np.ndarray:
+        """Temperature rank of every GLOBAL chain."""
+        return self._get()[0] if self.device else self._rank
+
+    @property
+    def swaps_tried(self) -> np.ndarray:
+        return self._get()[1] if self.device else self._tried
+
+    @property
+    def swaps_accepted(self) -> np.ndarray:
+        return self._get()[2] if self.device else self._accepted
 
     def cold(self) -> np.ndarray:
-        """Indices of the chains that are cold right now (one per group)."""
-        return np.nonzero(self.rank == 0)[0]
+        """Local indices of this backend's chains that are cold right now."""
+        return np.nonzero(self.rank[self.lo:self.lo + self.backend.batch] == 0)[0]
 
     def swap(self):
-        """One swap phase: n_swaps distinct adjacent pairs per group, applied one after the other."""
-        post = self.backend.posterior()
-        lnpi = post[:, 0] + post[:, 1]
-        for g in range(self.groups):
-            idx = np.arange(g * self.n, (g + 1) * self.n)
-            for i in self.rng.permutation(self.n - 1)[: self.n_swaps]:
-                a = idx[self.rank[idx] == i][0]
-                c = idx[self.rank[idx] == i + 1][0]
-                log_r = (self.ladder[i] - self.ladder[i + 1]) * (lnpi[c] - lnpi[a])
-                self.swaps_tried[i] += 1
-                if np.log(self.rng.uniform()) < log_r:                 # NaN compares false: no swap
-                    self.rank[a], self.rank[c] = i + 1, i
-                    self.swaps_accepted[i] += 1
-        self.backend.set_temperatures(self.ladder[self.rank])
+        """One swap phase."""
+        world = 1 if self.shard is None else self.shard.world
+        if self.device:
+            if world == 1:
+                _capi.check(_capi.lib().mcd_mh_mc3_swap(self.backend._h, self.n_swaps, None, 1, self.backend.batch))
+            else:
+                g = self.gather(self.backend)                          # device tensor [world][3][batch], on the sampler's stream
+                self._keep_gathered = g
+                _capi.check(_capi.lib().mcd_mh_mc3_swap(self.backend._h, self.n_swaps, C.c_void_p(g.data_ptr()), world, self.backend.batch))
+        else:
+            post = np.asarray(self.backend.posterior() if hasattr(self.backend, "posterior") else self.backend.post)   # [batch, 3]
+            local = np.ascontiguousarray(post[:, :3].T)                # [3][batch]
+            allp = local[None] if world == 1 else np.asarray(self.gather(local))
+            lnpi = (allp[:, 0, :] + allp[:, 1, :]).reshape(-1)
+            mc3_swap_host(self._rank, lnpi, self.ladder, self.n_swaps, self.seed, self.phase, self._tried, self._accepted)
+            self.backend.set_temperatures(self.ladder[self._rank[self.lo:self.lo + self.backend.batch]])
+        self.phase += 1
 
     def run(self, n_iter: int, collect_ages: bool = False):
         """n_iter iterations with a swap phase every swap_period iterations.  collect_ages: returns the absolute node ages
-        tH * h_v of the cold chains after every swap phase, [n_phases, groups, n_nodes]."""
+        tH * h_v of the cold chains after every swap phase, [n_phases, cold chains of this backend, n_nodes]."""
         out = []
         done = 0
         while done < n_iter:

@@ -90,6 +90,51 @@ def shard_sampler(tree_lik, prior, table, n_chains: int, seed: int, shard: Chain
     return Sampler(tree_lik, prior, table, shard.size, seed, first_chain=shard.lo)
 
 
+def gather_posterior_host(local, shard: ChainShard):
+    """[3][batch] ln prior / ln likelihood / ln Jacobian of this rank's chains (numpy) -> [world][3][batch] on every rank through
+    torch.distributed (gloo on CPU): what mcd_shard_allgather does with the device arrays, for rehearsals without a GPU."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if shard.world == 1:
+        return np.asarray(local)[None]
+    t = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float64))
+    out = torch.empty((shard.world * t.shape[0],) + tuple(t.shape[1:]), dtype=torch.float64)
+    dist.all_gather_into_tensor(out, t)
+    return out.numpy().reshape((shard.world,) + tuple(t.shape))
+
+
+def gather_posterior_device(sampler, comm: "ShardComm"):
+    """The sampler's device-resident [3][batch] posterior array all-gathered over the ranks on the SAMPLER'S stream (RCCL behind the
+    C ABI: mcd_mh_posterior_device + mcd_shard_allgather): a [world, 3, batch] CUDA tensor, valid in stream order -- what
+    mcd_mh_mc3_swap takes as `gathered`.  No host synchronisation."""
+    import ctypes as C
+
+    import torch
+
+    from . import _capi
+
+    lib = _capi.lib()
+    dptr, st = C.c_void_p(), C.c_void_p()
+    _capi.check(lib.mcd_mh_posterior_device(sampler._h, C.byref(dptr), C.byref(st)))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty((comm.shard.world, 3, sampler.batch), dtype=torch.float64, device=dev)
+    _capi.check(lib.mcd_shard_allgather(comm._comm, dptr, C.c_void_p(out.data_ptr()), 3 * sampler.batch, st))
+    return out
+
+
+def mc3_for_shard(sampler, shard: ChainShard, comm=None, **kw):
+    """Metropolis-coupled MCMC over a sharded set of chains (BASELINE.json config 5: `mc3 (MC3Settings (NChains 4) (SwapPeriod 2)
+    (NSwaps 3))`, app/Main.hs:476-478, over 8 GPUs): `sampler` = shard_sampler(...) of this rank, `comm` = its ShardComm (None on
+    one rank).  One period = sampler.run(swap_period) -> all-gather of the [3][batch] ln posteriors on the sampler's stream ->
+    mcd_mh_mc3_swap: sampler.MC3 with this rank's gather."""
+    from .sampler import MC3
+
+    gather = None if shard.world == 1 else (lambda smp: gather_posterior_device(smp, comm))
+    return MC3(sampler, shard=shard, gather=gather, **kw)
+
+
 class ShardComm:
     """The C ABI's communicator (include/mcmcdate_mvn.h: mcd_shard_*; RCCL's ncclAllGather bound at run time) -- what a host in
     the reference's language would use.  The unique id is drawn by rank 0 and handed to the other ranks through `exchange`, a

@@ -245,12 +245,16 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, monkeyp
         assert all(np.allclose(x, y, rtol=1e-13, atol=0) for x, y in zip(g1, g2))      # (sums formed per run, then added: not bitwise)
 
 
-@pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150), (70, 2100, 24)])
+@pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150), (70, 2100, 24), (140, 33, 150), (150, 512, 60), (160, 64, 100),
+                                                (513, 512, 24)])
 def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
     """Synthetic trees beyond 64 nodes (70 leaves: 139 nodes, N = 137, three row blocks; 128 leaves: 255 nodes, N = 253,
     the size of BASELINE.json's config 3, with 64 chains): lanes stride over the nodes and the likelihood runs through
-    the streaming kernel, two launches per step; parity with the CPU twin as for the small trees.  With 2100 chains the
-    likelihood launch takes the multiply form on the matrix cores (k_wide.hip)."""
+    the streaming kernel; parity with the CPU twin as for the small trees.  With 2100 chains the
+    likelihood launch takes the multiply form on the matrix cores (k_wide.hip).  140 / 150 / 160 leaves = 279 / 299 / 319 nodes:
+    the window between the streaming chain kernel (N <= 256, i.e. <= 258 nodes) and the workgroup-per-chain step kernel (more
+    than 320 nodes) -- one-wave k_mh_step with the prior inside + the row-split likelihood (round-2 review: no test reached it).
+    513 leaves x 512 chains = config 5's share of one GPU (1025 nodes), step by step against the twin."""
     from mcmc_date_amd import synthetic as S
 
     topo = S.random_topology(n_leaves, seed=3)
@@ -482,6 +486,64 @@ def test_heated_chains_and_mc3(gpu, golden):
         M.MC3(heated, n_chains=5)
     with pytest.raises(ValueError):
         M.MC3(heated, n_chains=4, n_swaps=4)
+
+
+def test_mc3_swap_phase_on_the_device(gpu, golden):
+    """The swap phase behind the C ABI (mcd_mh_mc3_init / mcd_mh_mc3_swap / mcd_mh_mc3_get, csrc/k_mc3.hip) against its host
+    restatement sampler.mc3_swap_host on the same counter-based draws: after every phase the temperature ranks of all chains, the
+    temperatures the driver holds and the swap counters are the same, bit for bit (24 chains = 6 groups of 4, a steep ladder so
+    that swaps are accepted and refused, 10 phases with two iterations of the cycle in between); a twin-backed MC3 (the CPU twin
+    behind the same class) follows the device run phase by phase.  Structural faults return error codes."""
+    import ctypes as C
+
+    from twin_backend import TwinBackend
+
+    fx = golden["12-leaves-variable-rate"]
+    B = 24
+    topo, ps, smp, twin = setup(fx, B=B, seed=51)
+    ladder = np.array([1.0, 0.7, 0.45, 0.25])
+    mc3 = M.MC3(smp, n_chains=4, swap_period=2, n_swaps=3, betas=ladder, seed=77)
+    tb = TwinBackend(twin, ps, seed=51)
+    ref = M.MC3(tb, n_chains=4, swap_period=2, n_swaps=3, betas=ladder, seed=77)
+    lib = M._capi.lib()
+    rank = np.arange(B, dtype=np.int32) % 4
+    tried, acc = np.zeros(3, np.int64), np.zeros(3, np.int64)
+    assert np.array_equal(mc3.rank, rank)
+    for phase in range(10):
+        smp.run(2)
+        tb.run(2)
+        post = smp.posterior()
+        assert np.allclose(post, tb.posterior(), rtol=1e-12, atol=1e-7)
+        M.sampler.mc3_swap_host(rank, post[:, 0] + post[:, 1], ladder, 3, mc3.seed, phase, tried, acc)
+        mc3.swap()
+        ref.swap()
+        beta = np.empty(B)
+        M._capi.check(lib.mcd_mh_mc3_get(smp._h, None, None, None, beta.ctypes.data_as(C.POINTER(C.c_double))))
+        assert np.array_equal(mc3.rank, rank) and np.array_equal(beta, ladder[rank]), phase
+        assert np.array_equal(mc3.swaps_tried, tried) and np.array_equal(mc3.swaps_accepted, acc)
+        assert np.array_equal(ref.rank, rank) and np.array_equal(twin.beta, beta)          # the twin-backed class: same decisions
+    assert acc.sum() > 0 and (tried - acc).sum() > 0 and not np.array_equal(rank, np.arange(B) % 4)
+    assert sorted(rank[:4].tolist()) == [0, 1, 2, 3] and len(mc3.cold()) == B // 4
+    compare_states(smp, twin)
+    # faults
+    assert lib.mcd_mh_mc3_init(smp._h, 5, ladder.ctypes.data_as(C.POINTER(C.c_double)), B, 1) == M._capi.MCD_ERR_INVALID_ARG     # 24 % 5
+    assert lib.mcd_mh_mc3_init(smp._h, 4, ladder[::-1].copy().ctypes.data_as(C.POINTER(C.c_double)), B, 1) == M._capi.MCD_ERR_INVALID_ARG
+    assert lib.mcd_mh_mc3_swap(smp._h, 4, None, 1, B) == M._capi.MCD_ERR_INVALID_ARG                                         # n_swaps > n - 1
+    _, _, fresh, _ = setup(fx, B=8, seed=1)
+    assert lib.mcd_mh_mc3_swap(fresh._h, 1, None, 1, 8) == M._capi.MCD_ERR_INVALID_ARG                                       # no init
+    _, _, part, _ = setup(fx, B=8, seed=1, first_chain=8)
+    assert lib.mcd_mh_mc3_init(part._h, 4, ladder.ctypes.data_as(C.POINTER(C.c_double)), 24, 1) == 0
+    assert lib.mcd_mh_mc3_swap(part._h, 3, None, 1, 8) == M._capi.MCD_ERR_INVALID_ARG                                        # a shard needs the gathered values
+    # a shard with the gathered posteriors of "three ranks": its own chains' temperatures follow the global table
+    import torch
+    g = torch.zeros((3, 3, 8), dtype=torch.float64, device=gpu)
+    g[:, 1, :] = torch.as_tensor(np.random.default_rng(3).normal(size=(3, 8)) * 5.0, device=gpu)
+    assert lib.mcd_mh_mc3_swap(part._h, 3, C.c_void_p(g.data_ptr()), 3, 8) == 0
+    r_all = np.empty(24, np.int32)
+    b_loc = np.empty(8)
+    M._capi.check(lib.mcd_mh_mc3_get(part._h, r_all.ctypes.data_as(C.POINTER(C.c_int32)), None, None, b_loc.ctypes.data_as(C.POINTER(C.c_double))))
+    expect = M.sampler.mc3_swap_host(np.arange(24, dtype=np.int32) % 4, g[:, 1, :].cpu().numpy().reshape(-1), ladder, 3, 1, 0)
+    assert np.array_equal(r_all, expect) and np.array_equal(b_loc, ladder[expect[8:16]]) and not np.array_equal(expect, np.arange(24) % 4)
 
 
 def test_cpp_sampler_mirror(gpu, golden, tmp_path):

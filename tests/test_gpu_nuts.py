@@ -227,6 +227,18 @@ def test_device_nuts_chains_agree_with_metropolis_hastings_chains(gpu, golden, n
     rel = np.abs(ages[inner] - ages_mh[inner]) / ages_mh[inner]
     assert 0.45 < np.mean(alphas) < 0.9, np.mean(alphas)
     assert rel.max() <= 0.03, (rel, np.mean(alphas))
+    # masses tuned in the library (mcd_hmc_nuts_warmup: `HTuneLeapfrog HTuneAllMasses`, app/Hamiltonian.hs:62-63) from the crude
+    # start (0.1 q)^2: the adapted inverse masses find the position variances of the Metropolis-Hastings sample (median ratio
+    # within a factor 1.5, every component within a factor 6), the closing window reaches the target acceptance statistic
+    if name == "12-leaves-variable-rate":
+        lf.set_state(smp.state())
+        q0 = lf.position()[0]
+        eps_w, im_w, alpha_c = lf.nuts_warmup(0.02, np.maximum((0.1 * np.abs(q0)).mean(axis=0) ** 2, 1e-12), windows=3, window=60, delta=0.65,
+                                              max_depth=6, seed=11)
+        ratio = im_w / inv_mass
+        assert np.all(np.isfinite(im_w)) and np.all(im_w > 0) and np.all((eps_w > 1e-3) & (eps_w < 1.0))
+        assert 1 / 1.5 < np.median(ratio) < 1.5 and ratio.max() < 6 and ratio.min() > 1 / 6, (np.median(ratio), ratio.min(), ratio.max())
+        assert 0.4 < alpha_c.mean() < 0.9, alpha_c.mean()
     # the random streams are keyed by the global chain index: chains 8 .. 15 alone retrace their part of the batch
     lf.set_state(smp.state())
     a_all, d_all = lf.nuts(eps, inv_mass, max_depth=6, seed=9, transition=7)

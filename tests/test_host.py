@@ -279,3 +279,32 @@ def test_load_calibrations_from_tree(tmp_path):
     assert got == [(0, 10.0, 0.01, 90.0, 0.01), (2, 9.0, 0.05, None, 0.0), (3, 5.0, 0.01, None, 0.0), (9, None, 0.0, 20.0, 0.01)]
     with pytest.raises(ValueError):
         M.load_calibrations_from_tree(topo, paths["rooted_tree"])      # no calibrations found
+
+
+def test_python_philox_mirror_matches_the_oracle():
+    """sampler.philox4x32 / uniform_pair (the host-side mirror of csrc/mh_device.hpp: philox_block, used by mc3_swap_host) against
+    Random123's known answers and the oracle's generator."""
+    import oracle as O
+    from mcmc_date_amd import sampler as SM
+
+    assert list(SM.philox4x32([0, 0, 0, 0], [0, 0])) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert list(SM.philox4x32([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    for seed, chain, step, d in [(3, 7, 11, 5), (2 ** 40 + 17, 4000, 2 ** 33 + 5, 0xFFFFFFFF), (SM.MC3_STREAM_DOMAIN ^ 5, 12, 0, 2)]:
+        assert tuple(O.uniform_pair(seed, chain, step, d)) == SM.uniform_pair(seed, chain, step, d)
+
+
+def test_mc3_swap_host_keeps_a_permutation_per_group():
+    from mcmc_date_amd import sampler as SM
+
+    rng = np.random.default_rng(1)
+    ladder = np.array([1.0, 0.8, 0.5, 0.3, 0.1])
+    rank = (np.arange(40) % 5).astype(np.int32)
+    tried, acc = np.zeros(4, np.int64), np.zeros(4, np.int64)
+    for phase in range(50):
+        SM.mc3_swap_host(rank, rng.normal(size=40) * 3, ladder, 4, 9, phase, tried, acc)
+        assert all(sorted(rank[g * 5:(g + 1) * 5].tolist()) == [0, 1, 2, 3, 4] for g in range(8))
+    assert tried.sum() == 50 * 8 * 4 and np.all(tried == 400) and 0 < acc.sum() < tried.sum()      # n_swaps = n - 1: every pair once per phase
+    r2 = rank.copy()
+    SM.mc3_swap_host(r2, np.full(40, np.nan), ladder, 4, 9, 99)                                  # NaN posteriors: no swap
+    assert np.array_equal(r2, rank)

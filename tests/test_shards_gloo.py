@@ -123,3 +123,69 @@ def test_sharded_mh_chains_equal_the_unsharded_run(n_chains):
     res = sorted(q.get(timeout=240) for _ in range(world))
     [p.join(timeout=60) for p in ps]
     assert all(p.exitcode == 0 for p in ps) and all(ok for _, ok in res)
+
+
+def _mc3_worker(rank, world, port, n_chains, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mcmc_date_amd as M
+    import oracle as O
+    from mcmc_date_amd.shards import ChainShard, gather_chain_rows, gather_posterior_host
+    from twin_backend import TwinBackend
+
+    fx = dict(np.load(os.path.join(ROOT, "tests", "golden", "06-leaves-constant-rate.npz")))
+    topo = M.Topology(fx["parent"])
+    ps, _ = M.proposals(topo, [], calibrations_available=False)
+    spec = O.PriorSpec(fx["parent"], float(fx["prior_ht"]), "UncorrelatedGamma", [], [], [])
+    model = O.MhModel(fx["parent"], fx["mu"], fx["sigma_inv"], float(fx["logdet"]), spec, M.table_arrays(ps))
+    x0 = M.init_with(topo, fx["mean_lengths"])
+
+    def backend(lo, hi):
+        s = M.StateBatch.from_states([x0] * (hi - lo))
+        return TwinBackend(O.MhChains(model, s.time_birth_rate, s.time_death_rate, s.time_height, s.heights, s.rate_mean, s.rate_variance,
+                                      s.rates, seed=9, chain0=lo), ps, seed=9)
+
+    ladder = [1.0, 0.8, 0.6, 0.4]                                          # a steep ladder: swaps are accepted and refused
+    sh = ChainShard(rank, world, n_chains)
+    mine = backend(sh.lo, sh.hi)
+    mc3 = M.MC3(mine, n_chains=4, swap_period=2, n_swaps=3, betas=ladder, seed=5, shard=sh,
+                gather=lambda local: gather_posterior_host(local, sh))
+    mc3.run(12)
+    full = backend(0, n_chains)
+    ref = M.MC3(full, n_chains=4, swap_period=2, n_swaps=3, betas=ladder, seed=5)
+    ref.run(12)
+    st, sf = mine.state(), full.state()
+    ok = (np.array_equal(mc3.rank, ref.rank) and np.array_equal(mc3.swaps_accepted, ref.swaps_accepted)
+          and np.array_equal(st.heights, sf.heights[sh.lo:sh.hi]) and np.array_equal(st.rates, sf.rates[sh.lo:sh.hi])
+          and np.array_equal(mine.c.beta, full.c.beta[sh.lo:sh.hi]) and np.array_equal(mine.c.post, full.c.post[sh.lo:sh.hi]))
+    moved = bool(ref.swaps_accepted.sum() > 0 and (ref.swaps_tried - ref.swaps_accepted).sum() > 0 and not np.array_equal(ref.rank, np.arange(n_chains) % 4))
+    # the cold chains, gathered: the same rows whatever the number of ranks
+    cold_local = np.zeros((sh.size, 1))
+    cold_local[mc3.cold(), 0] = 1.0
+    cold = gather_chain_rows(torch.as_tensor(cold_local), sh).numpy()[:, 0]
+    ok = ok and np.array_equal(np.nonzero(cold)[0], ref.cold()) and len(ref.cold()) == n_chains // 4
+    q.put((rank, bool(ok), moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mc3_does_not_depend_on_the_rank_count():
+    """BASELINE.json config 5's loop as a rehearsal on the CPU: chains sharded over two ranks, every SwapPeriod = 2 iterations one
+    all-gather of the per-chain ln posteriors and a swap phase of NSwaps = 3 adjacent pairs per group of NChains = 4
+    (app/Main.hs:476-478).  12 chains over 2 ranks: the middle group (chains 4 .. 7) straddles the ranks, so its swaps need the
+    gathered values.  Every rank evaluates all groups on counter-based draws: temperature ranks, swap counters, states and
+    cold-chain rows equal the single-process run bit for bit.  (The chains are the CPU twin; on a GPU the same loop runs through
+    mcd_mh_run -> mcd_shard_allgather -> mcd_mh_mc3_swap on the sampler's stream: shards.mc3_for_shard.)"""
+    world, n_chains = 2, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_mc3_worker, args=(r, world, port, n_chains, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps) and all(ok for _, ok, _ in res) and all(moved for _, _, moved in res)
