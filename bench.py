@@ -91,14 +91,20 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
     return out
 
 
-def mh_measure(dev_index, n, B, steps, warm, seed=3):
+def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_period=0, swap_steps=0, rehearsal=False):
     """Lock-step Metropolis-Hastings on the device (the metric's "= MCMC steps/sec x chains" reading):
     a synthetic tree of dimension n (255 for --n 256: 2L - 3 is odd), the reference's whole proposal cycle
-    (app/Definitions.hs:127-278) in its shuffled order, B chains stepping together; one step = one proposal of the cycle,
-    evaluated (prior + likelihood), accepted or rejected in every chain.  Returns a dict for the JSON line."""
+    (app/Definitions.hs:127-278) in its shuffled order, B chains per GPU stepping together; one step = one proposal of the cycle,
+    evaluated (prior + likelihood), accepted or rejected in every chain.  With world > 1 the chains are a global set of
+    world x B, this rank holding [rank B, (rank + 1) B) (shards.shard_sampler: global chain index = random-stream id).
+    swap_period = P > 0 (BASELINE.json config 5; `mc3 (MC3Settings (NChains 4) (SwapPeriod P) (NSwaps 3))`, app/Main.hs:476-478):
+    every P iterations of the cycle (or every `swap_steps` lock steps, for rehearsals shorter than an iteration) the ranks
+    all-gather their [3][B] ln posteriors on the sampler's stream (mcd_shard_allgather: RCCL over xGMI) and every rank runs the
+    swap phase of all groups on the gathered values (mcd_mh_mc3_swap) -- inside the timed region.  Returns a dict for the JSON line."""
     import torch
 
     import mcmc_date_amd as M
+    from mcmc_date_amd import shards as SH
     from mcmc_date_amd import synthetic as S
 
     topo = S.random_topology((n + 3) // 2, seed=seed)
@@ -107,29 +113,117 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3):
     tl = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index).bind_tree(topo)
     pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo, device=dev_index)
     ps, _ = M.proposals(topo, [], calibrations_available=True)
-    s0 = S.random_states(topo, B, seed=seed + 1)
+    shard = SH.ChainShard(rank, world, world * B)
+    s0 = S.random_states(topo, B, seed=seed + 1 + 1000 * rank)
     s0.time_birth_rate = np.full(B, 1.0)
     s0.time_death_rate = np.full(B, 0.8)
     s0.rate_variance = np.full(B, 0.3)
-    smp = M.Sampler(tl, pf, ps, B, seed=13)
+    smp = SH.shard_sampler(tl, pf, ps, world * B, 13, shard)
     smp.set_state(s0)
+    S_iter = int(sum(p.weight for p in ps))
     cyc = M.cycle_schedule(ps, 1, np.random.default_rng(0))
     reps = max(1, (steps + warm) // cyc.shape[1] + 1)
     sched = np.tile(cyc, (1, reps))
-    smp.run_schedule(sched[:, :warm])
+    mc3, comm, swap_info = None, None, None
+    period = 0
+    if swap_period > 0 or swap_steps > 0:
+        period = int(swap_steps) if swap_steps > 0 else int(swap_period) * S_iter
+        if world > 1 and not rehearsal:
+            comm = SH.ShardComm(shard, device=dev_index)
+            mc3 = SH.mc3_for_shard(smp, shard, comm, n_chains=4, swap_period=max(1, swap_period), n_swaps=3, seed=7)
+        elif world > 1:
+            # one-GPU rehearsal (every rank on cuda:0, RCCL refuses that): the gather goes through the host and gloo
+            def gather(sampler):
+                local = np.ascontiguousarray(sampler.posterior().T)
+                return torch.as_tensor(SH.gather_posterior_host(local, shard), device=torch.device("cuda", dev_index))
+
+            mc3 = M.MC3(smp, n_chains=4, swap_period=max(1, swap_period), n_swaps=3, seed=7, shard=shard, gather=gather)
+        else:
+            mc3 = M.MC3(smp, n_chains=4, swap_period=max(1, swap_period), n_swaps=3, seed=7)
+
+    phases = [0]
+
+    def advance(lo, hi):
+        """lock steps [lo, hi) of the schedule; a swap phase after every full period"""
+        pos = lo
+        while pos < hi:
+            nxt = hi if period == 0 else min(hi, (pos // period + 1) * period)
+            smp.run_schedule(sched[:, pos:nxt])
+            if period and nxt % period == 0:
+                mc3.swap()
+                phases[0] += 1
+            pos = nxt
+
+    advance(0, warm)
+    if mc3 is not None and warm < period:                      # the first phase of a short run: exercised once outside the clock
+        mc3.swap()
     torch.cuda.synchronize()
+    phases[0] = 0
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     t0 = time.perf_counter()
-    smp.run_schedule(sched[:, warm:warm + steps])
+    advance(warm, warm + steps)
+    if mc3 is not None and phases[0] == 0:                     # fewer steps than a period: the exchange still runs once under the clock
+        mc3.swap()
+        phases[0] += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     post = smp.posterior()
     assert np.all(np.isfinite(post)), "non-finite ln posterior after the Metropolis-Hastings run"
-    return {"value": B * steps / dt, "unit": "proposal steps/s (lock steps x chains)", "us_per_lockstep": 1e6 * dt / steps,
-            "n_nodes": int(topo.n_nodes), "dimension": int(nd), "chains": int(B), "lock_steps": int(steps),
-            "proposals_per_iteration": int(sum(p.weight for p in ps)),
-            "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device; "
-                    + ("whole schedule in one launch, two chains per workgroup, the factor streamed once per step" if (65 <= topo.n_nodes <= 320 and B <= 1024)
-                       else "two launches per lock step")}
+    if mc3 is not None:
+        rk = mc3.rank
+        assert all(sorted(rk[g * 4:(g + 1) * 4].tolist()) == [0, 1, 2, 3] for g in range(len(rk) // 4)), "temperature ranks are not a permutation"
+        swap_info = {"n_chains": 4, "n_swaps": 3, "period_iterations": int(swap_period), "period_lock_steps": int(period), "phases_timed": int(phases[0]),
+                     "ranks": int(world), "bytes_gathered_per_phase": int(world * 3 * B * 8),
+                     "allgather": ("mcd_shard_allgather (RCCL ncclAllGather) on the sampler's stream" if comm is not None else
+                                   "gloo through the host (one-GPU rehearsal)" if world > 1 else "none (one rank: the sampler's own array)"),
+                     "swaps_tried": mc3.swaps_tried.tolist(), "swaps_accepted": mc3.swaps_accepted.tolist()}
+    out = {"value": B * steps / dt, "unit": "proposal steps/s (lock steps x chains)", "us_per_lockstep": 1e6 * dt / steps,
+           "n_nodes": int(topo.n_nodes), "dimension": int(nd), "chains": int(B), "lock_steps": int(steps),
+           "proposals_per_iteration": S_iter,
+           "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device; " + smp.last_path()}
+    if swap_info:
+        out["mc3"] = swap_info
+    if comm is not None:
+        comm.close()
+    return out
+
+
+def full_gpu_measure(dev_index, n, chains=8192, launches=200):
+    """What the GPU does when it is FULL: the same log-density at `chains` chains, where every SIMD has work and the launch takes the
+    multiply form on the fp64 matrix cores (k_wide.hip) -- priced against the dense fp64 MFMA peak.  A secondary
+    field of the default line (the headline stays BASELINE.json's 512 chains, a latency-bound launch)."""
+    import torch
+
+    import mcmc_date_amd as M
+    from mcmc_date_amd import synthetic as S
+
+    dev = torch.device("cuda", dev_index)
+    mu, sigma = S.random_spd_problem(n, seed=n)
+    lik = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index)
+    X = torch.as_tensor(S.sample_chains(mu, sigma, chains, seed=n + 77), device=dev)
+    ll = torch.empty(chains, dtype=torch.float64, device=dev)
+    for _ in range(20):
+        lik.logpdf_into(X, ll)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        lik.logpdf_into(X, ll)
+    e1.record()
+    torch.cuda.synchronize()
+    per = e0.elapsed_time(e1) * 1e-3 / launches
+    chk = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index)
+    chk.set_form("sweep")
+    ref = chk.logpdf(X[:256])
+    assert float(((ll[:256] - ref).abs() / ref.abs()).max()) <= 1e-11, "full-GPU batch differs from the sweep form"
+    flops = algorithmic_flops_per_eval(n) * chains / per / 1e12
+    hbm = algorithmic_bytes_per_eval(n, chains) * chains / per / 1e9
+    return {"value": chains / per, "unit": "evals/s", "chains": int(chains), "n": int(n), "kernel_us_per_launch": per * 1e6, "launches": int(launches),
+            "launch": "eager", "form": "multiply (v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "achieved": flops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / FP64_PEAK_TFLOPS,
+                         "hbm_gbs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}}
 
 
 def main():
@@ -137,9 +231,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100000)
     ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--n", type=int, default=256, help="MVN dimension")
+    ap.add_argument("--n", "--dim", dest="n", type=int, default=256, help="MVN dimension (--dim: the spelling that survives torch.distributed.run's "
+                    "own option parser, where --n is an ambiguous prefix)")
     ap.add_argument("--chains", type=int, default=512, help="chains per GPU")
-    ap.add_argument("--swap-period", type=int, default=0, help="all-gather ll every P steps (0 = off)")
+    ap.add_argument("--swap-period", type=int, default=0, help="--kind mh: MC3 swap phase (all-gather of the ln posteriors + swaps) every P "
+                    "iterations of the proposal cycle, config 5; other kinds: all-gather ll every P steps (0 = off)")
+    ap.add_argument("--swap-steps", type=int, default=0, help="--kind mh: swap phase every Q lock steps instead (rehearsals shorter than an iteration)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
     ap.add_argument("--graph-chunk", type=int, default=100, help="steps captured per hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +281,8 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        r = mh_measure(dev_index, n, B, K, W, seed=3 + rank)
+        r = mh_measure(dev_index, n, B, K, W, seed=3, rank=rank, world=world, swap_period=args.swap_period, swap_steps=args.swap_steps,
+                       rehearsal=rehearsal)
         elapsed = K * r["us_per_lockstep"] * 1e-6
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
@@ -201,7 +299,10 @@ def main():
                 "config": {"workload": f"lock-step Metropolis-Hastings, synthetic {r['n_nodes']}-node tree (dimension {nd}), {B} chains per GPU, "
                                        f"the reference's proposal cycle ({r['proposals_per_iteration']} proposals per iteration)",
                            "n": nd, "chains_per_gpu": B, "kernel": "mh", "launch": "see mh.what",
-                           "parallelism": f"chains sharded x{world}, no data-path collective"},
+                           "swap_period": args.swap_period,
+                           "parallelism": (f"chains sharded x{world}, no data-path collective" if "mc3" not in r else
+                                           f"chains sharded x{world}; MC3 swap phase every {r['mc3']['period_lock_steps']} lock steps: one all-gather of "
+                                           f"{r['mc3']['bytes_gathered_per_phase']} bytes + swaps of temperatures")},
                 "roofline": {"bound": "hbm", "achieved": alg_b / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg_b / (elapsed / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "note": "algorithmic bytes of the likelihood launch only; the step also runs the proposal + prior launch"},
@@ -444,6 +545,8 @@ def main():
         if world == 1 and args.kind == "logpdf" and not args.no_mh:
             # the metric's "= MCMC steps/sec x chains": real Metropolis-Hastings steps on a tree of this size (secondary field)
             out["mh"] = mh_measure(dev_index, n, B, 4000, 400)
+        if world == 1 and args.kind == "logpdf" and not args.no_mh and B <= 1024:
+            out["full_gpu"] = full_gpu_measure(dev_index, n)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, mu, sigma, X_host)
         print(json.dumps(out))

@@ -20,6 +20,16 @@
 // proposal cannot move the likelihood (birth rate, death rate, rate variance) skip the sweep on both sides: the decision is a
 // function of the proposal row alone, so chain waves and loader waves take it alike.
 //
+// Round 3: most proposals of the cycle move at most a handful of branch distances (slide a node: three; scale one branch rate:
+// one; small sub trees), and the full sweep was 43 % of a step.  The chain wave keeps z = L^-1 (d - mu) of the CURRENT state in
+// registers; for a proposal whose table row is marked sparse (mcd_mh_create: MhDev::sparse) it forms z' = z + sum_j delta_j W[:, j]
+// over the distances that actually moved (found by comparing d' with d: right for any number of them) with columns of W = L^-1
+// from L2 (MvnDev::Wc, 2 KiB each), requested before the ln prior is evaluated and used after it, and q' = |z'|^2; the loader waves
+// do not stream on such steps.  Dense proposals take the sweep as before, which also leaves z' exact; every 256 steps (and at the
+// start of a launch) z is recomputed by a sweep of the current state.  ln likelihood values then agree with a full evaluation
+// to rounding (1e-13 relative), not bit for bit: decisions, states and counters still equal the two-launch path's, the traced
+// ln acceptance ratios and the ln likelihood agree within the twin's tolerance (tests/test_gpu_mh.py).
+//
 // Reference: the loop this replaces is `mhg`'s iteration of `mcmc` [external] driven from app/Main.hs:460-479 with the cycle of
 // app/Definitions.hs:256-278; likelihood app/Probability.hs:166-173, 195-207; jacobianRootBranch :393-410.
 #include "mvn_device.hpp"
@@ -40,6 +50,9 @@ __device__ __forceinline__ bool mhb_moves_likelihood(int kind, int node)
 __host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int n_prop) { return 4 * (size_t)n_nodes + 2 * (size_t)n_prop; }
 // ... and per workgroup: the tree tables (five int32 arrays of n_nodes, rounded up to doubles)
 __host__ __device__ inline size_t mhb_table_doubles(int n_nodes) { return (5 * (size_t)n_nodes + 1) / 2 + 1; }
+
+constexpr int kMhbRefresh = 256;   // steps between two recomputations of z by a full sweep of the current state (a power of two)
+constexpr int kMhbCols = 4;        // columns of L^-1 in flight per batch of moved distances
 
 template <int R>
 __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, TreeDev T, PriorDev P, const int32_t* __restrict__ sched,
@@ -62,20 +75,26 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         Stage<R, LW> st;
         int p = sched[0];
         int kind = M.kind[p], node = M.node[p];
+        const bool inc = V.Wc != nullptr;
+        int sp = inc ? M.sparse[p] : 0;
+        auto stream_once = [&]() {
+            // chunk 0 into the ring, chunks 1 and 2 requested -- all of it while the chain waves propose and evaluate the prior
+            // (the stand-alone launch requests 1 and 2 after the barrier, out of the way of the compute waves' state loads;
+            // here nothing competes and the stream's first round trip would be exposed at every step)
+            fwd_loader_prologue<R, LW>(V.Ft, ring, st, lw, lane);
+            fwd_loader_start<R, LW>(V.Ft, st, lw, lane);
+            lds_barrier();
+            fwd_loader<R, LW, 0>(V.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
+        };
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
-            if (mhb_moves_likelihood(kind, node)) {
-                // chunk 0 into the ring, chunks 1 and 2 requested -- all of it while the chain waves propose and evaluate the prior
-                // (the stand-alone launch requests 1 and 2 after the barrier, out of the way of the compute waves' state loads;
-                // here nothing competes and the stream's first round trip would be exposed at every step)
-                fwd_loader_prologue<R, LW>(V.Ft, ring, st, lw, lane);
-                fwd_loader_start<R, LW>(V.Ft, st, lw, lane);
-                lds_barrier();
-                fwd_loader<R, LW, 0>(V.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
-            }
+            const int sp_next = inc ? M.sparse[p_next] : 0;
+            if (inc && (gs & (kMhbRefresh - 1)) == 0) stream_once();               // z of the current state: start of the launch, then every 256 steps
+            if (mhb_moves_likelihood(kind, node) && !sp) stream_once();
             kind = kind_next;
             node = node_next;
+            sp = sp_next;
         }
         return;
     }
@@ -149,6 +168,45 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         sl_pa[k] = T.slot_parent[row];                       // 0 for padded rows
     }
     const int rr = T.root_right;
+    // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207), the
+    // arithmetic of load_tree (mvn_device.hpp); v[k] = distance of row 64 k + lane (0 in the padding), returns the root slot's
+    auto distances = [&](const double* Hx, const double* Rx, double s_, double (&v)[R]) -> double {
+        double dist0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int rw = 64 * k + lane;
+            double x = 0.0;
+            if (sl_a[k] >= 0) {
+                x = (Hx[sl_pa[k]] - Hx[sl_a[k]]) * Rx[sl_a[k]];
+                if (rw == 0) x = x + (Hx[0] - Hx[rr]) * Rx[rr];
+                x = x * s_;
+            }
+            if (k == 0) dist0 = x;
+            v[k] = x;
+        }
+        return dist0;
+    };
+    // z = L^-1 (v - mu) by the forward sweep against the ring (the loaders stream alongside); returns |z|^2
+    auto sweep = [&](const double (&v)[R], double (&z)[R]) -> double {
+        double d[R][1];
+#pragma unroll
+        for (int k = 0; k < R; ++k) d[k][0] = (v[k] - mu_r[k]) * iv_r[k];
+        lds_barrier();
+        fwd_compute<R, 1, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
+        double sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            z[k] = d[k][0];
+            sq = fma(d[k][0], d[k][0], sq);
+        }
+        return wave_sum(sq);
+    };
+    const bool inc = V.Wc != nullptr;                        // incremental evaluation of sparse proposals available
+    const int NPad = 64 * R;
+    double dcur[R], zc[R];                                   // distances and z = L^-1 (d - mu) of the CURRENT state
+    (void)distances(Hc, Rc, sc[2] * sc[3], dcur);
+#pragma unroll
+    for (int k = 0; k < R; ++k) zc[k] = 0.0;
     constexpr int NAGE = 5;                                  // strides of 64 nodes: n_nodes <= 258 + room
     double age_s[NAGE], age_q[NAGE];
 #pragma unroll
@@ -169,10 +227,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 #endif
     int p = sched[0];
     PropRow row = mh_load_row(M, p);
+    int row_sparse = inc ? M.sparse[p] : 0;
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
         const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
         const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
+        const int sparse_next = inc ? M.sparse[p_next] : 0;
+        if (inc && (gs & (kMhbRefresh - 1)) == 0) (void)sweep(dcur, zc);   // (the loaders stream for it: same condition)
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
             // parameter (as k_mh_chain.hip, and as k_mh_draws does for the two-launch path)
@@ -192,6 +253,56 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const double lnqj = mh_propose_wave(Ml, row, tune[p], dr, lane, sc1, Hc, Rc, Hp, Rp);
         __builtin_amdgcn_wave_barrier();
         MHB_TICK(1)
+        // distances of the proposed state; for a sparse row: which of them moved, and the first columns of L^-1 on their way
+        const bool moves = mhb_moves_likelihood(row.kind, row.node);      // (a function of the row alone: the loaders decide alike)
+        const bool sparse_step = moves && row_sparse != 0;
+        double vp[R], dl[R];
+        double lj1 = lj;
+        uint64_t mk[R];
+        int cj[kMhbCols];
+        double cd[kMhbCols], col[kMhbCols][R];
+        int ccnt = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) mk[k] = 0;
+        auto fetch_cols = [&]() {                             // up to kMhbCols moved distances, in row order: their columns requested
+            ccnt = 0;
+#pragma unroll
+            for (int c = 0; c < kMhbCols; ++c) {
+                int j = (c > 0) ? cj[c - 1] : 0;
+                double d_ = 0.0;                              // no more: the previous column again with weight 0 (exact)
+                bool got = false;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {                 // (wave-uniform; no early exit, so that the arrays stay registers)
+                    const bool take = !got && mk[k] != 0;
+                    if (take) {
+                        const int l = (int)__builtin_ctzll(mk[k]);
+                        mk[k] &= mk[k] - 1;
+                        j = 64 * k + l;
+                        d_ = readlane64(dl[k], l);
+                    }
+                    got = got || take;
+                }
+                ccnt += got ? 1 : 0;
+                cj[c] = j;
+                cd[c] = d_;
+                const double* wc = V.Wc + (size_t)j * NPad + lane;
+#pragma unroll
+                for (int k = 0; k < R; ++k) col[c][k] = wc[64 * k];
+            }
+        };
+        if (moves) {
+            const double dist0 = distances(Hp, Rp, sc1[2] * sc1[3], vp);
+            lj1 = log(1.0 / readlane64(dist0, 0));          // jacobianRootBranch, :393-410
+            if (sparse_step) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    dl[k] = vp[k] - dcur[k];
+                    mk[k] = __builtin_amdgcn_ballot_w64(vp[k] != dcur[k]);   // NaN != x: counted, and the NaN then reaches q
+                }
+                fetch_cols();
+            }
+        }
+        MHB_TICK(3)
         bool dH = false, dR = false;
         for (int w0 = 0; w0 < nn; w0 += 64) {
             const int w = w0 + lane;
@@ -206,33 +317,28 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                                ? prior_clock_wave(Pl, lane, sc1[3], sc1[4], Hp, Rp, &ccp) : c2;
         const double lp1 = c0p + c1p + c2p;
         MHB_TICK(2)
-        // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207),
-        // the arithmetic of load_tree (mvn_device.hpp)
-        double ll1 = ll, lj1 = lj;
-        if (mhb_moves_likelihood(row.kind, row.node)) {      // (a function of the row alone: the loaders decide alike)
-            const double s = sc1[2] * sc1[3];
-            double d[R][1];
-            double dist0 = 0.0;
+        double ll1 = ll;
+        double zp[R];
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int rw = 64 * k + lane;
-                double v = 0.0;
-                if (sl_a[k] >= 0) {
-                    v = (Hp[sl_pa[k]] - Hp[sl_a[k]]) * Rp[sl_a[k]];
-                    if (rw == 0) v = v + (Hp[0] - Hp[rr]) * Rp[rr];
-                    v = v * s;
-                }
-                if (k == 0) dist0 = v;
-                d[k][0] = (v - mu_r[k]) * iv_r[k];
+        for (int k = 0; k < R; ++k) zp[k] = zc[k];
+        if (sparse_step) {
+            // z' = z + sum_j delta_j W[:, j] over the moved distances, in row order; q' = |z'|^2
+            while (true) {
+#pragma unroll
+                for (int c = 0; c < kMhbCols; ++c)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) zp[k] = fma(cd[c], col[c][k], zp[k]);
+                if (ccnt < kMhbCols) break;
+                fetch_cols();                                 // (more than kMhbCols moved: another round trip)
+                if (ccnt == 0) break;
             }
-            lj1 = log(1.0 / readlane64(dist0, 0));          // jacobianRootBranch, :393-410
-            MHB_TICK(3)
-            lds_barrier();
-            fwd_compute<R, 1, 0>(d, ring, lane, ncols MCD_ACC_ARGS);
             double sq = 0.0;
 #pragma unroll
-            for (int k = 0; k < R; ++k) sq = fma(d[k][0], d[k][0], sq);
+            for (int k = 0; k < R; ++k) sq = fma(zp[k], zp[k], sq);
             const double q = wave_sum(sq);
+            ll1 = V.c + (-0.5) * (V.logdet + q);             // :169 (finish_ll)
+        } else if (moves) {
+            const double q = sweep(vp, zp);
             ll1 = V.c + (-0.5) * (V.logdet + q);             // :169 (finish_ll)
         }
         MHB_TICK(4)
@@ -253,6 +359,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             lp = lp1;
             ll = ll1;
             lj = lj1;
+            if (moves) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    zc[k] = zp[k];
+                    dcur[k] = vp[k];
+                }
+            }
         }
         if (lane == 0) {
             tried[p] += 1;
@@ -276,11 +389,12 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         }
         p = p_next;
         row = row_next;
+        row_sparse = sparse_next;
         MHB_TICK(5)
     }
 #ifdef MCD_MHB_STAMP
     if (trace_alpha && lane == 0 && valid)
-        for (int i = 0; i < 6; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // ticks: loop head, propose, prior, distances, barrier + sweep, accept
+        for (int i = 0; i < 6; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // ticks: loop head, propose, prior, distances + column requests, sweep or column update, accept
 #endif
     if (!valid) return;
 #pragma unroll
@@ -353,6 +467,17 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
 {
     if (n_steps <= 0) return hipSuccess;
     if (!mh_chain_big_available(M, V)) return hipErrorInvalidValue;
+    const char* env = getenv("MCD_MH_INCREMENTAL");          // 0: every proposal through the full sweep (tests, timing; read per call)
+    if (env && env[0] == '0') {
+        MvnDev V0 = V;
+        V0.Wc = nullptr;
+        switch (V.R) {
+        case 2: return launch_big_R<2>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+        case 3: return launch_big_R<3>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+        case 4: return launch_big_R<4>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (V.R) {
     case 2: return launch_big_R<2>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     case 3: return launch_big_R<3>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/mcmcdate_mvn.h"
@@ -199,6 +200,52 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
             default: return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_create: proposal %d: unknown kind %d", i, k);
         }
     }
+    // Which proposals move only a few branch distances (k_mh_chain_big.hip evaluates those by columns of L^-1 instead of a sweep):
+    // a distance changes where a node's height, its parent's height or its rate changes -- for the node kinds below the node
+    // itself with its daughters, or its sub tree.  The root's two daughters share distance slot 0.  This is a performance hint
+    // only: the kernel finds the moved distances from the data and is right for any number of them.
+    std::vector<int32_t> sparse((size_t)n_prop, 0);
+    {
+        std::vector<std::vector<int>> kids((size_t)n);
+        for (int v = 1; v < n; ++v) kids[(size_t)parent[v]].push_back(v);
+        auto slots_of = [&](const std::vector<int>& nodes) {
+            std::vector<int> sl;
+            for (int w : nodes) {
+                if (w == 0) continue;
+                const int key = (parent[w] == 0) ? 1 : w;              // both root daughters -> one slot
+                if (std::find(sl.begin(), sl.end(), key) == sl.end()) sl.push_back(key);
+            }
+            return (int)sl.size();
+        };
+        for (int i = 0; i < n_prop; ++i) {
+            const int k = kind[i], v = node[i];
+            std::vector<int> touched;
+            bool known = true;
+            switch (k) {
+                case MCD_PROP_SLIDE_NODE:
+                case MCD_PROP_SLIDE_NODE_CONTRA:
+                    touched.push_back(v);
+                    for (int c : kids[(size_t)v]) touched.push_back(c);
+                    break;
+                case MCD_PROP_SCALE_BRANCH_RATE: touched.push_back(v); break;
+                case MCD_PROP_SCALE_SUBTREE_TIME:
+                case MCD_PROP_SCALE_SUBTREE_RATE:
+                case MCD_PROP_SCALE_SUBTREE_CONTRA:
+                    if (size[v] > 2 * mcd::kMhSparseSlots) { known = false; break; }
+                    for (int w = v; w < v + size[v]; ++w) touched.push_back(w);
+                    break;
+                case MCD_PROP_SLIDE_BRACE:
+                case MCD_PROP_SLIDE_BRACE_CONTRA:
+                    for (int j = host_brace_ptr[v]; j < host_brace_ptr[v + 1]; ++j) {
+                        touched.push_back(host_brace_nodes[j]);
+                        for (int c : kids[(size_t)host_brace_nodes[j]]) touched.push_back(c);
+                    }
+                    break;
+                default: known = false; break;                         // scalars, whole-tree scalings, pulley, root slide
+            }
+            sparse[(size_t)i] = (known && slots_of(touched) <= mcd::kMhSparseSlots) ? 1 : 0;
+        }
+    }
     m->device = dev_t;
     m->seed = seed;
     for (int i = 0; i < n_prop; ++i) m->rows.push_back(mcd::MhRow{kind[i], node[i], n1[i], n2[i], jac_root[i], p0[i], p1[i]});
@@ -229,7 +276,7 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
         (rc = dev_alloc(m.get(), &D.tried, BP, true)) || (rc = dev_alloc(m.get(), &D.age_sum, BN, true)) ||
         (rc = dev_alloc(m.get(), &D.age_sq, BN, true)) || (rc = dev_alloc(m.get(), &D.pcomp, 3 * B, true)) ||
         (rc = dev_alloc(m.get(), &D.pcomp1, 3 * B, true)) || (rc = dev_alloc(m.get(), &D.draws, 64 * 5 * B, true)) ||
-        (rc = dev_alloc(m.get(), &D.pflags, B, true)))
+        (rc = dev_alloc(m.get(), &D.pflags, B, true)) || (rc = dev_upload(m.get(), &D.sparse, sparse.data(), (size_t)n_prop)))
         return rc;
     // trees of at most 64 nodes: the whole schedule runs in one launch with the factor staged in LDS (k_mh_chain.hip).
     // MCD_MH_PER_PHASE=1 (diagnostic) keeps the two-launches-per-step path that larger trees use.

@@ -132,7 +132,7 @@ struct mcd_mvn {
     int n = 0, R = 0, device = 0;
     double logdet = 0.0;
     mcd::MvnDev dev{};
-    double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr, *d_Wt = nullptr, *d_Wtb = nullptr;
+    double *d_mu = nullptr, *d_invdiag = nullptr, *d_Ft = nullptr, *d_Ut = nullptr, *d_Wt = nullptr, *d_Wtb = nullptr, *d_Wc = nullptr;
     std::vector<double> L;  // host copy of the factor (row-major lower)
     mutable WorkspacePool pool;
     mcd::SplitHost* split = nullptr;   // k_split.hip: schedules of the row-split form + scratch sets per stream
@@ -149,6 +149,7 @@ struct mcd_mvn {
         if (d_Wt) (void)hipFree(d_Wt);
         mcd::split_host_destroy(split);
         if (d_Wtb) (void)hipFree(d_Wtb);
+        if (d_Wc) (void)hipFree(d_Wc);
     }
 };
 
@@ -284,6 +285,14 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
         HIP_TRY(hipMemcpy(h->d_Wtb, Wtb.data(), Wtb.size() * sizeof(double), hipMemcpyHostToDevice));
         h->dev.Wt = h->d_Wt;
         h->dev.Wtb = h->d_Wtb;
+        if (h->R >= 2 && h->R <= 4) {        // the streaming Metropolis-Hastings chain kernel's sizes: columns of W for sparse proposals
+            std::vector<double> Wc((size_t)n * NP, 0.0);
+            for (int j = 0; j < n; ++j)
+                for (int i = j; i < n; ++i) Wc[(size_t)j * NP + i] = W[(size_t)i * n + j];
+            HIP_TRY(hipMalloc((void**)&h->d_Wc, Wc.size() * sizeof(double)));
+            HIP_TRY(hipMemcpy(h->d_Wc, Wc.data(), Wc.size() * sizeof(double), hipMemcpyHostToDevice));
+            h->dev.Wc = h->d_Wc;
+        }
         HIP_TRY(mcd::prepare_wide());
         HIP_TRY(mcd::prepare_wide_grad());
         HIP_TRY(mcd::prepare_wide_grad_mc());

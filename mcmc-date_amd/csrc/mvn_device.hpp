@@ -658,6 +658,9 @@ static inline Geometry pick_geometry(int64_t batch)
     // Up to 4096 chains: 4 compute waves per workgroup keep the grid within one wave of workgroups
     // per CU for longer (measured at N = 256, B = 1024: 9.5 us against 14.4 us).
     // More: 4 compute waves x 2 chains share each pass over the factor.
+    const char* env = getenv("MCD_GEOM");                // tuning: "21" | "41" | "42" = compute waves, chains per wave (read per launch)
+    if (env && env[0] == '2') return {2, 2, 1};
+    if (env && env[0] == '4') return {4, 2, env[1] == '2' ? 2 : 1};
     if (batch <= 512) return {2, 2, 1};
     if (batch <= 4096) return {4, 2, 1};
     return {4, 2, 2};

@@ -19,6 +19,8 @@ struct MvnDev {
     const double* Ut;       // backward factor L[i][r]/L[r][r], same layout, NP*NP
     const double* Wt;       // W = L^-1 as 16 x 4 MFMA operand tiles (host_factor.h: pack_w_tiles), for k_wide.hip
     const double* Wtb;      // the tiles of W^T for the gradient's second product (k_wide_grad.hip)
+    const double* Wc;       // W = L^-1 column by column, [N][NP] (column j = NP doubles, zero above row j and in the padding): the
+                            // incremental evaluation of sparse proposals in k_mh_chain_big.hip; NULL for R > 4
     const struct SplitHost* split;   // HOST pointer (never dereferenced on the device): schedules + scratch of the row-split form (k_split.hip)
     const int* form;        // HOST pointer: this handle's form override (MCD_FORM_*; 0 = the process default), mcd_mvn_set_form
 };
@@ -93,7 +95,9 @@ struct MhDev {
     double *pcomp, *pcomp1;
     double* draws;
     int32_t* pflags;           // [batch] which blocks of the ln prior the pending proposal moved (bit 0 nodes, 1 birth-death, 2 clock)
+    const int32_t* sparse;     // [n_prop] 1: the proposal moves at most kMhSparseSlots distances (k_mh_chain_big: z updated by columns of L^-1)
 };
+constexpr int kMhSparseSlots = 8;
 
 // Metropolis-coupled MCMC (k_mc3.hip): the temperature rank of every GLOBAL chain, the ladder of reciprocal temperatures and the
 // swap counters per rung; all pointers are device memory.

@@ -18,9 +18,14 @@
  *   - liftProposalWith jacobianRootBranch (app/Definitions.hs:148 ff.): J *= jf(y') / jf(y);
  *   - the auto-tuning rule of `mcmc` [EXTERNAL]: t' = clamp(t * exp(2 (rate - optimal(dim))), 1e-5, 1e3).
  *
- * PARITY UNPINNED for this row: the reference holds no expected outputs for its proposals or chains and cannot be
- * run here.  What pins this file: Philox4x32-10 known answer (Random123 kat vector), scipy.stats.truncnorm /
- * scipy.stats.gamma for the distributions, detailed-balance identities (tests/test_mh_oracle.py).
+ * PINNED AT THE SAMPLER LEVEL (round 3) by outputs the reference itself commits: the node ages of its six posterior and six
+ * prior-only chains on the 7-taxon mtCDNApri analysis (bench/comparison_with_mcmctree/03_compare_estimates/*_samples_run*.tsv).
+ * tests/test_reference_samples.py runs THIS twin (with mvn_oracle.c and prior_oracle.c underneath) on the same inputs, no GPU
+ * involved: all six ages within 1 % of the reference's pooled means in both analyses -- the prior-only one with the root bound
+ * the samples carry (30, not the committed file's 100: see that test) --, quantiles, standard deviations, correlations.
+ * Single steps remain unpinned (the reference holds no expected outputs for one proposal and cannot be run here); what
+ * pins them: Philox4x32-10 known answer (Random123 kat vector), scipy.stats.truncnorm / scipy.stats.gamma for the
+ * distributions, detailed-balance identities (tests/test_mh_oracle.py).
  *
  * Random numbers are COUNTER BASED so that the device driver reproduces them exactly:
  *   block(seed, chain, step, d) = Philox4x32-10(counter = (d, chain, step_lo, step_hi), key = (seed_lo, seed_hi));

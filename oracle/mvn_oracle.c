@@ -16,9 +16,11 @@
  * ddot (third-party, not vendored; version fixed only through stack.yaml:1 lts-21.22),
  * whose summation order is unspecified; parity is therefore to an fp64 tolerance.
  * (What the reference does commit are node ages SAMPLED with this likelihood -- the posterior runs of its mtCDNApri analysis.
- * The device sampler, whose likelihood values these functions check, reproduces them to 0.5 % on every node:
- * tests/test_gpu_mh.py::test_posterior_node_ages_against_the_references_own_samples.  That pins the path end to end, through
- * the sampler; single values of this file stay unpinned.)
+ * Since round 3 the CPU twin built on THESE functions (oracle/mh_oracle.c) reproduces them without a GPU, all six node ages
+ * within 0.5 % of the reference's means: tests/test_reference_samples.py::test_twin_reproduces_the_references_posterior_samples;
+ * the device sampler likewise, tests/test_gpu_mh.py::test_posterior_node_ages_against_the_references_own_samples.  That pins
+ * the path end to end, through a sampler -- a constant offset of ln likelihood would go unnoticed there, so single VALUES of this
+ * file stay unpinned.)
  *
  * Tree representation used throughout: nodes are numbered in PRE-ORDER (root = 0, a node
  * before its children, children left to right), which is the order of elynx-tree's

@@ -79,6 +79,19 @@ static int sampler_mode(const char* path)
         const Vec alpha = nuts.run(2, 4);
         const I xn = nuts.state(batch - 1);
         std::printf("nuts %d %.17g %.17g %.17g %.17g\n", nuts.dim(), alpha[0], alpha[batch - 1], xn.timeHeight, xn.timeTree[1]);
+        // step sizes and masses tuned in the library (mcd_hmc_nuts_warmup): one window of 6 transitions + the closing window
+        nuts.warmup(1, 6, 0.65, 4);
+        std::printf("warmup %.17g %.17g %.17g %.17g\n", nuts.stepSizes()[0], nuts.stepSizes()[batch - 1], nuts.inverseMasses()[0],
+                    nuts.inverseMasses()[nuts.dim() - 1]);
+    }
+    // the swap phase of Metropolis-coupled MCMC through the mirror (mcd_mh_mc3_init / mcd_mh_mc3_swap): groups of two chains
+    if (batch % 2 == 0) {
+        smp.mc3Init(2, Vec{1.0, 0.3}, 99);
+        smp.mc3Swap(1);
+        smp.mc3Swap(1);
+        std::printf("mc3");
+        for (int32_t r : smp.mc3Ranks()) std::printf(" %d", (int)r);
+        std::printf("\n");
     }
     std::mt19937_64 rng(1);
     const auto cyc = cycleSchedule(ps, 2, rng);
