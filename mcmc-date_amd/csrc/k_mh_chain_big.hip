@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     for (int w = lane; w < nn; w += 64) {
         Hc[w] = M.H[b * M.ld + w];
         Rc[w] = M.R[b * M.ld + w];
-        Hp[w] = 0.0;
-        Rp[w] = 0.0;
+        Hp[w] = Hc[w];                                       // invariant between steps: proposed arrays = current arrays
+        Rp[w] = Rc[w];
     }
     for (int i = lane; i < NP; i += 64) {
         tune[i] = M.tune[b * NP + i];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     const double beta = M.beta[b];
 #ifdef MCD_MHB_STAMP
     // diagnostic build (make stamp_mhbig): s_memtime ticks per phase, summed over the run, in the first rows of trace_alpha
-    uint64_t tk[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ... 6: column update of sparse steps (4: sweep of dense steps), 7: number of sparse steps, 8: the draws of 64 steps, 9: distances alone
 #define MHB_TICK(i)                                       \
     {                                                     \
         const uint64_t now_ = __builtin_readcyclecounter(); \
@@ -225,6 +225,23 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 #else
 #define MHB_TICK(i)
 #endif
+    // The nodes a proposal writes (PropApply: up to three pre-order ranges, five single nodes, the braced nodes with their
+    // daughters): f(w) for each of them, lanes in parallel (a node may come twice).  Between steps the proposed arrays equal the
+    // current ones, so a step applies, commits or takes back its proposal on these nodes only -- most proposals write one to
+    // three nodes of the 257, and the copies over all nodes were a fifth of the proposal and most of the accept phase.
+    auto for_write_set = [&](const PropApply& A, auto&& f) {
+        for (int w = A.hlo + lane; w < A.hhi; w += 64) f(w);
+        for (int w = A.hlo2 + lane; w < A.hhi2; w += 64) f(w);
+        if (A.rlo != A.hlo || A.rhi != A.hhi)
+            for (int w = A.rlo + lane; w < A.rhi; w += 64) f(w);
+        const int pt = (lane == 0) ? A.pt1 : (lane == 1) ? A.pt2 : (lane == 2) ? A.rp1 : (lane == 3) ? A.rp2 : (lane == 4) ? A.rp3 : -1;
+        if (pt >= 0) f(pt);
+        for (int i = A.brace_lo; i < A.brace_hi; ++i) {
+            const int x = M.brace_nodes[i];
+            const int w = (lane == 0) ? x : (lane == 1 && tb_nch[x] > 0) ? tb_first[x] : (lane == 2 && tb_nch[x] > 1) ? tb_second[x] : -1;
+            if (w >= 0) f(w);
+        }
+    };
     int p = sched[0];
     PropRow row = mh_load_row(M, p);
     int row_sparse = inc ? M.sparse[p] : 0;
@@ -237,11 +254,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
             // parameter (as k_mh_chain.hip, and as k_mh_draws does for the two-launch path)
+            MHB_TICK(0)
             const int64_t mine = gs + lane;
             if (mine < n_steps) {
                 const int pl = sched[mine];
                 pre = mh_step_draws(mh_load_row(M, pl), tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
             }
+            MHB_TICK(8)
         }
         const int sl = (int)(gs & 63);
         const StepDraws dr{mh_readlane64(pre.u, sl), mh_readlane64(pre.lnq, sl), mh_readlane64(pre.logu, sl), mh_readlane64(pre.U, sl),
@@ -250,7 +269,15 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
         MHB_TICK(0)
-        const double lnqj = mh_propose_wave(Ml, row, tune[p], dr, lane, sc1, Hc, Rc, Hp, Rp);
+        PropApply A;
+        const double lnqj = mh_propose_params(Ml, row, tune[p], dr, lane, sc1, Hc, Rc, A);
+        for_write_set(A, [&](int w) {
+            double h, r;
+            mh_propose_node(Ml, A, w, Hc, Rc, h, r);
+            Hp[w] = h;
+            Rp[w] = r;
+        });
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the writes above have landed before any lane reads them
         __builtin_amdgcn_wave_barrier();
         MHB_TICK(1)
         // distances of the proposed state; for a sparse row: which of them moved, and the first columns of L^-1 on their way
@@ -293,6 +320,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         if (moves) {
             const double dist0 = distances(Hp, Rp, sc1[2] * sc1[3], vp);
             lj1 = log(1.0 / readlane64(dist0, 0));          // jacobianRootBranch, :393-410
+            MHB_TICK(9)
             if (sparse_step) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -303,13 +331,9 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             }
         }
         MHB_TICK(3)
-        bool dH = false, dR = false;
-        for (int w0 = 0; w0 < nn; w0 += 64) {
-            const int w = w0 + lane;
-            const bool in = w < nn;
-            dH = dH || (__builtin_amdgcn_ballot_w64(in && Hp[in ? w : 0] != Hc[in ? w : 0]) != 0);     // NaN != NaN: re-evaluated
-            dR = dR || (__builtin_amdgcn_ballot_w64(in && Rp[in ? w : 0] != Rc[in ? w : 0]) != 0);
-        }
+        // which arrays the proposal writes (a superset of "changed": a block re-evaluated on unchanged inputs returns the same bits)
+        const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
+        const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
         ClockCache ccp = cc;                                 // refreshed only if the proposal moved rVar
         const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
         const double c1p = (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) ? prior_bd_wave(Pl, lane, sc1[0], sc1[1], Hp) : c1;
@@ -341,15 +365,17 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             const double q = sweep(vp, zp);
             ll1 = V.c + (-0.5) * (V.logdet + q);             // :169 (finish_ll)
         }
-        MHB_TICK(4)
+#ifdef MCD_MHB_STAMP
+        if (sparse_step) { MHB_TICK(6) tk[7] += 1; } else { MHB_TICK(4) }
+#endif
         double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
         if (row.jac_root) la += (double)row.jac_root * (lj1 - lj);
         const bool ok = (la >= 0) || (dr.Uacc < exp(la));
         if (ok) {
-            for (int w = lane; w < nn; w += 64) {
+            for_write_set(A, [&](int w) {
                 Hc[w] = Hp[w];
                 Rc[w] = Rp[w];
-            }
+            });
 #pragma unroll
             for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
             c0 = c0p;
@@ -366,6 +392,12 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                     dcur[k] = vp[k];
                 }
             }
+        }
+        if (!ok) {
+            for_write_set(A, [&](int w) {
+                Hp[w] = Hc[w];
+                Rp[w] = Rc[w];
+            });
         }
         if (lane == 0) {
             tried[p] += 1;
@@ -394,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     }
 #ifdef MCD_MHB_STAMP
     if (trace_alpha && lane == 0 && valid)
-        for (int i = 0; i < 6; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // ticks: loop head, propose, prior, distances + column requests, sweep or column update, accept
+        for (int i = 0; i < 10; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // ticks: loop head, propose, prior, distances + column requests, sweep or column update, accept
 #endif
     if (!valid) return;
 #pragma unroll

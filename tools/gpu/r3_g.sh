@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03
+timeout -k 10 600 python -m pytest tests/test_gpu_mh.py -q -m gpu -x -k "streaming or large_tree or lockstep_parity or rejects" > gpurun_out/r03/g_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03/g_tests.log
+tail -5 gpurun_out/r03/g_tests.log
+for cfg in "40 512" "70 512" "129 512" "129 1024"; do
+  set -- $cfg
+  timeout -k 10 120 python tools/bench_mh_large.py $1 $2 8000 2>&1 | tail -1
+done | tee gpurun_out/r03/g_timing.jsonl
+timeout -k 10 120 python tools/microbench/mhbig_stamps.py 256 512 8000 > gpurun_out/r03/g_mhbig_stamps.txt 2>&1
+cat gpurun_out/r03/g_mhbig_stamps.txt

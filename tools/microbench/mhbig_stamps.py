@@ -28,8 +28,11 @@ smp.run_schedule(sched[:, :200])
 t0 = time.perf_counter()
 ta, _ = smp.run_schedule(sched, trace=True)
 dt = time.perf_counter() - t0
-tk = ta[:6].mean(axis=1)
+tk = ta[:10].mean(axis=1)
+n_sparse = tk[7]
+tk = np.concatenate([tk[:7], tk[8:10]])
 print("us per lock step %.2f (n_nodes %d, chains %d; with tracing)" % (1e6 * dt / steps, topo.n_nodes, B))
-names = ["loop head", "propose", "prior", "distances", "barrier + sweep", "accept"]
+names = ["loop head", "propose", "prior", "distances + column requests", "barrier + sweep (dense steps)", "accept", "column update (sparse steps)", "draws of 64 steps (per step)", "distances + ln Jacobian"]
+print("  sparse steps: %.1f %% of %d" % (100 * n_sparse / steps, steps))
 for nm, v in zip(names, tk):
-    print("  %-16s %5.1f %%   (%.0f ticks per step)" % (nm, 100 * v / tk.sum(), v / steps))
+    print("  %-30s %5.1f %%   (%.0f ticks per step)" % (nm, 100 * v / tk.sum(), v / steps))
