@@ -47,7 +47,9 @@ __device__ __forceinline__ bool mhb_moves_likelihood(int kind, int node)
 }
 
 // LDS per chain (doubles): 4 state rows, tuning parameters, counters (two int32 per double)
-__host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int n_prop) { return 4 * (size_t)n_nodes + 2 * (size_t)n_prop; }
+// (+ round 3: the per-node summands of the birth-death and the clock block of the ln prior, current and proposed, with the step
+// that wrote the proposed one: 4 n_nodes doubles + 2 n_nodes int32)
+__host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int n_prop) { return 9 * (size_t)n_nodes + 2 * (size_t)n_prop + 1; }
 // ... and per workgroup: the tree tables (five int32 arrays of n_nodes, rounded up to doubles)
 __host__ __device__ inline size_t mhb_table_doubles(int n_nodes) { return (5 * (size_t)n_nodes + 1) / 2 + 1; }
 
@@ -133,7 +135,15 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     double* tune = Rp + nn;
     int32_t* acc = reinterpret_cast<int32_t*>(tune + NP);
     int32_t* tried = acc + NP;
+    double* tbd_cur = tune + 2 * NP;                         // summand of node v in the birth-death block, current state
+    double* tbd_prop = tbd_cur + nn;                         // ... proposed state, valid where stamp_bd[v] = this step
+    double* tcl_cur = tbd_prop + nn;                         // the same for the clock block
+    double* tcl_prop = tcl_cur + nn;
+    int32_t* stamp_bd = reinterpret_cast<int32_t*>(tcl_prop + nn);
+    int32_t* stamp_cl = stamp_bd + nn;
     for (int w = lane; w < nn; w += 64) {
+        stamp_bd[w] = 0;
+        stamp_cl[w] = 0;
         Hc[w] = M.H[b * M.ld + w];
         Rc[w] = M.R[b * M.ld + w];
         Hp[w] = Hc[w];                                       // invariant between steps: proposed arrays = current arrays
@@ -152,9 +162,34 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     __builtin_amdgcn_wave_barrier();
     // the three blocks of the ln prior of the current state; a step re-evaluates only the blocks whose inputs moved
     double c0 = prior_nodes_wave(Pl, lane, sc[2], Hc);
-    double c1 = prior_bd_wave(Pl, lane, sc[0], sc[1], Hc);
+    // The birth-death and the clock block are sums of one summand per node (prior_device.hpp: prior_bd_term, prior_clock_term).  The
+    // summands of the current state are kept; a proposal that writes a few nodes re-evaluates the summands of those nodes (and,
+    // for the birth-death block, of their daughters) in ONE pass with the nodes compacted onto the first lanes, and the sum is
+    // taken over kept and new summands in the order of the full evaluation: the same function values added in the same order, the
+    // same bits as prior_bd_wave / prior_clock_wave -- at one summand's latency instead of four pipelined ones.
+    auto bd_full = [&](double la_, double mu_, const double* Hx, double* store) -> double {
+        const bool near = prior_bd_near(la_, mu_);
+        double bd = 0.0;
+        for (int v = 1 + lane; v < nn; v += 64) {
+            const double t = prior_bd_term(Pl, v, near, la_, mu_, Hx);
+            store[v] = t;
+            bd += t;
+        }
+        return prior_bd_finish(pr_wave_sum(bd), la_, mu_);
+    };
+    auto clock_full = [&](double rm_, double va_, const double* Hx, const double* Rx, ClockCache& c, double* store) -> double {
+        if (c.va != va_) prior_clock_scalars(va_, c);
+        double cl = 0.0;
+        for (int v = 1 + lane; v < nn; v += 64) {
+            const double t = prior_clock_term(Pl, v, va_, c.lg_k, c.log_t, Hx, Rx);
+            store[v] = t;
+            cl += t;
+        }
+        return prior_clock_finish(Pl, pr_wave_sum(cl), rm_, va_, c.hyper);
+    };
+    double c1 = bd_full(sc[0], sc[1], Hc, tbd_cur);
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
-    double c2 = prior_clock_wave(Pl, lane, sc[3], sc[4], Hc, Rc, &cc);
+    double c2 = clock_full(sc[3], sc[4], Hc, Rc, cc, tcl_cur);
     double lp = c0 + c1 + c2;
     // rows 64 k + lane of the solve: mean, 1 / L_ii, the node whose branch feeds the distance slot and that node's parent
     double mu_r[R], iv_r[R];
@@ -336,9 +371,75 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
         ClockCache ccp = cc;                                 // refreshed only if the proposal moved rVar
         const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
-        const double c1p = (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) ? prior_bd_wave(Pl, lane, sc1[0], sc1[1], Hp) : c1;
-        const double c2p = (dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2))
-                               ? prior_clock_wave(Pl, lane, sc1[3], sc1[4], Hp, Rp, &ccp) : c2;
+        const int st = (int)(gs + 1);                        // this step's mark on proposed summands
+        const int nbr = A.brace_hi - A.brace_lo;
+        // candidate l of the birth-death block: the nodes whose height the proposal writes, with their daughters (a range is a sub
+        // tree without its root: closed under "daughter of"); -1 = none
+        const int len1 = A.hhi > A.hlo ? A.hhi - A.hlo : 0, len2 = A.hhi2 > A.hlo2 ? A.hhi2 - A.hlo2 : 0;
+        auto cand_bd = [&](int l) -> int {
+            if (l < len1) return A.hlo + l;
+            l -= len1;
+            if (l < len2) return A.hlo2 + l;
+            l -= len2;
+            const int g = l / 3, r = l - 3 * g;
+            int base = -1;
+            if (g == 0) base = A.pt1; else if (g == 1) base = A.pt2; else if (g - 2 < nbr) base = M.brace_nodes[A.brace_lo + g - 2];
+            if (base < 0) return -1;
+            if (r == 0) return base;
+            return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+        };
+        const int cnt_bd = len1 + len2 + 3 * (2 + nbr);
+        // ... of the clock block (uncorrelated models: a summand depends on its node's rate only): the nodes whose rate is written
+        const int lenr = A.rhi > A.rlo ? A.rhi - A.rlo : 0;
+        const int nbr_r = (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA) ? nbr : 0;
+        auto cand_cl = [&](int l) -> int {
+            if (l < lenr) return A.rlo + l;
+            l -= lenr;
+            if (l < 3) return l == 0 ? A.rp1 : l == 1 ? A.rp2 : A.rp3;
+            l -= 3;
+            const int g = l / 3, r = l - 3 * g;
+            if (g >= nbr_r) return -1;
+            const int base = M.brace_nodes[A.brace_lo + g];
+            if (r == 0) return base;
+            return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+        };
+        const int cnt_cl = lenr + 3 + 3 * nbr_r;
+        const bool bd_scalars = sc1[0] != sc[0] || sc1[1] != sc[1];
+        const bool need_bd = dH || bd_scalars;
+        const bool few_bd = need_bd && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
+        double c1p = c1;
+        if (few_bd) {
+            const int v = cand_bd(lane);
+            if (lane < cnt_bd && v >= 1) {
+                tbd_prop[v] = prior_bd_term(Pl, v, false, sc1[0], sc1[1], Hp);
+                stamp_bd[v] = st;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            double bd = 0.0;
+            for (int w = 1 + lane; w < nn; w += 64) bd += (stamp_bd[w] == st) ? tbd_prop[w] : tbd_cur[w];
+            c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+        } else if (need_bd) {
+            c1p = bd_full(sc1[0], sc1[1], Hp, tbd_prop);
+        }
+        const bool cl_heights = dH && P.clock_model >= 2;    // white noise / autocorrelated: the summands also hold branch durations
+        const bool need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
+        const bool few_cl = need_cl && sc1[4] == sc[4] && P.clock_model < 2 && cnt_cl <= 64;
+        double c2p = c2;
+        if (few_cl) {
+            const int v = cand_cl(lane);
+            if (lane < cnt_cl && v >= 1) {
+                tcl_prop[v] = prior_clock_term(Pl, v, sc1[4], cc.lg_k, cc.log_t, Hp, Rp);
+                stamp_cl[v] = st;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            double cl = 0.0;
+            for (int w = 1 + lane; w < nn; w += 64) cl += (stamp_cl[w] == st) ? tcl_prop[w] : tcl_cur[w];
+            c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
+        } else if (need_cl) {
+            c2p = clock_full(sc1[3], sc1[4], Hp, Rp, ccp, tcl_prop);
+        }
         const double lp1 = c0p + c1p + c2p;
         MHB_TICK(2)
         double ll1 = ll;
@@ -378,6 +479,18 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             });
 #pragma unroll
             for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
+            if (few_bd) {
+                const int v = cand_bd(lane);
+                if (lane < cnt_bd && v >= 1) tbd_cur[v] = tbd_prop[v];
+            } else if (need_bd) {
+                for (int w = 1 + lane; w < nn; w += 64) tbd_cur[w] = tbd_prop[w];
+            }
+            if (few_cl) {
+                const int v = cand_cl(lane);
+                if (lane < cnt_cl && v >= 1) tcl_cur[v] = tcl_prop[v];
+            } else if (need_cl) {
+                for (int w = 1 + lane; w < nn; w += 64) tcl_cur[w] = tcl_prop[w];
+            }
             c0 = c0p;
             c1 = c1p;
             c2 = c2p;
