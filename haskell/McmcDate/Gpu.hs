@@ -17,6 +17,11 @@ module McmcDate.Gpu
     withGpuLikelihood,
     likelihoodFunctionGpu,
     jacobianRootBranchGpu,
+    -- * The sparse form (precision matrix kept sparse on the device, N up to 8192)
+    McdSparse,
+    McdSparseTree,
+    withGpuSparseLikelihood,
+    likelihoodFunctionGpuSparse,
     -- * Batched prior and lock-step Metropolis-Hastings driver (raw bindings)
     McdPrior,
     McdMh,
@@ -172,6 +177,66 @@ likelihoodFunctionGpu ht = Exp . fst . evalState ht
 -- | Drop-in for 'jacobianRootBranch' (app/Probability.hs:408-410).
 jacobianRootBranchGpu :: ForeignPtr McdTree -> JacobianFunction I
 jacobianRootBranchGpu ht = Exp . snd . evalState ht
+
+-- The sparse form: the precision matrix stays sparse on the device (mcd_sparse_*), any N up to 8192 -- the reference's route for
+-- trees with thousands of branches.
+data McdSparse
+
+data McdSparseTree
+
+foreign import ccall unsafe "mcd_sparse_create"
+  c_sparse_create :: Ptr (Ptr McdSparse) -> CInt -> Ptr CDouble -> Int64 -> Ptr Int32 -> Ptr Int32 -> Ptr CDouble -> CDouble -> CInt -> IO CInt
+
+foreign import ccall unsafe "&mcd_sparse_destroy"
+  p_sparse_destroy :: FunPtr (Ptr McdSparse -> IO ())
+
+foreign import ccall unsafe "mcd_sparse_tree_create"
+  c_sparse_tree_create :: Ptr (Ptr McdSparseTree) -> Ptr McdSparse -> CInt -> Ptr Int32 -> IO CInt
+
+foreign import ccall unsafe "&mcd_sparse_tree_destroy"
+  p_sparse_tree_destroy :: FunPtr (Ptr McdSparseTree -> IO ())
+
+foreign import ccall unsafe "mcd_sparse_tree_loglik_batch"
+  c_sparse_tree_loglik ::
+    Ptr McdSparseTree -> Ptr CDouble -> Ptr CDouble -> Int64 -> Ptr CDouble -> Ptr CDouble -> Int64 -> CInt -> Ptr () -> Ptr CDouble ->
+    Ptr CDouble -> IO CInt
+
+-- | Stage the operands of @Sparse mu sigmaInvSparse logDetSigma@ (the association list of the .data file's SparseS record,
+-- app/Main.hs:95-97, 142-155) and bind the topology; replaces the Sparse branch of 'getLikelihoodFunction'.
+withGpuSparseLikelihood ::
+  Int -> L.Vector Double -> [((Int, Int), Double)] -> Double -> T.Tree e a -> IO (ForeignPtr McdSparse, ForeignPtr McdSparseTree)
+withGpuSparseLikelihood dev mu assoc logDetSigma tr = do
+  let n = VS.length mu
+      is = VS.fromList [fromIntegral i | ((i, _), _) <- assoc] :: VS.Vector Int32
+      js = VS.fromList [fromIntegral j | ((_, j), _) <- assoc] :: VS.Vector Int32
+      vs = VS.fromList [realToFrac v | (_, v) <- assoc] :: VS.Vector CDouble
+  hs <- alloca $ \pp -> do
+    rc <- VS.unsafeWith (VS.map realToFrac mu) $ \pmu -> VS.unsafeWith is $ \pis -> VS.unsafeWith js $ \pjs -> VS.unsafeWith vs $ \pvs ->
+      c_sparse_create pp (fromIntegral n) pmu (fromIntegral (VS.length vs)) pis pjs pvs (realToFrac logDetSigma) (fromIntegral dev)
+    check "mcd_sparse_create" rc
+    peek pp >>= newForeignPtr p_sparse_destroy
+  ht <- withForeignPtr hs $ \m -> alloca $ \pp -> do
+    let ps = VS.fromList (parents tr)
+    rc <- VS.unsafeWith ps $ \pps -> c_sparse_tree_create pp m (fromIntegral (VS.length ps)) pps
+    check "mcd_sparse_tree_create" rc
+    peek pp >>= newForeignPtr p_sparse_tree_destroy
+  pure (hs, ht)
+
+-- | Drop-in for @likelihoodFunction (Sparse mu sigmaInvSparse logDetSigma)@ (app/Probability.hs:279, 178-184).
+likelihoodFunctionGpuSparse :: ForeignPtr McdSparseTree -> LikelihoodFunction I
+likelihoodFunctionGpuSparse ht x = Exp $ unsafePerformIO $
+  withForeignPtr ht $ \t ->
+    VS.unsafeWith hs $ \ph -> VS.unsafeWith rs $ \pr ->
+      with (realToFrac (x ^. timeHeight)) $ \pth -> with (realToFrac (x ^. rateMean)) $ \prm ->
+        alloca $ \pll -> do
+          rc <- c_sparse_tree_loglik t ph pr (fromIntegral nn) pth prm 1 0 nullPtr pll nullPtr
+          check "mcd_sparse_tree_loglik_batch" rc
+          realToFrac <$> peek pll
+  where
+    hs = VS.fromList $ map realToFrac $ T.branches $ getHeightTree (x ^. timeTree)
+    rs = VS.fromList $ map realToFrac $ T.branches $ getLengthTree (x ^. rateTree)
+    nn = VS.length hs
+{-# NOINLINE likelihoodFunctionGpuSparse #-}
 
 
 -- ---------------------------------------------------------------------------------------------------------------

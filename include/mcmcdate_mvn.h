@@ -377,6 +377,36 @@ int mcd_mh_get_age_sums(const mcd_mh_t* m, double* age_sum, double* age_sq, int6
 int mcd_mh_reset_age_sums(mcd_mh_t* m);
 
 /* ------------------------------------------------------------------------------------------------
+ * The sparse form: the precision matrix as it is, in CSR on the device, no densification; N up to MCD_MAX_SPARSE_DIM.
+ * Replaces: logDensitySparseMultivariateNormal (app/Probability.hs:178-184) and the closure likelihoodFunction (Sparse mu
+ * sigmaInvSparse logDetSigma) (:279) over the operands of getData's SparseS branch (app/Main.hs:95-97: the association list
+ * [((i, j), v)] of `prepare`'s graphical-lasso estimate, :142-155, 257-277) -- the reference's route for trees with thousands
+ * of branches (tutorial/main/tutorial.org:487-496), beyond MCD_MAX_DIM of the dense kernels.
+ *   ll = -N ln sqrt(2 pi) - 1/2 (logdet_sigma + dx^T P dx),  dx = x - mu;   mcd_sparse_grad_batch also returns G = -P dx.
+ * row / col / val: the nnz entries in any order, entries of one position are added up; P is used as given (no symmetrisation,
+ * no positive-definiteness check: the reference evaluates the form with whatever the .data file holds).  Batches are chain-major
+ * like everywhere; trees as in mcd_tree_create.  (mcd_mvn_create with a densified matrix remains the route to the gradient of
+ * tree states and to the Metropolis-Hastings / NUTS drivers, N <= MCD_MAX_DIM.)
+ */
+#define MCD_MAX_SPARSE_DIM 8192
+typedef struct mcd_sparse mcd_sparse_t;
+typedef struct mcd_sparse_tree mcd_sparse_tree_t;
+int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, const int32_t* row, const int32_t* col, const double* val,
+                      double logdet_sigma, int device_id);
+void mcd_sparse_destroy(mcd_sparse_t* h);
+int mcd_sparse_dim(const mcd_sparse_t* h);
+int64_t mcd_sparse_nnz(const mcd_sparse_t* h);   /* stored entries after adding up duplicates */
+int mcd_sparse_logpdf_batch(const mcd_sparse_t* h, const double* X, int64_t ld, int64_t batch, int on_device, void* stream, double* ll);
+int mcd_sparse_grad_batch(const mcd_sparse_t* h, const double* X, int64_t ld, int64_t batch, int on_device, void* stream, double* ll,
+                          double* G, int64_t ldg);
+/* State -> ln likelihood (likelihoodFunctionWrapper, app/Probability.hs:195-207) and ln jacobianRootBranch (:393-410) over a sparse
+ * precision matrix; arguments as mcd_tree_loglik_batch. */
+int mcd_sparse_tree_create(mcd_sparse_tree_t** out, const mcd_sparse_t* h, int n_nodes, const int32_t* parent);
+void mcd_sparse_tree_destroy(mcd_sparse_tree_t* t);
+int mcd_sparse_tree_loglik_batch(const mcd_sparse_tree_t* t, const double* heights, const double* rates, int64_t ld_state, const double* tH,
+                                 const double* rMu, int64_t batch, int on_device, void* stream, double* ll, double* log_jac);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-GPU.  Chains are independent: every rank (one process per GPU) holds the operands and evaluates its own
  * contiguous block of chains; nothing is exchanged on the likelihood path.  The sampler-level exchange -- the per-chain ln
  * posterior that MC3's swap phase compares (`mc3 (MC3Settings (NChains 4) (SwapPeriod 2) (NSwaps 3))`, app/Main.hs:476-478; in

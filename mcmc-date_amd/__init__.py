@@ -6,7 +6,7 @@ One hot path, hand-written for gfx950, behind the reference's likelihood plugin 
 """
 from . import _capi, monitor
 from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating
-from .likelihood import (Full, LikelihoodData, MvnLikelihood, set_logpdf_form, NoData, Sparse, TreeLikelihood, Univariate,
+from .likelihood import (Full, LikelihoodData, MvnLikelihood, set_logpdf_form, NoData, Sparse, SparseLikelihood, SparseTreeLikelihood, TreeLikelihood, Univariate,
                          jacobian_root_branch, likelihood_function, read_data_file, write_data_file)
 from .hmc import DualAveraging, Leapfrog, hmc_transition, nuts_transition, nuts_warmup, run_cycle_with_nuts
 from .hamiltonian import from_vector_with, get_mask, grad_to_vector, target_grad, to_vector
@@ -18,7 +18,7 @@ from .tree import (Topology, TreeError, branch_slots, get_branches, height_tree_
                    read_newick_file, sum_first_two)
 
 __all__ = [
-    "Full", "Sparse", "Univariate", "NoData", "LikelihoodData", "MvnLikelihood", "TreeLikelihood",
+    "Full", "Sparse", "Univariate", "NoData", "LikelihoodData", "MvnLikelihood", "TreeLikelihood", "SparseLikelihood", "SparseTreeLikelihood",
     "likelihood_function", "jacobian_root_branch", "read_data_file", "write_data_file", "set_logpdf_form",
     "State", "StateBatch", "Topology", "TreeError", "parse_newick", "read_newick_file", "get_branches",
     "sum_first_two", "branch_slots", "height_tree_to_length_tree",

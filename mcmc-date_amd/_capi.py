@@ -55,6 +55,15 @@ SYMBOLS = {
     "mcd_prior_destroy": (None, [_vp]),
     "mcd_prior_logprior_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "mcd_prior_grad_batch": (C.c_int, [_vp] * 8 + [C.c_int64, C.c_int64, C.c_int, _vp] + [_vp] * 8),
+    "mcd_sparse_create": (C.c_int, [C.POINTER(_vp), C.c_int, _dp, C.c_int64, _ip, _ip, _dp, C.c_double, C.c_int]),
+    "mcd_sparse_destroy": (None, [_vp]),
+    "mcd_sparse_dim": (C.c_int, [_vp]),
+    "mcd_sparse_nnz": (C.c_int64, [_vp]),
+    "mcd_sparse_logpdf_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp]),
+    "mcd_sparse_grad_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int64]),
+    "mcd_sparse_tree_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, _ip]),
+    "mcd_sparse_tree_destroy": (None, [_vp]),
+    "mcd_sparse_tree_loglik_batch": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "mcd_hmc_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, C.c_int64]),
     "mcd_hmc_destroy": (None, [_vp]),
     "mcd_hmc_dim": (C.c_int, [_vp]),

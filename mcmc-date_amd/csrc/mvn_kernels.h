@@ -99,6 +99,28 @@ struct MhDev {
 };
 constexpr int kMhSparseSlots = 8;
 
+// The sparse form (k_sparse.hip): the precision matrix in CSR, any N up to kSparseMaxDim; all pointers are device memory.
+struct SparseDev {
+    int n;
+    int64_t nnz;
+    const int32_t* rowptr;   // [n + 1]
+    const int32_t* col;      // [nnz], ascending inside a row
+    const double* val;       // [nnz]
+    const double* mu;        // [n]
+    double c, logdet;        // -N ln sqrt(2 pi), log det Sigma
+};
+struct SparseTreeDev {
+    int n_nodes, root_right;
+    const int32_t* slot_node;     // [n] distance slot -> node (getBranches . sumFirstTwo order)
+    const int32_t* slot_parent;   // [n] that node's parent
+};
+constexpr int kSparseMaxDim = 8192;
+int sparse_tile_chains(int n);
+hipError_t launch_sparse_logpdf(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
+hipError_t launch_sparse_grad(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, hipStream_t st);
+hipError_t launch_sparse_tree_logpdf(const SparseDev& S, const SparseTreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
+                                     const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st);
+
 // Metropolis-coupled MCMC (k_mc3.hip): the temperature rank of every GLOBAL chain, the ladder of reciprocal temperatures and the
 // swap counters per rung; all pointers are device memory.
 struct Mc3Dev {

@@ -1,0 +1,272 @@
+// sparse_capi.cpp -- the C ABI of the sparse form (include/mcmcdate_mvn.h: mcd_sparse_*) on top of k_sparse.hip.
+// Replaces: likelihoodFunction (Sparse mu sigmaInvSparse logDetSigma) (app/Probability.hs:279, 178-184) with the operands
+// of getData's SparseS branch (app/Main.hs:95-97).  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <memory>
+#include <numeric>
+#include <vector>
+
+#include "../../include/mcmcdate_mvn.h"
+#include "mvn_kernels.h"
+
+extern "C" int mcd_set_last_error_(int code, const char* msg);
+
+namespace {
+
+int sfail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return mcd_set_last_error_(code, buf);
+}
+
+#define SHIP_TRY(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return sfail(MCD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+}  // namespace
+
+struct mcd_sparse {
+    int n = 0, device = 0;
+    mcd::SparseDev dev{};
+    std::vector<void*> allocs;
+    ~mcd_sparse()
+    {
+        (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+    }
+};
+
+struct mcd_sparse_tree {
+    const mcd_sparse* sp = nullptr;
+    mcd::SparseTreeDev dev{};
+    int32_t* d_slot = nullptr;
+    ~mcd_sparse_tree()
+    {
+        if (sp) (void)hipSetDevice(sp->device);
+        if (d_slot) (void)hipFree(d_slot);
+    }
+};
+
+namespace {
+
+template <class T>
+int upload(mcd_sparse* h, const T** dst, const T* src, size_t count)
+{
+    T* d = nullptr;
+    SHIP_TRY(hipMalloc((void**)&d, sizeof(T) * (count ? count : 1)));
+    h->allocs.push_back(d);
+    if (count) SHIP_TRY(hipMemcpy(d, src, sizeof(T) * count, hipMemcpyHostToDevice));
+    *dst = d;
+    return MCD_OK;
+}
+
+// host arrays through a temporary device buffer on a stream of the call's own (host-pointer entry points: copy, run, copy)
+struct Scratch {
+    hipStream_t st = nullptr;
+    std::vector<void*> bufs;
+    ~Scratch()
+    {
+        for (void* p : bufs) (void)hipFree(p);
+        if (st) (void)hipStreamDestroy(st);
+    }
+    double* alloc(size_t doubles)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, sizeof(double) * (doubles ? doubles : 1)) != hipSuccess) return nullptr;
+        bufs.push_back(p);
+        return (double*)p;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, const int32_t* row, const int32_t* col, const double* val,
+                      double logdet_sigma, int device_id)
+{
+    if (!out) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_create: out is NULL");
+    *out = nullptr;
+    if (n < 1 || n > mcd::kSparseMaxDim) return sfail(MCD_ERR_UNSUPPORTED, "mcd_sparse_create: dimension %d not in 1 .. %d", n, mcd::kSparseMaxDim);
+    if (!mu || nnz < 0 || (nnz > 0 && (!row || !col || !val))) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_create: NULL argument");
+    if (!std::isfinite(logdet_sigma)) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_create: logdet_sigma is not finite");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sfail(MCD_ERR_NO_DEVICE, "mcd_sparse_create: no HIP device (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_create: device %d of %d", device_id, ndev);
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(mu[i])) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_create: mu[%d] is not finite", i);
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (row[k] < 0 || row[k] >= n || col[k] < 0 || col[k] >= n) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_create: entry %lld (%d, %d) outside the matrix", (long long)k, row[k], col[k]);
+        if (!std::isfinite(val[k])) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_create: entry %lld is not finite", (long long)k);
+    }
+    // association list -> CSR (L.mkSparse, app/Main.hs:95): sorted by (row, column), entries of one position added up
+    std::vector<int64_t> order((size_t)nnz);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return row[a] != row[b] ? row[a] < row[b] : col[a] < col[b]; });
+    std::vector<int32_t> rowptr((size_t)n + 1, 0), cc;
+    std::vector<double> vv;
+    for (size_t q = 0; q < order.size(); ++q) {
+        const int64_t k = order[q];
+        if (q > 0 && row[order[q - 1]] == row[k] && col[order[q - 1]] == col[k]) {
+            vv.back() += val[k];
+            continue;
+        }
+        cc.push_back(col[k]);
+        vv.push_back(val[k]);
+        rowptr[(size_t)row[k] + 1] += 1;
+    }
+    for (int i = 0; i < n; ++i) rowptr[(size_t)i + 1] += rowptr[(size_t)i];
+    if (mcd::sparse_tile_chains(n) == 0) return sfail(MCD_ERR_UNSUPPORTED, "mcd_sparse_create: dimension %d does not fit a CU's LDS", n);
+    std::unique_ptr<mcd_sparse> h(new mcd_sparse());
+    h->n = n;
+    h->device = device_id;
+    SHIP_TRY(hipSetDevice(device_id));
+    int rc = MCD_OK;
+    if ((rc = upload(h.get(), &h->dev.rowptr, rowptr.data(), rowptr.size())) || (rc = upload(h.get(), &h->dev.col, cc.data(), cc.size())) ||
+        (rc = upload(h.get(), &h->dev.val, vv.data(), vv.size())) || (rc = upload(h.get(), &h->dev.mu, mu, (size_t)n)))
+        return rc;
+    h->dev.n = n;
+    h->dev.nnz = (int64_t)vv.size();
+    h->dev.c = -(0.9189385332046727417803297364056176 * (double)n);   // m_ln_sqrt_2_pi * k, Probability.hs:181-183
+    h->dev.logdet = logdet_sigma;
+    *out = h.release();
+    return MCD_OK;
+}
+
+void mcd_sparse_destroy(mcd_sparse_t* h) { delete h; }
+int mcd_sparse_dim(const mcd_sparse_t* h) { return h ? h->n : sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_dim: NULL handle"); }
+int64_t mcd_sparse_nnz(const mcd_sparse_t* h) { return h ? h->dev.nnz : (int64_t)sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_nnz: NULL handle"); }
+
+int mcd_sparse_logpdf_batch(const mcd_sparse_t* h, const double* X, int64_t ld, int64_t batch, int on_device, void* stream, double* ll)
+{
+    if (!h) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_logpdf_batch: NULL handle");
+    if (batch < 0 || ld < h->n) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_logpdf_batch: need batch >= 0 and ld >= n");
+    if (batch == 0) return MCD_OK;
+    if (!X || !ll) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_logpdf_batch: NULL data pointer");
+    SHIP_TRY(hipSetDevice(h->device));
+    if (on_device) {
+        SHIP_TRY(mcd::launch_sparse_logpdf(h->dev, X, ld, batch, ll, (hipStream_t)stream));
+        return MCD_OK;
+    }
+    Scratch s;
+    SHIP_TRY(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    double* dX = s.alloc((size_t)batch * h->n);
+    double* dll = s.alloc((size_t)batch);
+    if (!dX || !dll) return sfail(MCD_ERR_HIP, "mcd_sparse_logpdf_batch: out of device memory");
+    SHIP_TRY(hipMemcpy2DAsync(dX, sizeof(double) * h->n, X, sizeof(double) * ld, sizeof(double) * h->n, (size_t)batch, hipMemcpyHostToDevice, s.st));
+    SHIP_TRY(mcd::launch_sparse_logpdf(h->dev, dX, h->n, batch, dll, s.st));
+    SHIP_TRY(hipMemcpyAsync(ll, dll, sizeof(double) * (size_t)batch, hipMemcpyDeviceToHost, s.st));
+    SHIP_TRY(hipStreamSynchronize(s.st));
+    return MCD_OK;
+}
+
+int mcd_sparse_grad_batch(const mcd_sparse_t* h, const double* X, int64_t ld, int64_t batch, int on_device, void* stream, double* ll, double* G,
+                          int64_t ldg)
+{
+    if (!h) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_grad_batch: NULL handle");
+    if (batch < 0 || ld < h->n || ldg < h->n) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_grad_batch: need batch >= 0, ld >= n and ldg >= n");
+    if (batch == 0) return MCD_OK;
+    if (!X || !ll || !G) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_grad_batch: NULL data pointer");
+    SHIP_TRY(hipSetDevice(h->device));
+    if (on_device) {
+        if (G == X) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_grad_batch: the gradient cannot be written in place");
+        SHIP_TRY(mcd::launch_sparse_grad(h->dev, X, ld, batch, ll, G, ldg, (hipStream_t)stream));
+        return MCD_OK;
+    }
+    Scratch s;
+    SHIP_TRY(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    double* dX = s.alloc((size_t)batch * h->n);
+    double* dG = s.alloc((size_t)batch * h->n);
+    double* dll = s.alloc((size_t)batch);
+    if (!dX || !dG || !dll) return sfail(MCD_ERR_HIP, "mcd_sparse_grad_batch: out of device memory");
+    SHIP_TRY(hipMemcpy2DAsync(dX, sizeof(double) * h->n, X, sizeof(double) * ld, sizeof(double) * h->n, (size_t)batch, hipMemcpyHostToDevice, s.st));
+    SHIP_TRY(mcd::launch_sparse_grad(h->dev, dX, h->n, batch, dll, dG, h->n, s.st));
+    SHIP_TRY(hipMemcpyAsync(ll, dll, sizeof(double) * (size_t)batch, hipMemcpyDeviceToHost, s.st));
+    SHIP_TRY(hipMemcpy2DAsync(G, sizeof(double) * ldg, dG, sizeof(double) * h->n, sizeof(double) * h->n, (size_t)batch, hipMemcpyDeviceToHost, s.st));
+    SHIP_TRY(hipStreamSynchronize(s.st));
+    return MCD_OK;
+}
+
+int mcd_sparse_tree_create(mcd_sparse_tree_t** out, const mcd_sparse_t* h, int n_nodes, const int32_t* parent)
+{
+    if (!out) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_create: out is NULL");
+    *out = nullptr;
+    if (!h || !parent || n_nodes < 3) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_create: NULL argument or fewer than 3 nodes");
+    if (parent[0] != -1) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_create: parent[0] must be -1 (root first, pre-order)");
+    for (int v = 1; v < n_nodes; ++v)
+        if (parent[v] < 0 || parent[v] >= v) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_create: nodes must be numbered in pre-order (parent[%d] = %d)", v, parent[v]);
+    std::vector<int> rc;
+    for (int v = 1; v < n_nodes; ++v)
+        if (parent[v] == 0) rc.push_back(v);
+    if (rc.size() != 2) return sfail(MCD_ERR_ROOT_NOT_BIFURCATING, "getBranches: Root node is not bifurcating.");   // app/Tools.hs:43
+    if (n_nodes - 2 != h->n)
+        return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_create: tree has %d branches after merging the root branches, likelihood has dimension %d",
+                     n_nodes - 2, h->n);
+    const int l = rc[0], r = rc[1];
+    // getBranches order: [l, r] ++ (l+1 .. r-1) ++ (r+1 .. n_nodes-1); sumFirstTwo merges the first two (app/Tools.hs:36-48)
+    std::vector<int32_t> slot;
+    slot.push_back(l);
+    for (int v = l + 1; v < r; ++v) slot.push_back(v);
+    for (int v = r + 1; v < n_nodes; ++v) slot.push_back(v);
+    const size_t n = slot.size();
+    slot.resize(2 * n);
+    for (size_t i = 0; i < n; ++i) slot[n + i] = parent[slot[i]];
+    std::unique_ptr<mcd_sparse_tree> t(new mcd_sparse_tree());
+    t->sp = h;
+    SHIP_TRY(hipSetDevice(h->device));
+    SHIP_TRY(hipMalloc((void**)&t->d_slot, sizeof(int32_t) * slot.size()));
+    SHIP_TRY(hipMemcpy(t->d_slot, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice));
+    t->dev.n_nodes = n_nodes;
+    t->dev.root_right = r;
+    t->dev.slot_node = t->d_slot;
+    t->dev.slot_parent = t->d_slot + n;
+    *out = t.release();
+    return MCD_OK;
+}
+
+void mcd_sparse_tree_destroy(mcd_sparse_tree_t* t) { delete t; }
+
+int mcd_sparse_tree_loglik_batch(const mcd_sparse_tree_t* t, const double* heights, const double* rates, int64_t ld_state, const double* tH,
+                                 const double* rMu, int64_t batch, int on_device, void* stream, double* ll, double* log_jac)
+{
+    if (!t) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_loglik_batch: NULL handle");
+    const int nn = t->dev.n_nodes;
+    if (batch < 0 || ld_state < nn) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_loglik_batch: need batch >= 0 and ld_state >= n_nodes");
+    if (batch == 0) return MCD_OK;
+    if (!heights || !rates || !tH || !rMu || !ll) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_tree_loglik_batch: NULL data pointer");
+    const mcd_sparse* h = t->sp;
+    SHIP_TRY(hipSetDevice(h->device));
+    if (on_device) {
+        SHIP_TRY(mcd::launch_sparse_tree_logpdf(h->dev, t->dev, heights, rates, ld_state, tH, rMu, batch, ll, log_jac, (hipStream_t)stream));
+        return MCD_OK;
+    }
+    Scratch s;
+    SHIP_TRY(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    const size_t BN = (size_t)batch * nn, B = (size_t)batch;
+    double* dH = s.alloc(BN);
+    double* dR = s.alloc(BN);
+    double* dsc = s.alloc(4 * B);
+    if (!dH || !dR || !dsc) return sfail(MCD_ERR_HIP, "mcd_sparse_tree_loglik_batch: out of device memory");
+    SHIP_TRY(hipMemcpy2DAsync(dH, sizeof(double) * nn, heights, sizeof(double) * ld_state, sizeof(double) * nn, B, hipMemcpyHostToDevice, s.st));
+    SHIP_TRY(hipMemcpy2DAsync(dR, sizeof(double) * nn, rates, sizeof(double) * ld_state, sizeof(double) * nn, B, hipMemcpyHostToDevice, s.st));
+    SHIP_TRY(hipMemcpyAsync(dsc, tH, sizeof(double) * B, hipMemcpyHostToDevice, s.st));
+    SHIP_TRY(hipMemcpyAsync(dsc + B, rMu, sizeof(double) * B, hipMemcpyHostToDevice, s.st));
+    SHIP_TRY(mcd::launch_sparse_tree_logpdf(h->dev, t->dev, dH, dR, nn, dsc, dsc + B, batch, dsc + 2 * B, dsc + 3 * B, s.st));
+    SHIP_TRY(hipMemcpyAsync(ll, dsc + 2 * B, sizeof(double) * B, hipMemcpyDeviceToHost, s.st));
+    if (log_jac) SHIP_TRY(hipMemcpyAsync(log_jac, dsc + 3 * B, sizeof(double) * B, hipMemcpyDeviceToHost, s.st));
+    SHIP_TRY(hipStreamSynchronize(s.st));
+    return MCD_OK;
+}
+
+}  // extern "C"

@@ -176,6 +176,42 @@ private:
     std::unique_ptr<mcd_tree_t, detail::TreeDeleter> tree_;
 };
 
+// likelihoodFunction (Sparse mu sigmaInvSparse logDetSigma) with the precision matrix kept SPARSE on the device (mcd_sparse_*; N up to
+// MCD_MAX_SPARSE_DIM): logDensitySparseMultivariateNormal, app/Probability.hs:178-184 -- the reference's route for thousands of branches.
+class SparseLikelihood {
+public:
+    SparseLikelihood(const Sparse& s, const Topology& topo, int device = 0) : topo_(topo)
+    {
+        std::vector<int32_t> row, col;
+        Vec val;
+        for (auto& e : s.sigmaInvAssoc) { row.push_back(e.first.first); col.push_back(e.first.second); val.push_back(e.second); }
+        mcd_sparse_t* h = nullptr;
+        detail::check(mcd_sparse_create(&h, (int)s.mu.size(), s.mu.data(), (int64_t)val.size(), row.data(), col.data(), val.data(), s.logDetSigma, device));
+        sp_.reset(h, [](mcd_sparse_t* p) { mcd_sparse_destroy(p); });
+        mcd_sparse_tree_t* t = nullptr;
+        detail::check(mcd_sparse_tree_create(&t, h, topo.nNodes(), topo.parent.data()));
+        tree_.reset(t, [](mcd_sparse_tree_t* p) { mcd_sparse_tree_destroy(p); });
+    }
+    double operator()(const I& x) const
+    {
+        double ll = 0.0;
+        detail::check(mcd_sparse_tree_loglik_batch(tree_.get(), x.timeTree.data(), x.rateTree.data(), topo_.nNodes(), &x.timeHeight, &x.rateMean, 1, 0,
+                                                   nullptr, &ll, nullptr));
+        return ll;
+    }
+    double logDensity(const Vec& xs) const
+    {
+        double ll = 0.0;
+        detail::check(mcd_sparse_logpdf_batch(sp_.get(), xs.data(), (int64_t)xs.size(), 1, 0, nullptr, &ll));
+        return ll;
+    }
+
+private:
+    Topology topo_;
+    std::shared_ptr<mcd_sparse_t> sp_;
+    std::shared_ptr<mcd_sparse_tree_t> tree_;
+};
+
 // likelihoodFunction :: LikelihoodData -> LikelihoodFunction I   (app/Probability.hs:277-281)
 inline std::function<double(const I&)> likelihoodFunction(const LikelihoodData& lhd, const Topology& topo, int device = 0)
 {

@@ -407,6 +407,138 @@ class TreeLikelihood:
 
 
 # ----------------------------------------------------------------------------------------------
+# the sparse form, natively (no densification; N up to MCD_MAX_SPARSE_DIM = 8192)
+# ----------------------------------------------------------------------------------------------
+MAX_SPARSE_DIM = 8192
+
+
+class SparseLikelihood:
+    """`likelihoodFunction (Sparse mu sigmaInvSparse logDetSigma)` (app/Probability.hs:279, 178-184) with the precision matrix kept
+    sparse on the device (csrc/k_sparse.hip, mcd_sparse_*): the reference's route for trees with thousands of branches.  Takes the
+    `Sparse` record of a `.data` file (read_data_file) or of `prepare`.  logpdf / grad on raw vectors, bind_tree(topo).loglik on
+    states.  `MvnLikelihood(Sparse ...)` densifies instead (N <= 1024) and is what the samplers and the tree gradient use."""
+
+    def __init__(self, lhd: Sparse, device: int = 0):
+        if not isinstance(lhd, Sparse):
+            raise TypeError("SparseLikelihood: need a Sparse record")
+        self._h = C.c_void_p()
+        self.device = int(device)
+        self.lhd = lhd
+        mu = _host(lhd.mu)
+        self.n = len(mu)
+        row = np.ascontiguousarray([ij[0] for ij, _ in lhd.sigma_inv_assoc], dtype=np.int32)
+        col = np.ascontiguousarray([ij[1] for ij, _ in lhd.sigma_inv_assoc], dtype=np.int32)
+        val = np.ascontiguousarray([v for _, v in lhd.sigma_inv_assoc], dtype=np.float64)
+        ip = C.POINTER(C.c_int32)
+        _capi.check(_capi.lib().mcd_sparse_create(C.byref(self._h), self.n, mu.ctypes.data_as(_dp), len(val), row.ctypes.data_as(ip),
+                                                  col.ctypes.data_as(ip), val.ctypes.data_as(_dp), C.c_double(float(lhd.logdet_sigma)),
+                                                  self.device))
+        self.nnz = int(_capi.lib().mcd_sparse_nnz(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _capi.lib().mcd_sparse_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def logpdf(self, X):
+        """[batch, n] chain-major (numpy or CUDA tensor) -> ll[batch]."""
+        L = _capi.lib()
+        if _is_torch(X):
+            import torch
+
+            _check_cuda(X, self.device, "X")
+            if X.dim() != 2 or X.shape[1] != self.n:
+                raise ValueError("logpdf: X must be [batch, n]")
+            ll = torch.empty(X.shape[0], dtype=torch.float64, device=X.device)
+            _capi.check(L.mcd_sparse_logpdf_batch(self._h, _ptr(X), X.stride(0), X.shape[0], 1, _stream_ptr(self.device), _ptr(ll)))
+            return ll
+        X = _host(X)
+        if X.ndim != 2 or X.shape[1] != self.n:
+            raise ValueError("logpdf: X must be [batch, n]")
+        ll = np.empty(X.shape[0])
+        _capi.check(L.mcd_sparse_logpdf_batch(self._h, _ptr(X), X.shape[1], X.shape[0], 0, None, _ptr(ll)))
+        return ll
+
+    def grad(self, X):
+        """(ll, G) with G[b] = d ll / d x_b = -P (x_b - mu)."""
+        L = _capi.lib()
+        if _is_torch(X):
+            import torch
+
+            _check_cuda(X, self.device, "X")
+            ll = torch.empty(X.shape[0], dtype=torch.float64, device=X.device)
+            G = torch.empty_like(X)
+            _capi.check(L.mcd_sparse_grad_batch(self._h, _ptr(X), X.stride(0), X.shape[0], 1, _stream_ptr(self.device), _ptr(ll), _ptr(G),
+                                                G.stride(0)))
+            return ll, G
+        X = _host(X)
+        if X.ndim != 2 or X.shape[1] != self.n:
+            raise ValueError("grad: X must be [batch, n]")
+        ll = np.empty(X.shape[0])
+        G = np.empty_like(X)
+        _capi.check(L.mcd_sparse_grad_batch(self._h, _ptr(X), X.shape[1], X.shape[0], 0, None, _ptr(ll), _ptr(G), X.shape[1]))
+        return ll, G
+
+    def bind_tree(self, topo: Topology) -> "SparseTreeLikelihood":
+        return SparseTreeLikelihood(self, topo)
+
+
+class SparseTreeLikelihood:
+    """State -> ln likelihood and ln jacobianRootBranch over a sparse precision matrix (mcd_sparse_tree_*)."""
+
+    def __init__(self, sp: SparseLikelihood, topo: Topology):
+        self.sp = sp
+        self.topo = topo
+        self._t = C.c_void_p()
+        par = np.ascontiguousarray(topo.parent, dtype=np.int32)
+        _capi.check(_capi.lib().mcd_sparse_tree_create(C.byref(self._t), sp._h, len(par), par.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def close(self):
+        if getattr(self, "_t", None) is not None and self._t.value:
+            _capi.lib().mcd_sparse_tree_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def loglik(self, states: StateBatch, want_jacobian: bool = True):
+        """(ll[batch], log jacobianRootBranch[batch] or None)."""
+        H, R, tH, rMu = states.heights, states.rates, states.time_height, states.rate_mean
+        L = _capi.lib()
+        nn = self.topo.n_nodes
+        if _is_torch(H):
+            import torch
+
+            dev = self.sp.device
+            for t, nm in ((H, "heights"), (R, "rates"), (tH, "time_height"), (rMu, "rate_mean")):
+                _check_cuda(t, dev, nm)
+            B = H.shape[0]
+            ll = torch.empty(B, dtype=torch.float64, device=H.device)
+            lj = torch.empty(B, dtype=torch.float64, device=H.device) if want_jacobian else None
+            _capi.check(L.mcd_sparse_tree_loglik_batch(self._t, _ptr(H), _ptr(R), H.stride(0), _ptr(tH), _ptr(rMu), B, 1, _stream_ptr(dev),
+                                                       _ptr(ll), _ptr(lj) if want_jacobian else None))
+            return ll, lj
+        H, R, tH, rMu = (_host(a) for a in (H, R, tH, rMu))
+        B = H.shape[0]
+        if H.shape != (B, nn) or R.shape != (B, nn) or tH.shape != (B,) or rMu.shape != (B,):
+            raise ValueError("loglik: inconsistent state shapes")
+        ll = np.empty(B)
+        lj = np.empty(B) if want_jacobian else None
+        _capi.check(L.mcd_sparse_tree_loglik_batch(self._t, _ptr(H), _ptr(R), nn, _ptr(tH), _ptr(rMu), B, 0, None, _ptr(ll),
+                                                   _ptr(lj) if want_jacobian else None))
+        return ll, lj
+
+
+# ----------------------------------------------------------------------------------------------
 # the reference's plugin functions
 # ----------------------------------------------------------------------------------------------
 def likelihood_function(lhd: LikelihoodData, topo: Topology, device: int = 0) -> Callable[[State], float]:

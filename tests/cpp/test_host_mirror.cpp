@@ -154,6 +154,17 @@ int main(int argc, char** argv)
         if (!threw) return 1;
         // NoData: likelihood 1.0
         if (mcmcdate::likelihoodFunction(mcmcdate::LikelihoodData{mcmcdate::NoData{}}, topo)(x) != 0.0) return 1;
+        // the same precision matrix as an association list through the sparse form (mcd_sparse_*): the same value to rounding
+        mcmcdate::Sparse sp;
+        sp.mu = full.mu;
+        sp.logDetSigma = full.logDetSigma;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (full.sigmaInv[(size_t)i * n + j] != 0.0) sp.sigmaInvAssoc.push_back({{i, j}, full.sigmaInv[(size_t)i * n + j]});
+        mcmcdate::SparseLikelihood slik(sp, topo);
+        const double ll_s = slik(x);
+        std::printf("ll_sparse=%.17g\n", ll_s);
+        if (std::fabs(ll_s - ll_ref) > 1e-10 * std::fmax(1.0, std::fabs(ll_ref))) return 1;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 3;
