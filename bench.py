@@ -226,6 +226,64 @@ def full_gpu_measure(dev_index, n, chains=8192, launches=200):
                          "hbm_gbs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}}
 
 
+def sparse_measure(dev_index, n, B, steps, warm, band=3, extra=4):
+    """The sparse form (csrc/k_sparse.hip; logDensitySparseMultivariateNormal, app/Probability.hs:178-184): a synthetic symmetric,
+    diagonally dominant precision matrix with a band and `extra` random entries per row -- the density a graphical-lasso estimate of a
+    large tree has -- B chains, device resident.  HBM-priced: the CSR stream (12 bytes per nonzero) once per launch plus the chain vectors."""
+    import scipy.sparse as sps
+    import torch
+
+    import mcmc_date_amd as M
+
+    rng = np.random.default_rng(n)
+    rows, cols, vals = [], [], []
+    for d in range(1, band + 1):
+        i = np.arange(n - d)
+        v = rng.uniform(-1.0, 1.0, n - d)
+        rows += [i, i + d]; cols += [i + d, i]; vals += [v, v]
+    i = rng.integers(0, n, n * extra); j = rng.integers(0, n, n * extra)
+    keep = np.abs(i - j) > band
+    i, j = i[keep], j[keep]
+    v = rng.uniform(-0.5, 0.5, len(i))
+    rows += [i, j]; cols += [j, i]; vals += [v, v]
+    A = sps.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    P = ((A + sps.diags(np.abs(A).sum(axis=1).A1 + 1.0)) * 1e3).tocoo()
+    mu = rng.uniform(0.01, 0.2, n)
+    sp = M.SparseLikelihood(M.Sparse(mu, [((int(a), int(b)), float(c)) for a, b, c in zip(P.row, P.col, P.data)], 0.0), device=dev_index)
+    dev = torch.device("cuda", dev_index)
+    X = torch.as_tensor(mu + 0.01 * rng.standard_normal((B, n)), device=dev)
+    ll = torch.empty(B, dtype=torch.float64, device=dev)
+    lib = M._capi.lib()
+
+    def step():
+        M._capi.check(lib.mcd_sparse_logpdf_batch(sp._h, X.data_ptr(), X.stride(0), B, 1, torch.cuda.current_stream().cuda_stream, ll.data_ptr()))
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = e0.elapsed_time(e1) * 1e-3 / steps
+    dx = X.cpu().numpy() - mu
+    Pc = P.tocsr()
+    ref = -n * 0.9189385332046727 - 0.5 * np.einsum("bi,bi->b", dx, (Pc @ dx.T).T)
+    err = float(np.max(np.abs(ll.cpu().numpy() - ref) / np.abs(ref)))
+    assert err <= 1e-12, f"sparse form differs from scipy.sparse: {err}"
+    alg = 12.0 * sp.nnz + 4.0 * (n + 1) + 8.0 * n + B * (8.0 * n + 8.0)
+    flops = (2.0 * sp.nnz + 3.0 * n) * B / per / 1e12
+    return dt, per, {"n": int(n), "nnz": int(sp.nnz), "chains": int(B), "chains_per_tile": int({True: 16}.get(False, 0)) or None,
+                     "kernel_us_per_launch": per * 1e6, "alg_bytes_per_launch": alg, "fp64_tflops": flops,
+                     "roofline": {"bound": "hbm", "achieved": alg / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,7 +300,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--form", default="auto", choices=["auto", "sweep", "multiply"],
                     help="log-density kernel form (mcd_set_logpdf_form); auto = multiply for N >= 96 and >= 2048 chains, N >= 32 and >= 8192")
-    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior", "mh"])
+    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior", "mh", "sparse"])
     ap.add_argument("--no-mh", action="store_true", help="skip the secondary Metropolis-Hastings measurement of the default run")
     args = ap.parse_args()
 
@@ -307,6 +365,21 @@ def main():
                              "frac": alg_b / (elapsed / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "note": "algorithmic bytes of the likelihood launch only; the step also runs the proposal + prior launch"},
                 "mh": r}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.kind == "sparse":
+        K, W = args.steps, args.warmup
+        dt, per, r = sparse_measure(dev_index, n, B, K, W)
+        if rank == 0:
+            r.pop("chains_per_tile")
+            print(json.dumps({
+                "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes", "value": B * K / dt, "unit": "evals/s",
+                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"sparse form: synthetic {n}-dimensional MVN, precision matrix with {r['nnz']} nonzeros (band 3 + 4 random per row), "
+                                       f"{B} chains per GPU", "n": n, "chains_per_gpu": B, "kernel": "sparse", "launch": "eager"},
+                "roofline": r.pop("roofline"), "sparse": r}))
         if world > 1:
             dist.destroy_process_group()
         return

@@ -1,4 +1,4 @@
-// k_sparse.hip -- the sparse form of the log-density on the device (gfx950): the precision matrix as it is, CSR, no densification.
+// k_sparse.hip -- the sparse form of the log-density on the device (gfx950): the precision matrix as it is, no densification.
 //
 // Reference: logDensitySparseMultivariateNormal, app/Probability.hs:178-184 --
 //     ll = c - 1/2 (log det Sigma + dx . (P !#> dx)),   dx = x - mu,   c = -N ln sqrt(2 pi),
@@ -7,14 +7,20 @@
 // (tutorial/main/tutorial.org:487-496), beyond the dense kernels' N <= 1024.  State -> distances as everywhere
 // (likelihoodFunctionWrapper, :195-207); d ll / d x = -P dx falls out of the same product.
 //
-// Mapping.  A workgroup (4 waves) owns a tile of C chains (16 .. 1: as many as fit the CU's LDS with the whole dx tile,
-// xs[N][C + 1] doubles, the + 1 keeps a column's lanes on different banks).  Phase 1 stages the tile: chain vectors read
-// coalesced along j (tree states: distances computed from heights and rates on the way).  Phase 2 deals the rows to the waves
-// (row i to wave i mod 4); a wave walks row i's nonzeros 64 / C at a time -- lane = (nonzero slot s, chain c): the column
-// index and value of a nonzero are one coalesced read shared by C lanes, its dx a 128-byte LDS segment --, folds the slots with
-// lane exchanges (y_i for C chains), adds dx_i y_i to the chains' quadratic forms and, for the gradient, stores -y_i.
-// Phase 3 adds the four waves' partial forms in a fixed order.  Everything is summed in a fixed order: bit-reproducible.
-// HBM-bound on the CSR stream: 12 bytes per nonzero per tile from L2 (the matrix is shared by all tiles) for 2 C flops.
+// Mapping: lanes = chains.  Three launches on the caller's stream:
+//   k_sparse_stage   dx of every chain, TRANSPOSED to [N][Bp] (chain-minor) through 64 x 64 LDS tiles: chain vectors are read
+//                    coalesced along j (tree states: the distances are formed on the way, heights and rates gathered from the chain's
+//                    own row), written coalesced along the chains;
+//   k_sparse_rows    a wave owns 64 chains and a chunk of RPC consecutive rows.  The chunk's nonzeros are contiguous in the
+//                    row-sorted triplets: lane l loads nonzero p + l (row, column, value: coalesced), then the wave walks the 64 of
+//                    them -- v_readlane puts row, column and value into SGPRs, the dx of column j for the wave's 64 chains is ONE
+//                    coalesced 512-byte load from L2, the value is the scalar operand of v_fma_f64 (the sweep's broadcast trick).
+//                    At a row's end y_i (64 chains) is complete: dx_i y_i joins the chunk's partial quadratic form, -y_i is stored
+//                    coalesced (gradient).  Loads of 16 nonzeros are in flight before their FMAs; the FMAs run in nonzero order;
+//   k_sparse_finish  ll[b] = c - 1/2 (logdet + sum over the chunks' partial forms, in chunk order); the gradient transposed back
+//                    to chain-major through LDS tiles.
+// Everything is summed in a fixed order: bit-reproducible.  Bound: L2 bandwidth -- one 512-byte line of dx per nonzero and 64
+// chains (the matrix itself is 16 bytes per nonzero per 64 chains); no LDS capacity limit, any N.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,122 +28,179 @@
 
 namespace mcd {
 
-template <int C, bool TREE, bool GRAD>
-__global__ __launch_bounds__(256) void k_sparse(SparseDev S, SparseTreeDev T, const double* __restrict__ X, const double* __restrict__ Rt,
-                                               int64_t ld, const double* __restrict__ tH, const double* __restrict__ rMu, int64_t batch,
-                                               double* __restrict__ ll, double* __restrict__ logjac, double* __restrict__ G, int64_t ldg)
+__device__ __forceinline__ double sp_readlane64(double v, int l)
 {
-    extern __shared__ double xs[];                           // [n][C + 1] dx of the tile, then [4][C] partial quadratic forms
-    constexpr int XS = C + 1;
-    constexpr int NS = 64 / C;                               // nonzeros a wave takes per step
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+// dx[b][j] -> xsT[j][b] (b < Bp = batch rounded up to 64; chains beyond the batch get 0).  Block = 64 chains x 64 columns.
+template <bool TREE>
+__global__ __launch_bounds__(256) void k_sparse_stage(SparseDev S, SparseTreeDev T, const double* __restrict__ X, const double* __restrict__ Rt,
+                                                     int64_t ld, const double* __restrict__ tH, const double* __restrict__ rMu, int64_t batch,
+                                                     int64_t Bp, double* __restrict__ xsT, double* __restrict__ logjac)
+{
+    __shared__ double tile[64][65];
     const int n = S.n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t b0 = (int64_t)blockIdx.x * C;
-    double* qred = xs + (size_t)n * XS;
-
-    // ---- phase 1: the tile's dx into LDS, chain after chain, coalesced along j
-#pragma unroll 1
-    for (int c = 0; c < C; ++c) {
-        const int64_t b = b0 + c;
-        const bool in = b < batch;
-        const int64_t bb = in ? b : batch - 1;               // a chain beyond the batch repeats the last one and stores nothing
-        if constexpr (TREE) {
-            const double* H = X + bb * ld;
-            const double* R = Rt + bb * ld;
-            const double s = tH[bb] * rMu[bb];
-            for (int j = tid; j < n; j += 256) {
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int j0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int cb = w; cb < 64; cb += 4) {                     // chain b0 + cb, column j0 + lane
+        const int64_t b = b0 + cb;
+        const int j = j0 + lane;
+        double v = 0.0;
+        if (b < batch && j < n) {
+            if constexpr (TREE) {
+                const double* H = X + b * ld;
+                const double* R = Rt + b * ld;
                 const int a = T.slot_node[j], pa = T.slot_parent[j];
-                double v = (H[pa] - H[a]) * R[a];            // heightTreeToLengthTree, times * rates
-                if (j == 0) {
-                    v = v + (H[0] - H[T.root_right]) * R[T.root_right];   // sumFirstTwo
-                    v = v * s;
-                    if (in && logjac) logjac[b] = log(1.0 / v);            // jacobianRootBranch, :393-410
-                } else {
-                    v = v * s;
-                }
-                xs[(size_t)j * XS + c] = v - S.mu[j];
+                double d = (H[pa] - H[a]) * R[a];            // heightTreeToLengthTree, times * rates
+                if (j == 0) d = d + (H[0] - H[T.root_right]) * R[T.root_right];   // sumFirstTwo
+                d = d * (tH[b] * rMu[b]);
+                if (j == 0 && logjac) logjac[b] = log(1.0 / d);                    // jacobianRootBranch, :393-410
+                v = d - S.mu[j];
+            } else {
+                v = X[b * ld + j] - S.mu[j];
             }
-        } else {
-            const double* x = X + bb * ld;
-            for (int j = tid; j < n; j += 256) xs[(size_t)j * XS + c] = x[j] - S.mu[j];
         }
+        tile[cb][lane] = v;
     }
     __syncthreads();
+    for (int jj = w; jj < 64; jj += 4) {
+        const int j = j0 + jj;
+        if (j < n) xsT[(int64_t)j * Bp + b0 + lane] = tile[lane][jj];
+    }
+}
 
-    // ---- phase 2: y = P dx row by row, q += dx_i y_i
-    const int s = lane / C, c = lane - s * C;
-    double q = 0.0;
-    for (int i = wave; i < n; i += 4) {
-        const int p1 = S.rowptr[i + 1];
-        double acc = 0.0;
-        for (int p = S.rowptr[i] + s; p < p1; p += NS) acc = fma(S.val[p], xs[(size_t)S.col[p] * XS + c], acc);
+// nonzero triplets sorted by (row, column): trow / tcol / tval [nnz]; rowptr [n + 1]
+template <int RPC, bool GRAD>
+__global__ __launch_bounds__(256) void k_sparse_rows(SparseDev S, int64_t Bp, const double* __restrict__ xsT, double* __restrict__ qpart,
+                                                    double* __restrict__ yT)
+{
+    constexpr int U = 16;
+    const int n = S.n;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.y * 4 + wave;
+    const int r0 = chunk * RPC;
+    if (r0 >= n) return;
+    const int r1 = (r0 + RPC < n) ? r0 + RPC : n;
+    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    const int p_begin = S.rowptr[r0], p_end = S.rowptr[r1];
+    double q = 0.0, acc = 0.0;
+    int cur = r0;                                            // row being accumulated (wave-uniform)
+    double xcur = xsT[(int64_t)r0 * Bp + b];                 // its own dx (the dx_i of dx_i y_i): requested when the row begins
+    auto flush_to = [&](int row) {                           // rows cur .. row - 1 are complete (rows without a nonzero: y = 0)
+        while (cur < row) {
+            q = fma(xcur, acc, q);
+            if constexpr (GRAD) yT[(int64_t)cur * Bp + b] = -acc;    // d ll / d x_i = -(P dx)_i
+            acc = 0.0;
+            ++cur;
+            if (cur < r1) xcur = xsT[(int64_t)cur * Bp + b];
+        }
+    };
+    for (int p = p_begin; p < p_end; p += 64) {
+        const int mine = (p + lane < p_end) ? p + lane : p_end - 1;
+        const int tr = S.trow[mine], tc = S.col[mine];
+        const double tv = (p + lane < p_end) ? S.val[mine] : 0.0;
+        const int cnt = (p_end - p < 64) ? p_end - p : 64;
+        for (int u0 = 0; u0 < cnt; u0 += U) {
+            double x[U];
 #pragma unroll
-        for (int off = C; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-        q = fma(xs[(size_t)i * XS + c], acc, q);
-        if constexpr (GRAD) {
-            if (s == 0 && b0 + c < batch) G[(b0 + c) * ldg + i] = -acc;      // d ll / d x_i = -(P dx)_i
+            for (int u = 0; u < U; ++u) {
+                const int l = (u0 + u < cnt) ? u0 + u : cnt - 1;                  // (clamped: the weight below is 0 there)
+                const int c = __builtin_amdgcn_readlane(tc, l);
+                x[u] = xsT[(int64_t)c * Bp + b];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u0 + u < cnt) {                                              // wave-uniform
+                    const int l = u0 + u;
+                    const int r = __builtin_amdgcn_readlane(tr, l);
+                    if (r != cur) flush_to(r);
+                    acc = fma(sp_readlane64(tv, l), x[u], acc);
+                }
+            }
         }
     }
-    if (s == 0) qred[wave * C + c] = q;
-    __syncthreads();
-    if (tid < C && b0 + tid < batch) {
-        const double qq = ((qred[tid] + qred[C + tid]) + qred[2 * C + tid]) + qred[3 * C + tid];
-        ll[b0 + tid] = S.c + (-0.5) * (S.logdet + qq);       // :180 (c - 1/2 (logdet + q))
+    flush_to(r1);
+    qpart[(int64_t)chunk * Bp + b] = q;
+}
+
+// ll and, for the gradient, yT [N][Bp] -> G [batch][ldg]
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_sparse_finish(SparseDev S, int n_chunks, int64_t Bp, int64_t batch, const double* __restrict__ qpart,
+                                                      double* __restrict__ ll, const double* __restrict__ yT, double* __restrict__ G, int64_t ldg)
+{
+    __shared__ double tile[64][65];
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (blockIdx.y == 0 && w == 0) {
+        const int64_t b = b0 + lane;
+        double q = 0.0;
+        for (int c = 0; c < n_chunks; ++c) q += qpart[(int64_t)c * Bp + b];
+        if (b < batch) ll[b] = S.c + (-0.5) * (S.logdet + q);            // :180 (c - 1/2 (logdet + q))
+    }
+    if constexpr (GRAD) {
+        const int j0 = blockIdx.y * 64;
+        for (int jj = w; jj < 64; jj += 4) tile[jj][lane] = (j0 + jj < S.n) ? yT[(int64_t)(j0 + jj) * Bp + b0 + lane] : 0.0;
+        __syncthreads();
+        for (int cb = w; cb < 64; cb += 4) {
+            const int64_t b = b0 + cb;
+            if (b < batch && j0 + lane < S.n) G[b * ldg + j0 + lane] = tile[lane][cb];
+        }
     }
 }
 
-size_t sparse_lds_bytes(int n, int C) { return ((size_t)n * (C + 1) + 4 * (size_t)C) * sizeof(double); }
-
-// chains per tile: the most that fit 150 KiB of LDS with the dx tile
-int sparse_tile_chains(int n)
+// doubles of scratch a launch needs: xsT [n][Bp], qpart [chunks][Bp], yT [n][Bp] (gradient)
+int sparse_rows_per_chunk(int n, int64_t batch) { return ((batch + 63) / 64) * ((n + 15) / 16) >= 512 ? 16 : 4; }
+size_t sparse_scratch_doubles(int n, int64_t batch, bool grad)
 {
-    const int cs[] = {16, 8, 4, 2, 1};
-    for (int c : cs)
-        if (sparse_lds_bytes(n, c) <= 150 * 1024) return c;
-    return 0;
-}
-
-template <int C, bool TREE, bool GRAD>
-static hipError_t launch_c(const SparseDev& S, const SparseTreeDev& T, const double* X, const double* Rt, int64_t ld, const double* tH,
-                           const double* rMu, int64_t batch, double* ll, double* logjac, double* G, int64_t ldg, hipStream_t st)
-{
-    const size_t lds = sparse_lds_bytes(S.n, C);
-    if (lds > 64 * 1024)
-        if (hipError_t e = hipFuncSetAttribute((const void*)k_sparse<C, TREE, GRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
-    hipLaunchKernelGGL((k_sparse<C, TREE, GRAD>), dim3((unsigned)((batch + C - 1) / C)), dim3(256), lds, st, S, T, X, Rt, ld, tH, rMu, batch, ll,
-                       logjac, G, ldg);
-    return hipGetLastError();
+    const size_t Bp = (size_t)((batch + 63) / 64) * 64;
+    const int rpc = sparse_rows_per_chunk(n, batch);
+    const size_t chunks = ((size_t)(n + rpc - 1) / rpc + 3) / 4 * 4;
+    return Bp * ((size_t)n * (grad ? 2 : 1) + chunks);
 }
 
 template <bool TREE, bool GRAD>
 static hipError_t launch_any(const SparseDev& S, const SparseTreeDev& T, const double* X, const double* Rt, int64_t ld, const double* tH,
-                             const double* rMu, int64_t batch, double* ll, double* logjac, double* G, int64_t ldg, hipStream_t st)
+                             const double* rMu, int64_t batch, double* ll, double* logjac, double* G, int64_t ldg, double* scratch, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
-    switch (sparse_tile_chains(S.n)) {
-    case 16: return launch_c<16, TREE, GRAD>(S, T, X, Rt, ld, tH, rMu, batch, ll, logjac, G, ldg, st);
-    case 8: return launch_c<8, TREE, GRAD>(S, T, X, Rt, ld, tH, rMu, batch, ll, logjac, G, ldg, st);
-    case 4: return launch_c<4, TREE, GRAD>(S, T, X, Rt, ld, tH, rMu, batch, ll, logjac, G, ldg, st);
-    case 2: return launch_c<2, TREE, GRAD>(S, T, X, Rt, ld, tH, rMu, batch, ll, logjac, G, ldg, st);
-    case 1: return launch_c<1, TREE, GRAD>(S, T, X, Rt, ld, tH, rMu, batch, ll, logjac, G, ldg, st);
-    default: return hipErrorInvalidValue;
-    }
+    const int n = S.n;
+    const int64_t Bp = ((batch + 63) / 64) * 64;
+    const int rpc = sparse_rows_per_chunk(n, batch);
+    const int chunks = (n + rpc - 1) / rpc, chunk_blocks = (chunks + 3) / 4;
+    double* xsT = scratch;
+    double* qpart = xsT + (size_t)n * Bp;
+    double* yT = qpart + (size_t)chunk_blocks * 4 * Bp;
+    const unsigned gb = (unsigned)(Bp / 64), gj = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL((k_sparse_stage<TREE>), dim3(gb, gj), dim3(256), 0, st, S, T, X, Rt, ld, tH, rMu, batch, Bp, xsT, logjac);
+    if (rpc == 16)
+        hipLaunchKernelGGL((k_sparse_rows<16, GRAD>), dim3(gb, (unsigned)chunk_blocks), dim3(256), 0, st, S, Bp, xsT, qpart, yT);
+    else
+        hipLaunchKernelGGL((k_sparse_rows<4, GRAD>), dim3(gb, (unsigned)chunk_blocks), dim3(256), 0, st, S, Bp, xsT, qpart, yT);
+    hipLaunchKernelGGL((k_sparse_finish<GRAD>), dim3(gb, GRAD ? gj : 1u), dim3(256), 0, st, S, chunks, Bp, batch, qpart, ll, yT, G, ldg);
+    return hipGetLastError();
 }
 
-hipError_t launch_sparse_logpdf(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
+hipError_t launch_sparse_logpdf(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* scratch, hipStream_t st)
 {
-    return launch_any<false, false>(S, SparseTreeDev{}, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, nullptr, 0, st);
+    return launch_any<false, false>(S, SparseTreeDev{}, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, nullptr, 0, scratch, st);
 }
 
-hipError_t launch_sparse_grad(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, hipStream_t st)
+hipError_t launch_sparse_grad(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, double* scratch,
+                              hipStream_t st)
 {
-    return launch_any<false, true>(S, SparseTreeDev{}, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, G, ldg, st);
+    return launch_any<false, true>(S, SparseTreeDev{}, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, G, ldg, scratch, st);
 }
 
 hipError_t launch_sparse_tree_logpdf(const SparseDev& S, const SparseTreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
-                                     const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st)
+                                     const double* rMu, int64_t batch, double* ll, double* logjac, double* scratch, hipStream_t st)
 {
-    return launch_any<true, false>(S, T, H, Rt, lds, tH, rMu, batch, ll, logjac, nullptr, 0, st);
+    return launch_any<true, false>(S, T, H, Rt, lds, tH, rMu, batch, ll, logjac, nullptr, 0, scratch, st);
 }
 
 }  // namespace mcd

@@ -104,6 +104,7 @@ struct SparseDev {
     int n;
     int64_t nnz;
     const int32_t* rowptr;   // [n + 1]
+    const int32_t* trow;     // [nnz] row of every stored entry (the triplets are sorted by row, then column)
     const int32_t* col;      // [nnz], ascending inside a row
     const double* val;       // [nnz]
     const double* mu;        // [n]
@@ -115,11 +116,13 @@ struct SparseTreeDev {
     const int32_t* slot_parent;   // [n] that node's parent
 };
 constexpr int kSparseMaxDim = 8192;
-int sparse_tile_chains(int n);
-hipError_t launch_sparse_logpdf(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st);
-hipError_t launch_sparse_grad(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, hipStream_t st);
+// scratch: sparse_scratch_doubles(n, batch, gradient?) doubles of device memory that live until the launches have run
+size_t sparse_scratch_doubles(int n, int64_t batch, bool grad);
+hipError_t launch_sparse_logpdf(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* scratch, hipStream_t st);
+hipError_t launch_sparse_grad(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, double* scratch,
+                              hipStream_t st);
 hipError_t launch_sparse_tree_logpdf(const SparseDev& S, const SparseTreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
-                                     const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st);
+                                     const double* rMu, int64_t batch, double* ll, double* logjac, double* scratch, hipStream_t st);
 
 // Metropolis-coupled MCMC (k_mc3.hip): the temperature rank of every GLOBAL chain, the ladder of reciprocal temperatures and the
 // swap counters per rung; all pointers are device memory.

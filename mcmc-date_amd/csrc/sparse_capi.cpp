@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <memory>
@@ -40,10 +42,17 @@ struct mcd_sparse {
     int n = 0, device = 0;
     mcd::SparseDev dev{};
     std::vector<void*> allocs;
+    // scratch of the device-resident entry points (the transposed chain vectors, partial forms): one grow-only buffer per stream
+    // of the caller's, launches on a stream being ordered.  (A stream under capture shares its eager buffer: a graph replayed on
+    // ANOTHER stream must not run beside launches on the stream it was captured from.)
+    mutable std::mutex mu;
+    mutable std::map<hipStream_t, std::pair<double*, size_t>> scratch;
     ~mcd_sparse()
     {
         (void)hipSetDevice(device);
         for (void* p : allocs) (void)hipFree(p);
+        for (auto& kv : scratch)
+            if (kv.second.first) (void)hipFree(kv.second.first);
     }
 };
 
@@ -59,6 +68,25 @@ struct mcd_sparse_tree {
 };
 
 namespace {
+
+int scratch_for(const mcd_sparse* h, hipStream_t st, size_t doubles, double** out)
+{
+    std::lock_guard<std::mutex> lock(h->mu);
+    auto& e = h->scratch[st];
+    if (e.second < doubles) {
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;      // (legal while the calling thread captures a stream)
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e.first) (void)hipFree(e.first);                          // waits for the device: earlier launches are done with it
+        e = {nullptr, 0};
+        double* p = nullptr;
+        const hipError_t err = hipMalloc((void**)&p, sizeof(double) * doubles);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (err != hipSuccess) return sfail(MCD_ERR_HIP, "mcd_sparse: %zu bytes of scratch: %s", sizeof(double) * doubles, hipGetErrorString(err));
+        e = {p, doubles};
+    }
+    *out = e.first;
+    return MCD_OK;
+}
 
 template <class T>
 int upload(mcd_sparse* h, const T** dst, const T* src, size_t count)
@@ -114,7 +142,7 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
     std::vector<int64_t> order((size_t)nnz);
     std::iota(order.begin(), order.end(), (int64_t)0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return row[a] != row[b] ? row[a] < row[b] : col[a] < col[b]; });
-    std::vector<int32_t> rowptr((size_t)n + 1, 0), cc;
+    std::vector<int32_t> rowptr((size_t)n + 1, 0), cc, rr;
     std::vector<double> vv;
     for (size_t q = 0; q < order.size(); ++q) {
         const int64_t k = order[q];
@@ -123,17 +151,18 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
             continue;
         }
         cc.push_back(col[k]);
+        rr.push_back(row[k]);
         vv.push_back(val[k]);
         rowptr[(size_t)row[k] + 1] += 1;
     }
     for (int i = 0; i < n; ++i) rowptr[(size_t)i + 1] += rowptr[(size_t)i];
-    if (mcd::sparse_tile_chains(n) == 0) return sfail(MCD_ERR_UNSUPPORTED, "mcd_sparse_create: dimension %d does not fit a CU's LDS", n);
     std::unique_ptr<mcd_sparse> h(new mcd_sparse());
     h->n = n;
     h->device = device_id;
     SHIP_TRY(hipSetDevice(device_id));
     int rc = MCD_OK;
     if ((rc = upload(h.get(), &h->dev.rowptr, rowptr.data(), rowptr.size())) || (rc = upload(h.get(), &h->dev.col, cc.data(), cc.size())) ||
+        (rc = upload(h.get(), &h->dev.trow, rr.data(), rr.size())) ||
         (rc = upload(h.get(), &h->dev.val, vv.data(), vv.size())) || (rc = upload(h.get(), &h->dev.mu, mu, (size_t)n)))
         return rc;
     h->dev.n = n;
@@ -156,16 +185,19 @@ int mcd_sparse_logpdf_batch(const mcd_sparse_t* h, const double* X, int64_t ld, 
     if (!X || !ll) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_logpdf_batch: NULL data pointer");
     SHIP_TRY(hipSetDevice(h->device));
     if (on_device) {
-        SHIP_TRY(mcd::launch_sparse_logpdf(h->dev, X, ld, batch, ll, (hipStream_t)stream));
+        double* sc = nullptr;
+        if (int rc = scratch_for(h, (hipStream_t)stream, mcd::sparse_scratch_doubles(h->n, batch, false), &sc)) return rc;
+        SHIP_TRY(mcd::launch_sparse_logpdf(h->dev, X, ld, batch, ll, sc, (hipStream_t)stream));
         return MCD_OK;
     }
     Scratch s;
     SHIP_TRY(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
     double* dX = s.alloc((size_t)batch * h->n);
     double* dll = s.alloc((size_t)batch);
-    if (!dX || !dll) return sfail(MCD_ERR_HIP, "mcd_sparse_logpdf_batch: out of device memory");
+    double* sc = s.alloc(mcd::sparse_scratch_doubles(h->n, batch, false));
+    if (!dX || !dll || !sc) return sfail(MCD_ERR_HIP, "mcd_sparse_logpdf_batch: out of device memory");
     SHIP_TRY(hipMemcpy2DAsync(dX, sizeof(double) * h->n, X, sizeof(double) * ld, sizeof(double) * h->n, (size_t)batch, hipMemcpyHostToDevice, s.st));
-    SHIP_TRY(mcd::launch_sparse_logpdf(h->dev, dX, h->n, batch, dll, s.st));
+    SHIP_TRY(mcd::launch_sparse_logpdf(h->dev, dX, h->n, batch, dll, sc, s.st));
     SHIP_TRY(hipMemcpyAsync(ll, dll, sizeof(double) * (size_t)batch, hipMemcpyDeviceToHost, s.st));
     SHIP_TRY(hipStreamSynchronize(s.st));
     return MCD_OK;
@@ -180,8 +212,9 @@ int mcd_sparse_grad_batch(const mcd_sparse_t* h, const double* X, int64_t ld, in
     if (!X || !ll || !G) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_grad_batch: NULL data pointer");
     SHIP_TRY(hipSetDevice(h->device));
     if (on_device) {
-        if (G == X) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_grad_batch: the gradient cannot be written in place");
-        SHIP_TRY(mcd::launch_sparse_grad(h->dev, X, ld, batch, ll, G, ldg, (hipStream_t)stream));
+        double* sc = nullptr;
+        if (int rc = scratch_for(h, (hipStream_t)stream, mcd::sparse_scratch_doubles(h->n, batch, true), &sc)) return rc;
+        SHIP_TRY(mcd::launch_sparse_grad(h->dev, X, ld, batch, ll, G, ldg, sc, (hipStream_t)stream));   // (G may be X: the stage has read every x)
         return MCD_OK;
     }
     Scratch s;
@@ -189,9 +222,10 @@ int mcd_sparse_grad_batch(const mcd_sparse_t* h, const double* X, int64_t ld, in
     double* dX = s.alloc((size_t)batch * h->n);
     double* dG = s.alloc((size_t)batch * h->n);
     double* dll = s.alloc((size_t)batch);
-    if (!dX || !dG || !dll) return sfail(MCD_ERR_HIP, "mcd_sparse_grad_batch: out of device memory");
+    double* sc = s.alloc(mcd::sparse_scratch_doubles(h->n, batch, true));
+    if (!dX || !dG || !dll || !sc) return sfail(MCD_ERR_HIP, "mcd_sparse_grad_batch: out of device memory");
     SHIP_TRY(hipMemcpy2DAsync(dX, sizeof(double) * h->n, X, sizeof(double) * ld, sizeof(double) * h->n, (size_t)batch, hipMemcpyHostToDevice, s.st));
-    SHIP_TRY(mcd::launch_sparse_grad(h->dev, dX, h->n, batch, dll, dG, h->n, s.st));
+    SHIP_TRY(mcd::launch_sparse_grad(h->dev, dX, h->n, batch, dll, dG, h->n, sc, s.st));
     SHIP_TRY(hipMemcpyAsync(ll, dll, sizeof(double) * (size_t)batch, hipMemcpyDeviceToHost, s.st));
     SHIP_TRY(hipMemcpy2DAsync(G, sizeof(double) * ldg, dG, sizeof(double) * h->n, sizeof(double) * h->n, (size_t)batch, hipMemcpyDeviceToHost, s.st));
     SHIP_TRY(hipStreamSynchronize(s.st));
@@ -248,7 +282,9 @@ int mcd_sparse_tree_loglik_batch(const mcd_sparse_tree_t* t, const double* heigh
     const mcd_sparse* h = t->sp;
     SHIP_TRY(hipSetDevice(h->device));
     if (on_device) {
-        SHIP_TRY(mcd::launch_sparse_tree_logpdf(h->dev, t->dev, heights, rates, ld_state, tH, rMu, batch, ll, log_jac, (hipStream_t)stream));
+        double* sc = nullptr;
+        if (int rc = scratch_for(h, (hipStream_t)stream, mcd::sparse_scratch_doubles(h->n, batch, false), &sc)) return rc;
+        SHIP_TRY(mcd::launch_sparse_tree_logpdf(h->dev, t->dev, heights, rates, ld_state, tH, rMu, batch, ll, log_jac, sc, (hipStream_t)stream));
         return MCD_OK;
     }
     Scratch s;
@@ -257,12 +293,13 @@ int mcd_sparse_tree_loglik_batch(const mcd_sparse_tree_t* t, const double* heigh
     double* dH = s.alloc(BN);
     double* dR = s.alloc(BN);
     double* dsc = s.alloc(4 * B);
-    if (!dH || !dR || !dsc) return sfail(MCD_ERR_HIP, "mcd_sparse_tree_loglik_batch: out of device memory");
+    double* sc = s.alloc(mcd::sparse_scratch_doubles(h->n, batch, false));
+    if (!dH || !dR || !dsc || !sc) return sfail(MCD_ERR_HIP, "mcd_sparse_tree_loglik_batch: out of device memory");
     SHIP_TRY(hipMemcpy2DAsync(dH, sizeof(double) * nn, heights, sizeof(double) * ld_state, sizeof(double) * nn, B, hipMemcpyHostToDevice, s.st));
     SHIP_TRY(hipMemcpy2DAsync(dR, sizeof(double) * nn, rates, sizeof(double) * ld_state, sizeof(double) * nn, B, hipMemcpyHostToDevice, s.st));
     SHIP_TRY(hipMemcpyAsync(dsc, tH, sizeof(double) * B, hipMemcpyHostToDevice, s.st));
     SHIP_TRY(hipMemcpyAsync(dsc + B, rMu, sizeof(double) * B, hipMemcpyHostToDevice, s.st));
-    SHIP_TRY(mcd::launch_sparse_tree_logpdf(h->dev, t->dev, dH, dR, nn, dsc, dsc + B, batch, dsc + 2 * B, dsc + 3 * B, s.st));
+    SHIP_TRY(mcd::launch_sparse_tree_logpdf(h->dev, t->dev, dH, dR, nn, dsc, dsc + B, batch, dsc + 2 * B, dsc + 3 * B, sc, s.st));
     SHIP_TRY(hipMemcpyAsync(ll, dsc + 2 * B, sizeof(double) * B, hipMemcpyDeviceToHost, s.st));
     if (log_jac) SHIP_TRY(hipMemcpyAsync(log_jac, dsc + 3 * B, sizeof(double) * B, hipMemcpyDeviceToHost, s.st));
     SHIP_TRY(hipStreamSynchronize(s.st));

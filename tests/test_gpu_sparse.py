@@ -154,4 +154,4 @@ def test_structural_faults_and_duplicates(gpu):
         sp1 = M.SparseLikelihood(M.Sparse(np.array([0.1, 0.2]), [((0, 0), 1.0), ((1, 1), 1.0)], 0.0))
         sp1.bind_tree(M.Topology(np.array([-1, 0, 0, 0], dtype=np.int32)))
     with pytest.raises(M.McdError):
-        sp.bind_tree(M.Topology(np.array([-1, 0, 0, 1, 1, 2, 2], dtype=np.int32)))     # 7 nodes: dimension 5, not 3
+        sp.bind_tree(M.Topology(np.array([-1, 0, 1, 1, 0, 4, 4], dtype=np.int32)))     # 7 nodes: dimension 5, not 3
