@@ -137,11 +137,26 @@ __global__ __launch_bounds__(256) void k_sparse_finish(SparseDev S, int n_chunks
     __shared__ double tile[64][65];
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (blockIdx.y == 0 && w == 0) {
+    if (blockIdx.y == 0) {
+        // wave w adds the chunks w, w + 4, ... (eight loads in flight), wave 0 the four partial sums in wave order: a fixed order
         const int64_t b = b0 + lane;
         double q = 0.0;
-        for (int c = 0; c < n_chunks; ++c) q += qpart[(int64_t)c * Bp + b];
-        if (b < batch) ll[b] = S.c + (-0.5) * (S.logdet + q);            // :180 (c - 1/2 (logdet + q))
+        int c = w;
+        for (; c + 28 < n_chunks; c += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = qpart[(int64_t)(c + 4 * u) * Bp + b];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q += v[u];
+        }
+        for (; c < n_chunks; c += 4) q += qpart[(int64_t)c * Bp + b];
+        tile[w][lane] = q;
+        __syncthreads();
+        if (w == 0 && b < batch) {
+            const double qq = ((tile[0][lane] + tile[1][lane]) + tile[2][lane]) + tile[3][lane];
+            ll[b] = S.c + (-0.5) * (S.logdet + qq);                      // :180 (c - 1/2 (logdet + q))
+        }
+        __syncthreads();
     }
     if constexpr (GRAD) {
         const int j0 = blockIdx.y * 64;
