@@ -342,6 +342,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t ste
 #define MCD_MH_PATH_TWO_LAUNCH_PRIOR_BESIDE 3 /* step + likelihood launch that also carries the ln prior of the proposal */
 #define MCD_MH_PATH_TWO_LAUNCH 4              /* step (prior inside) + likelihood launch */
 #define MCD_MH_PATH_STEP_WG_X 5               /* workgroup-per-chain step leaving distances + plain-vector likelihood launch */
+#define MCD_MH_PATH_STEP_WG_INCREMENTAL 6     /* the same, the likelihood launch only for proposals that move many distances (k_mh_inc.hip) */
 int mcd_mh_last_path(const mcd_mh_t* m);
 /* Auto tuning at the end of a tuning period [mcmc]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3). */
 int mcd_mh_tune(mcd_mh_t* m);

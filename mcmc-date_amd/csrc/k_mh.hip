@@ -23,7 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "mh_device.hpp"
+#include "mh_inc_device.hpp"
 #include "prior_device.hpp"
 
 namespace mcd {
@@ -216,8 +216,9 @@ constexpr int MHW = 4;                                     // waves per chain (t
 __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P, int p_acc, int jac_root_acc, int p_prop, PropRow row_prop,
                                                             int draw_slot, uint64_t step_acc, uint64_t seed, int accumulate_now,
                                                             double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int prior_inline,
-                                                            TreeDev T, int n_dim, double* __restrict__ X1, int64_t ldx)
+                                                            TreeDev T, int n_dim, double* __restrict__ X1, int64_t ldx, MhInc I, MvnDev V)
 {
+    __shared__ IncShared incsh;
     extern __shared__ double sh[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,6 +291,19 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
             if (tid == 1) mine = pc[1];
             if (tid == 2) mine = pc[2];
             M.pcomp[b * 3 + tid] = mine;
+        }
+    }
+    if (ok && I.X0 != nullptr && I.mode != 0) {
+        // incremental likelihood (k_mh_inc.hip): the accepted proposal's distances and z = L^-1 (d - mu) become the current ones --
+        // z' from where the pending proposal's likelihood step left it.  (X1 is rewritten below by the same threads, in program order.)
+        for (int j = tid; j < n_dim; j += NT) I.X0[b * ldx + j] = X1[b * ldx + j];
+        double* zc = I.zcur + b * I.NPz;
+        if (I.mode == 1) {
+            const double* zp = I.zprop + b * I.NPz;
+            for (int i = tid; i < I.NPz; i += NT) zc[i] = zp[i];
+        } else {
+            const double* zt = I.zt + ((b >> 4) * I.nr) * 16 + (b & 15);
+            for (int i = tid; i < I.NPz; i += NT) zc[i] = (i < I.nr) ? zt[(int64_t)i * 16] : 0.0;
         }
     }
     if (p_prop < 0) return;
@@ -373,6 +387,17 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
                 d = d * s;
             }
             X1[b * ldx + j] = d;
+        }
+        if (I.X0 != nullptr && I.prop_mode != 2) {
+            // incremental likelihood (k_mh_inc.hip): this proposal moves a few distances, or none -- its ln likelihood here, from the
+            // current z and columns of L^-1, instead of a likelihood launch
+            __syncthreads();                                 // X1 of this chain is written (global, read back by the same workgroup)
+            if (I.prop_mode == 1) {
+                const double ll1 = mh_inc_ll_block(V, I, X1 + b * ldx, I.X0 + b * ldx, I.zcur + b * I.NPz, I.zprop + b * I.NPz, incsh, tid);
+                if (tid == 0) M.post1[B + b] = ll1;
+            } else if (tid == 0) {
+                M.post1[B + b] = M.post[B + b];
+            }
         }
     }
     if (!prior_inline) {                                   // the ln prior is evaluated beside the likelihood (mh_prior_role.hpp)
@@ -483,7 +508,7 @@ bool mh_step_wg_active(const MhDev& M, int prior_inline)
 
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, int draw_slot,
                           uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
-                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st)
+                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st, const MhInc* inc, const MvnDev* V)
 {
     const PropRow row_{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
     if (mh_step_wg_active(M, prior_inline)) {
@@ -492,7 +517,7 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
         const bool dist = T != nullptr && X1 != nullptr;
         hipLaunchKernelGGL(k_mh_step_wg, dim3((unsigned)M.batch), dim3(64 * MHW), lds, st, M, P, p_acc, jac_root_acc, p_prop, row_, draw_slot,
                            step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline, dist ? *T : TreeDev{}, n_dim,
-                           dist ? X1 : (double*)nullptr, ldx);
+                           dist ? X1 : (double*)nullptr, ldx, (dist && inc && V) ? *inc : MhInc{}, (dist && inc && V) ? *V : MvnDev{});
         return hipGetLastError();
     }
     if (X1 != nullptr) return hipErrorInvalidValue;        // (the caller asked for distances: only the workgroup kernel writes them)

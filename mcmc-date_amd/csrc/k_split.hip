@@ -920,7 +920,7 @@ static int pick_variant(const SplitHost* s, int64_t batch)
 // MODE 0: ll.  MODE 1: ll + gradient: the z pass, the y pass (schedule of J W^T J) and, for tree states, the chain rule.
 template <bool TREE, int MODE>
 static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch, double* ll, double* G, int64_t ldg, double* gR, double* gtH,
-                               double* grMu, hipStream_t st)
+                               double* grMu, hipStream_t st, bool z_only = false, const double** zt_out = nullptr, int* nr_out = nullptr)
 {
     if (batch <= 0) return hipSuccess;
     SplitHost* s = const_cast<SplitHost*>(M.split);
@@ -951,7 +951,13 @@ static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch,
     default: return hipErrorInvalidValue;
     }
     if (hipError_t e = hipGetLastError()) return e;
+    if (zt_out) *zt_out = set.zt;
+    if (nr_out) *nr_out = 16 * S.NB;
     if constexpr (MODE == 1) {
+        if (z_only) {                                        // ll and the z tiles only (the incremental Metropolis-Hastings path keeps z)
+            if (probe) scratch_retire(s, st);
+            return hipGetLastError();
+        }
         const SplitSched& Sb = s->sched_b[v];
         if (Sb.G != S.G || Sb.nc != S.nc) return hipErrorInvalidValue;
         Gr.out = TREE ? set.yt : G;
@@ -984,6 +990,16 @@ hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, in
     A.X = X;
     A.ldx = ldx;
     return launch_split<false, 0>(M, A, batch, ll, nullptr, 0, nullptr, nullptr, nullptr, st);
+}
+
+// ll, and z = L^-1 (x - mu) left tile-major in the stream's scratch set: element (row r, chain b) at zt[((b / 16) nr + r) 16 + b % 16];
+// valid until the next gradient-type launch on the stream (k_mh_inc.hip copies what it keeps)
+hipError_t launch_logpdf_split_z(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, const double** zt, int* nr, hipStream_t st)
+{
+    WideSrc A{};
+    A.X = X;
+    A.ldx = ldx;
+    return launch_split<false, 1>(M, A, batch, ll, nullptr, 0, nullptr, nullptr, nullptr, st, true, zt, nr);
 }
 
 // ll and d ll / d x = -Sigma^-1 (x - mu) as two triangular products on the row-split schedule (G may be X: the first launch

@@ -48,7 +48,10 @@ struct mcd_mh {
     bool have_state = false;
     bool chain_kernel = false;   // n_nodes <= 64: whole schedule in one launch
     double* d_X1 = nullptr;         // [batch][n]: distances of the proposed states (large trees: written by k_mh_step_wg)
+    double* d_inc_ll = nullptr;     // [batch] ln likelihood output of the refreshing full products (not used)
+    mcd::MhInc inc{};               // incremental likelihood of that path (k_mh_inc.hip): X0, zcur, zprop allocated on first use
     std::vector<mcd::MhRow> rows;   // host copy of the proposal table
+    std::vector<int32_t> sparse_rows;   // per row: 1 = moves at most kMhSparseSlots distances (MhDev::sparse)
     const double* d_Fp = nullptr;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
@@ -246,6 +249,7 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
             sparse[(size_t)i] = (known && slots_of(touched) <= mcd::kMhSparseSlots) ? 1 : 0;
         }
     }
+    m->sparse_rows = sparse;
     m->device = dev_t;
     m->seed = seed;
     for (int i = 0; i < n_prop; ++i) m->rows.push_back(mcd::MhRow{kind[i], node[i], n1[i], n2[i], jac_root[i], p0[i], p1[i]});
@@ -534,10 +538,45 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         m->last_path = use_x ? MCD_MH_PATH_STEP_WG_X : beside ? MCD_MH_PATH_TWO_LAUNCH_PRIOR_BESIDE : MCD_MH_PATH_TWO_LAUNCH;
         const mcd::TreeDev* Tx = use_x ? m->tree : nullptr;
         double* X1 = use_x ? m->d_X1 : nullptr;
+        // Large trees at a sampler's batch: the likelihood launch only for the proposals that move many distances (k_mh_inc.hip);
+        // the others are evaluated from columns of L^-1 on the kept z.  MCD_MH_INCREMENTAL=0: the full evaluation at every step.
+        const char* env_inc = getenv("MCD_MH_INCREMENTAL");
+        const bool inc = use_x && !(env_inc && env_inc[0] == '0') && m->mvn->Wc != nullptr && 64 * m->mvn->R <= 1024 &&
+                         mcd::use_split(*m->mvn, D.batch);
+        mcd::MhInc& I = m->inc;
+        if (inc && I.X0 == nullptr) {
+            I.NPz = 64 * m->mvn->R;
+            MHIP_TRY(hipMalloc((void**)&I.X0, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
+            m->allocs.push_back(I.X0);
+            MHIP_TRY(hipMalloc((void**)&I.zcur, sizeof(double) * (size_t)D.batch * (size_t)I.NPz));
+            m->allocs.push_back(I.zcur);
+            MHIP_TRY(hipMalloc((void**)&I.zprop, sizeof(double) * (size_t)D.batch * (size_t)I.NPz));
+            m->allocs.push_back(I.zprop);
+            MHIP_TRY(hipMalloc((void**)&m->d_inc_ll, sizeof(double) * (size_t)D.batch));
+            m->allocs.push_back(m->d_inc_ll);
+        }
+        auto refresh_z = [&]() -> int {                      // zcur <- L^-1 (X0 - mu) by a full product (the row-split kernel's z tiles)
+            MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, I.X0, n_dim, D.batch, m->d_inc_ll, &I.zt, &I.nr, m->stream));   // (its ll is not used)
+            MHIP_TRY(mcd::launch_mh_inc_take_z(D, I, m->stream));
+            return MCD_OK;
+        };
+        if (inc) {
+            I.mode = 0;
+            MHIP_TRY(mcd::launch_mh_inc_init(D, *m->tree, I, n_dim, n_dim, m->stream));
+            if (int rc = refresh_z()) return rc;
+        }
+        auto moves_likelihood = [&](int p) { return !(m->rows[p].kind == MCD_PROP_SCALE_SCALAR && (m->rows[p].node == 0 || m->rows[p].node == 1 || m->rows[p].node == 4)); };
+        auto inc_mode = [&](int p) { return p < 0 ? 0 : !moves_likelihood(p) ? 0 : m->sparse_rows[(size_t)p] ? 1 : 2; };
+        I.prop_mode = inc ? inc_mode(schedule[0]) : 0;
         MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr,
-                                     prior_inline, Tx, n_dim, X1, n_dim, m->stream));
+                                     prior_inline, Tx, n_dim, X1, n_dim, m->stream, inc ? &I : nullptr, m->mvn));
         for (int64_t gs = 0; gs < total; ++gs) {
-            if (use_x)
+            const int pa = schedule[gs];
+            if (inc) {
+                I.mode = inc_mode(pa);                       // the step kernel evaluated modes 0 and 1 itself
+                if (I.mode == 2)
+                    MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, &I.zt, &I.nr, m->stream));
+            } else if (use_x)
                 MHIP_TRY(mcd::launch_logpdf(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, m->stream));
             else if (beside)
                 MHIP_TRY(mcd::launch_tree_logpdf_with_prior(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
@@ -546,15 +585,21 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, D.H1, D.R1, D.ld, D.sc1 + 2 * D.batch, D.sc1 + 3 * D.batch, D.batch,
                                                  D.post1 + D.batch, D.post1 + 2 * D.batch, m->stream));
             const bool closes = ((gs + 1) % S) == 0;
-            const int pa = schedule[gs], pn = (gs + 1 < total) ? schedule[gs + 1] : -1;
+            const int pn = (gs + 1 < total) ? schedule[gs + 1] : -1;
             if (pn >= 0)
                 if (int rc = draws_for(gs + 1)) return rc;
+            const bool refresh_now = inc && ((gs + 1) & 255) == 0;
+            I.prop_mode = inc ? inc_mode(pn) : 0;
             MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, (int)((gs + 1) & 63), m->step,
                                          m->seed, (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
-                                         trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream));
+                                         trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream,
+                                         inc ? &I : nullptr, m->mvn));
+            if (refresh_now)                                 // (X0 is exact; z has been updated column by column since the last full product)
+                if (int rc = refresh_z()) return rc;
             m->step += 1;
             if (accumulate && closes) m->n_samples += 1;
         }
+        if (inc) m->last_path = MCD_MH_PATH_STEP_WG_INCREMENTAL;
     }
     if (trace_alpha) MHIP_TRY(hipMemcpyAsync(trace_alpha, m->d_trace_alpha, sizeof(double) * steps * B, hipMemcpyDeviceToHost, m->stream));
     if (trace_accept) MHIP_TRY(hipMemcpyAsync(trace_accept, m->d_trace_accept, steps * B, hipMemcpyDeviceToHost, m->stream));

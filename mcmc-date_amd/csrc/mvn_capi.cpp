@@ -285,7 +285,8 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
         HIP_TRY(hipMemcpy(h->d_Wtb, Wtb.data(), Wtb.size() * sizeof(double), hipMemcpyHostToDevice));
         h->dev.Wt = h->d_Wt;
         h->dev.Wtb = h->d_Wtb;
-        if (h->R >= 2 && h->R <= 4) {        // the streaming Metropolis-Hastings chain kernel's sizes: columns of W for sparse proposals
+        if (h->R >= 2) {                     // columns of W for the incremental evaluation of sparse Metropolis-Hastings proposals
+                                             // (k_mh_chain_big.hip at R <= 4, k_mh_inc.hip above)
             std::vector<double> Wc((size_t)n * NP, 0.0);
             for (int j = 0; j < n; ++j)
                 for (int i = j; i < n; ++i) Wc[(size_t)j * NP + i] = W[(size_t)i * n + j];

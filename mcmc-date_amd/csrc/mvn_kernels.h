@@ -134,6 +134,20 @@ struct Mc3Dev {
     unsigned long long *tried, *accepted;   // [n_chains - 1] swaps between the ranks i and i + 1
 };
 
+// Incremental likelihood of the two-launch Metropolis-Hastings path on large trees (k_mh_inc.hip): distances and z = L^-1 (d - mu) of
+// every chain's CURRENT state, z' of the pending proposal; mode = how the pending proposal's z' reaches zcur when it is accepted.
+struct MhInc {
+    double* X0;          // [batch][ldx] distances of the current states
+    double* zcur;        // [batch][NPz]
+    double* zprop;       // [batch][NPz] z' of a pending sparse proposal
+    const double* zt;    // tile-major z' of a pending dense proposal (k_split's scratch), nr rows per tile
+    int NPz, nr;
+    int mode;            // of the PENDING proposal: 0 likelihood not moved, 1 sparse (zprop), 2 dense (zt)
+    int prop_mode;       // of the proposal k_mh_step_wg is about to make: 0 / 1: it writes ll' itself (1: by columns of L^-1), 2: the row-split launch follows
+};
+hipError_t launch_mh_inc_init(const MhDev& M, const TreeDev& T, const MhInc& I, int n_dim, int64_t ldx, hipStream_t st);   // X0 from the current states
+hipError_t launch_mh_inc_take_z(const MhDev& M, const MhInc& I, hipStream_t st);                                          // zcur <- zt, all chains
+
 // Workspace of the device leapfrog (k_hmc.hip); all pointers are device memory.
 struct HmcDev {
     int n_nodes, dim, root_right;
@@ -193,6 +207,7 @@ hipError_t launch_logpdf_split(const MvnDev& M, const double* X, int64_t ldx, in
 hipError_t launch_tree_logpdf_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                     const double* rMu, int64_t batch, double* ll, double* logjac, hipStream_t st);
 hipError_t launch_grad_split(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, hipStream_t st);
+hipError_t launch_logpdf_split_z(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, const double** zt, int* nr, hipStream_t st);
 hipError_t launch_tree_grad_split(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                   const double* rMu, int64_t batch, double* ll, double* gH, double* gR, double* gtH, double* grMu, hipStream_t st);
 bool use_split_grad(const MvnDev& M, int64_t batch);
@@ -236,7 +251,7 @@ struct MhRow {
 // accept the pending step of proposal p_acc (< 0: none) and propose proposal p_prop (< 0: none) with the ln prior of its proposed state
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& row_prop, int draw_slot,
                           uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
-                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st);
+                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st, const MhInc* inc = nullptr, const MvnDev* V = nullptr);
 // true: launch_mh_step takes the workgroup-per-chain kernel, which can also leave the proposed states' distances in X1 [batch][ldx]
 // (T, n_dim, X1 given) for a plain-vector likelihood launch
 bool mh_step_wg_active(const MhDev& M, int prior_inline);

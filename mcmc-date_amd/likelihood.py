@@ -546,7 +546,10 @@ def likelihood_function(lhd: LikelihoodData, topo: Topology, device: int = 0) ->
 
     Returns a pure function State -> log-likelihood (log domain) that evaluates on the GPU.
     """
-    tl = MvnLikelihood(lhd, device).bind_tree(topo)
+    if isinstance(lhd, Sparse) and len(lhd.mu) > 1024:           # beyond the dense kernels: the precision matrix stays sparse on the device
+        tl = SparseLikelihood(lhd, device).bind_tree(topo)
+    else:
+        tl = MvnLikelihood(lhd, device).bind_tree(topo)
 
     def f(x: State) -> float:
         ll, _ = tl.loglik(StateBatch.from_states([x]), want_jacobian=False)

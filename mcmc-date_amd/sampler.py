@@ -355,7 +355,8 @@ class Sampler:
 MC3_STREAM_DOMAIN = 0x4D43335F53574150          # "MC3_SWAP": keeps the swap draws apart from the proposal draws of the same seed
 PATHS = {0: "none", 1: "whole schedule in one launch, factor resident in LDS", 2: "whole schedule in one launch, two chains per workgroup, the factor streamed once per step",
          3: "two launches per lock step, the ln prior of the proposal beside its likelihood", 4: "two launches per lock step (prior inside the step kernel)",
-         5: "two launches per lock step: workgroup-per-chain step kernel leaving distances + plain-vector likelihood"}
+         5: "two launches per lock step: workgroup-per-chain step kernel leaving distances + plain-vector likelihood",
+         6: "workgroup-per-chain step kernel + a likelihood launch only for proposals that move many distances (the others: columns of L^-1 on the kept z)"}
 
 
 def philox4x32(counter, key):

@@ -170,6 +170,7 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
     from mcmc_date_amd import synthetic as S
 
     monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
+    monkeypatch.setenv("MCD_MH_INCREMENTAL", "0")            # (the incremental likelihood of the large-tree path has its own test below)
     topo = S.random_topology(n_leaves, seed=41)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=41)
@@ -259,6 +260,44 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
             assert np.array_equal(getattr(s1, f), getattr(s2, f)), (model, f)
         assert all(np.array_equal(x, y) for x, y in zip(t1, t2))
         assert all(np.allclose(x, y, rtol=1e-13, atol=0) for x, y in zip(g1, g2))      # (sums formed per run, then added: not bitwise)
+
+
+@pytest.mark.parametrize("n_leaves,B", [(200, 40), (513, 64)])
+def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
+    """Trees of more than 320 nodes at a sampler's batch (399 and 1025 nodes here): the workgroup-per-chain step kernel with the
+    likelihood launch only for the proposals that move many distances (k_mh_inc.hip; the others: columns of L^-1 on a z kept in
+    global memory, refreshed by a full product every 256 steps) against the same path with the full evaluation at every step
+    (MCD_MH_INCREMENTAL=0): 1 500 lock steps, identical accept / reject decisions, states, ln priors and ln Jacobians bit for
+    bit, ln acceptance ratios and ln likelihoods within the twin's tolerance."""
+    from mcmc_date_amd import synthetic as S
+
+    topo = S.random_topology(n_leaves, seed=61)
+    n = topo.n_nodes - 2
+    mu, sigma = S.random_spd_problem(n, seed=61)
+    s0 = S.random_states(topo, B, seed=62)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    cal = [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025), M.Calibration("n", 5, 0.2, 0.025, None, 0.0)]
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :1500]
+    runs = []
+    for inc in ("1", "0"):
+        monkeypatch.setenv("MCD_MH_INCREMENTAL", inc)
+        lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+        smp = M.Sampler(lik, M.PriorFunction(1.0, "UncorrelatedGamma", cal, [], [], topo), ps, B, seed=13)
+        smp.set_state(s0)
+        tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
+        a, k = smp.run_schedule(sched[:, :700], accumulate=True, trace=True)
+        a2, k2 = smp.run_schedule(sched[:, 700:], accumulate=True, trace=True)       # a second call starts from a fresh full product
+        assert ("only for proposals that move many distances" in smp.last_path()) == (inc == "1"), smp.last_path()
+        runs.append((np.concatenate([a, a2]), np.concatenate([k, k2]), smp.state(), smp.posterior(), smp.tuning(), smp.age_sums()[:2]))
+    (a1, k1, s1, p1, t1, g1), (a2, k2, s2, p2, t2, g2) = runs
+    assert np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
+    fin = np.isfinite(a2)
+    assert np.array_equal(np.isfinite(a1), fin) and alpha_close(a1[fin], a2[fin], tol), np.max(np.abs(a1[fin] - a2[fin]))
+    for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
+        assert np.array_equal(getattr(s1, f), getattr(s2, f)), f
+    assert np.array_equal(p1[:, [0, 2]], p2[:, [0, 2]]) and np.allclose(p1[:, 1], p2[:, 1], rtol=1e-12, atol=tol)
+    assert all(np.array_equal(x, y) for x, y in zip(t1, t2)) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
 def test_streaming_chain_kernel_over_many_steps_against_the_twin(gpu):
