@@ -325,7 +325,7 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  * n_iter iterations of steps_per_iter proposals; schedule[n_iter * steps_per_iter] = proposal row per step (host).
  * accumulate != 0: after every iteration add the absolute node ages tH * h_v to the running sums.
  * trace_alpha / trace_accept (host, may be NULL): [n_iter * steps_per_iter][batch] ln acceptance ratio / decision.
- * Trees of at most 64 nodes: the whole schedule in one launch, the factor of Sigma in LDS; up to 258 nodes (N <= 256) and 1024 chains: the
+ * Trees of at most 64 nodes: the whole schedule in one launch, the factor of Sigma in LDS; up to 514 nodes (N <= 512) and 1024 chains: the
  * same with the factor streamed through LDS once per step.  Larger trees or batches: two launches per step -- accept the pending
  * proposal and propose the next one; then ln likelihood of the proposed states, which up to 256 dimensions also carries their ln
  * prior as workgroups of a second role (both depend on the proposal only).  Environment, read per call, for tests and timing:

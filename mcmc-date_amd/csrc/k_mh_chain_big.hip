@@ -1,4 +1,4 @@
-// k_mh_chain_big.hip -- a whole Metropolis-Hastings-Green schedule in ONE launch for trees of 65 .. 258 nodes at a sampler's
+// k_mh_chain_big.hip -- a whole Metropolis-Hastings-Green schedule in ONE launch for trees of 65 .. 514 nodes at a sampler's
 // batch (gfx950).  SURVEY.md 8(f) row f2; the persistent form VERDICT (round 1, item 5) asked for, with the factor streamed
 // instead of resident: it does not fit (263 KB at N = 255), but it stays in L2, every workgroup streams it at the same time, and
 // what a launch per step really costs -- 1.7 us of dispatch twice per step, every chain's state, posterior terms, tuning
@@ -46,15 +46,47 @@ __device__ __forceinline__ bool mhb_moves_likelihood(int kind, int node)
     return !(kind == MCD_PROP_SCALE_SCALAR && (node == 0 || node == 1 || node == 4));
 }
 
-// LDS per chain (doubles): 4 state rows, tuning parameters, counters (two int32 per double)
-// (+ round 3: the per-node summands of the birth-death and the clock block of the ln prior, current and proposed, with the step
-// that wrote the proposed one: 4 n_nodes doubles + 2 n_nodes int32)
-__host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int n_prop) { return 9 * (size_t)n_nodes + 2 * (size_t)n_prop + 1; }
+// LDS per chain (doubles): 4 state rows; the per-node summands of the birth-death and the clock block of the ln prior, current and
+// proposed, with the step that wrote the proposed one (4 n_nodes doubles + 2 n_nodes int32).  The tuning parameters and the
+// accept / try counters ([n_prop] each: 22 KiB per chain at 385 nodes) stay in global memory -- a step reads one tuning parameter and
+// bumps two counters -- which is what lets trees of up to 514 nodes (N <= 512, R = 6 and 8) fit beside the 64-KiB ring.
+__host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int /*n_prop*/) { return 9 * (size_t)n_nodes + 1; }
 // ... and per workgroup: the tree tables (five int32 arrays of n_nodes, rounded up to doubles)
 __host__ __device__ inline size_t mhb_table_doubles(int n_nodes) { return (5 * (size_t)n_nodes + 1) / 2 + 1; }
 
 constexpr int kMhbRefresh = 256;   // steps between two recomputations of z by a full sweep of the current state (a power of two)
-constexpr int kMhbCols = 4;        // columns of L^-1 in flight per batch of moved distances
+// One pass of the loader waves over the factor, as a function of its own: inside the kernel its staging registers were allocated
+// together with the chain role's code and spilled from R = 6 up (76 / 674 registers at R = 6 / 8); a call costs a few hundred cycles
+// per pass of some 14 000.
+template <int R, int LW>
+__device__ __forceinline__ void mhb_stream_pass_body(const double* __restrict__ Ft, d2* ring, int lw, int lane, int ncols)
+{
+    MCD_ACC_DECL
+    Stage<R, LW> st;
+    // chunk 0 into the ring, chunks 1 and 2 requested -- all of it while the chain waves propose and evaluate the prior
+    // (the stand-alone launch requests 1 and 2 after the barrier, out of the way of the compute waves' state loads;
+    // here nothing competes and the stream's first round trip would be exposed at every step)
+    fwd_loader_prologue<R, LW>(Ft, ring, st, lw, lane);
+    fwd_loader_start<R, LW>(Ft, st, lw, lane);
+    lds_barrier();
+    fwd_loader<R, LW, 0>(Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
+}
+template <int R, int LW>
+__device__ __noinline__ void mhb_stream_pass_call(const double* __restrict__ Ft, d2* ring, int lw, int lane, int ncols)
+{
+    mhb_stream_pass_body<R, LW>(Ft, ring, lw, lane, ncols);
+}
+// (R <= 4 keeps the body inline: no call frame, no scratch at all in those instantiations)
+template <int R, int LW>
+__device__ __forceinline__ void mhb_stream_pass(const double* __restrict__ Ft, d2* ring, int lw, int lane, int ncols)
+{
+    if constexpr (R <= 4)
+        mhb_stream_pass_body<R, LW>(Ft, ring, lw, lane, ncols);
+    else
+        mhb_stream_pass_call<R, LW>(Ft, ring, lw, lane, ncols);
+}
+
+template <int R> struct MhbCols { static constexpr int N = (R <= 4) ? 4 : 2; };   // columns of L^-1 in flight per batch of moved distances
 
 template <int R>
 __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, TreeDev T, PriorDev P, const int32_t* __restrict__ sched,
@@ -74,26 +106,18 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     // ---- loader waves: one pass over the factor per step that needs the likelihood
     if (wave >= CW) {
         const int lw = wave - CW;
-        Stage<R, LW> st;
         int p = sched[0];
         int kind = M.kind[p], node = M.node[p];
         const bool inc = V.Wc != nullptr;
         int sp = inc ? M.sparse[p] : 0;
-        auto stream_once = [&]() {
-            // chunk 0 into the ring, chunks 1 and 2 requested -- all of it while the chain waves propose and evaluate the prior
-            // (the stand-alone launch requests 1 and 2 after the barrier, out of the way of the compute waves' state loads;
-            // here nothing competes and the stream's first round trip would be exposed at every step)
-            fwd_loader_prologue<R, LW>(V.Ft, ring, st, lw, lane);
-            fwd_loader_start<R, LW>(V.Ft, st, lw, lane);
-            lds_barrier();
-            fwd_loader<R, LW, 0>(V.Ft, ring, st, lw, lane, ncols MCD_ACC_ARGS);
-        };
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
             const int sp_next = inc ? M.sparse[p_next] : 0;
-            if (inc && (gs & (kMhbRefresh - 1)) == 0) stream_once();               // z of the current state: start of the launch, then every 256 steps
-            if (mhb_moves_likelihood(kind, node) && !sp) stream_once();
+            // z of the current state (start of the launch, then every 256 steps), then the step's own sweep if its proposal is dense
+            // (one call site: the stream is a long unrolled body)
+            const int passes = ((inc && (gs & (kMhbRefresh - 1)) == 0) ? 1 : 0) + ((mhb_moves_likelihood(kind, node) && !sp) ? 1 : 0);
+            for (int r = 0; r < passes; ++r) mhb_stream_pass<R, LW>(V.Ft, ring, lw, lane, ncols);
             kind = kind_next;
             node = node_next;
             sp = sp_next;
@@ -132,10 +156,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     double* Rc = Hc + nn;
     double* Hp = Rc + nn;
     double* Rp = Hp + nn;
-    double* tune = Rp + nn;
-    int32_t* acc = reinterpret_cast<int32_t*>(tune + NP);
-    int32_t* tried = acc + NP;
-    double* tbd_cur = tune + 2 * NP;                         // summand of node v in the birth-death block, current state
+    const double* tune = M.tune + b * NP;                    // (constant during a launch: mcd_mh_tune is a call of its own)
+    int32_t* acc = M.acc + b * NP;
+    int32_t* tried = M.tried + b * NP;
+    double* tbd_cur = Rp + nn;                               // summand of node v in the birth-death block, current state
     double* tbd_prop = tbd_cur + nn;                         // ... proposed state, valid where stamp_bd[v] = this step
     double* tcl_cur = tbd_prop + nn;                         // the same for the clock block
     double* tcl_prop = tcl_cur + nn;
@@ -148,11 +172,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         Rc[w] = M.R[b * M.ld + w];
         Hp[w] = Hc[w];                                       // invariant between steps: proposed arrays = current arrays
         Rp[w] = Rc[w];
-    }
-    for (int i = lane; i < NP; i += 64) {
-        tune[i] = M.tune[b * NP + i];
-        acc[i] = M.acc[b * NP + i];
-        tried[i] = M.tried[b * NP + i];
     }
     double sc[5];
 #pragma unroll
@@ -242,10 +261,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     (void)distances(Hc, Rc, sc[2] * sc[3], dcur);
 #pragma unroll
     for (int k = 0; k < R; ++k) zc[k] = 0.0;
-    constexpr int NAGE = 5;                                  // strides of 64 nodes: n_nodes <= 258 + room
-    double age_s[NAGE], age_q[NAGE];
-#pragma unroll
-    for (int i = 0; i < NAGE; ++i) age_s[i] = age_q[i] = 0.0;
     const double beta = M.beta[b];
 #ifdef MCD_MHB_STAMP
     // diagnostic build (make stamp_mhbig): s_memtime ticks per phase, summed over the run, in the first rows of trace_alpha
@@ -285,7 +300,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
         const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
         const int sparse_next = inc ? M.sparse[p_next] : 0;
-        if (inc && (gs & (kMhbRefresh - 1)) == 0) (void)sweep(dcur, zc);   // (the loaders stream for it: same condition)
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
             // parameter (as k_mh_chain.hip, and as k_mh_draws does for the two-launch path)
@@ -321,15 +335,15 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         double vp[R], dl[R];
         double lj1 = lj;
         uint64_t mk[R];
-        int cj[kMhbCols];
-        double cd[kMhbCols], col[kMhbCols][R];
+        int cj[MhbCols<R>::N];
+        double cd[MhbCols<R>::N], col[MhbCols<R>::N][R];
         int ccnt = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k) mk[k] = 0;
-        auto fetch_cols = [&]() {                             // up to kMhbCols moved distances, in row order: their columns requested
+        auto fetch_cols = [&]() {                             // up to MhbCols<R>::N moved distances, in row order: their columns requested
             ccnt = 0;
 #pragma unroll
-            for (int c = 0; c < kMhbCols; ++c) {
+            for (int c = 0; c < MhbCols<R>::N; ++c) {
                 int j = (c > 0) ? cj[c - 1] : 0;
                 double d_ = 0.0;                              // no more: the previous column again with weight 0 (exact)
                 bool got = false;
@@ -444,26 +458,46 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         MHB_TICK(2)
         double ll1 = ll;
         double zp[R];
+        // The sweeps of this step, ONE call site (the sweep is a long unrolled body): first z of the CURRENT state when it is due
+        // (start of the launch, then every 256 steps: the loaders stream for it under the same condition), then the step's own if its
+        // proposal is dense.
+        const bool refresh_now = inc && (gs & (kMhbRefresh - 1)) == 0;
+        const bool dense_step = moves && !sparse_step;
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool rf = pass == 0 && refresh_now;
+            if (!rf && !(pass == 1 && dense_step)) continue;
+            double vin[R], zout[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) zp[k] = zc[k];
+            for (int k = 0; k < R; ++k) vin[k] = rf ? dcur[k] : vp[k];
+            const double q = sweep(vin, zout);
+            if (rf) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) zc[k] = zout[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) zp[k] = zout[k];
+                ll1 = V.c + (-0.5) * (V.logdet + q);         // :169 (finish_ll)
+            }
+        }
+        if (!dense_step) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) zp[k] = zc[k];
+        }
         if (sparse_step) {
             // z' = z + sum_j delta_j W[:, j] over the moved distances, in row order; q' = |z'|^2
             while (true) {
 #pragma unroll
-                for (int c = 0; c < kMhbCols; ++c)
+                for (int c = 0; c < MhbCols<R>::N; ++c)
 #pragma unroll
                     for (int k = 0; k < R; ++k) zp[k] = fma(cd[c], col[c][k], zp[k]);
-                if (ccnt < kMhbCols) break;
-                fetch_cols();                                 // (more than kMhbCols moved: another round trip)
+                if (ccnt < MhbCols<R>::N) break;
+                fetch_cols();                                 // (more than MhbCols<R>::N moved: another round trip)
                 if (ccnt == 0) break;
             }
             double sq = 0.0;
 #pragma unroll
             for (int k = 0; k < R; ++k) sq = fma(zp[k], zp[k], sq);
             const double q = wave_sum(sq);
-            ll1 = V.c + (-0.5) * (V.logdet + q);             // :169 (finish_ll)
-        } else if (moves) {
-            const double q = sweep(vp, zp);
             ll1 = V.c + (-0.5) * (V.logdet + q);             // :169 (finish_ll)
         }
 #ifdef MCD_MHB_STAMP
@@ -513,23 +547,19 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             });
         }
         if (lane == 0) {
-            tried[p] += 1;
-            if (ok) acc[p] += 1;
             if (valid) {
+                tried[p] += 1;                               // (global memory; nothing waits for it)
+                if (ok) acc[p] += 1;
                 if (trace_alpha) trace_alpha[gs * B + b] = la;
                 if (trace_accept) trace_accept[gs * B + b] = ok ? 1 : 0;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (accumulate && (gs + 1) % S == 0) {
-#pragma unroll
-            for (int i = 0; i < NAGE; ++i) {
-                const int w = 64 * i + lane;
-                if (w < nn) {
-                    const double a = sc[2] * Hc[w];
-                    age_s[i] += a;
-                    age_q[i] += a * a;
-                }
+        if (accumulate && valid && (gs + 1) % S == 0) {      // once per iteration of the cycle: straight into the running sums
+            for (int w = lane; w < nn; w += 64) {
+                const double a = sc[2] * Hc[w];
+                M.age_sum[b * nn + w] += a;
+                M.age_sq[b * nn + w] += a * a;
             }
         }
         p = p_next;
@@ -542,21 +572,9 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         for (int i = 0; i < 10; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // ticks: loop head, propose, prior, distances + column requests, sweep or column update, accept
 #endif
     if (!valid) return;
-#pragma unroll
-    for (int i = 0; i < NAGE; ++i) {
-        const int w = 64 * i + lane;
-        if (w < nn) {
-            M.H[b * M.ld + w] = Hc[w];
-            M.R[b * M.ld + w] = Rc[w];
-            if (accumulate) {
-                M.age_sum[b * nn + w] += age_s[i];
-                M.age_sq[b * nn + w] += age_q[i];
-            }
-        }
-    }
-    for (int i = lane; i < NP; i += 64) {
-        M.acc[b * NP + i] = acc[i];
-        M.tried[b * NP + i] = tried[i];
+    for (int w = lane; w < nn; w += 64) {
+        M.H[b * M.ld + w] = Hc[w];
+        M.R[b * M.ld + w] = Rc[w];
     }
     if (lane < 5) {
         double mine = sc[0];
@@ -580,11 +598,11 @@ static size_t mhb_lds_bytes(int n_nodes, int n_prop)
     return sizeof(double) * (mhb_table_doubles(n_nodes) + 2 * mhb_chain_doubles(n_nodes, n_prop));
 }
 
-// trees of 65 .. 258 + 64 nodes whose factor the sweep holds in 2 .. 4 register blocks, a batch of at most two rounds of workgroups
-// (one workgroup per CU: 512 chains per round), state + tables + the 64 KiB ring within a CU's LDS
+// trees of 65 .. 514 nodes whose factor the sweep holds in 2 .. 8 register blocks (N <= 512), a batch of at most two rounds of
+// workgroups (one workgroup per CU: 512 chains per round), state + tables + the 64 KiB ring within a CU's LDS
 bool mh_chain_big_available(const MhDev& M, const MvnDev& V)
 {
-    if (V.R < 2 || V.R > 4 || M.n_nodes > 64 * 5 || M.batch > 1024) return false;   // (1024 chains: two rounds of workgroups, still ahead of two launches per step)
+    if (V.R < 2 || V.R > 8 || M.n_nodes > 64 * V.R + 2 || M.batch > 1024) return false;   // (1024 chains: two rounds of workgroups, still ahead of two launches per step)
     return mhb_lds_bytes(M.n_nodes, M.n_prop) + 64 * 1024 <= 160 * 1024;
 }
 
@@ -620,6 +638,8 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
         case 2: return launch_big_R<2>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         case 3: return launch_big_R<3>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         case 4: return launch_big_R<4>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+        case 6: return launch_big_R<6>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+        case 8: return launch_big_R<8>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         default: return hipErrorInvalidValue;
         }
     }
@@ -627,6 +647,8 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
     case 2: return launch_big_R<2>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     case 3: return launch_big_R<3>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     case 4: return launch_big_R<4>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+    case 6: return launch_big_R<6>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
+    case 8: return launch_big_R<8>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -200,11 +200,12 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
         assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
-@pytest.mark.parametrize("n_leaves,B", [(40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777)])
+@pytest.mark.parametrize("n_leaves,B", [(40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777), (150, 64), (193, 33), (257, 512)])
 @pytest.mark.parametrize("incremental", ["1", "0"])
 def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, incremental, monkeypatch):
-    """Trees of 65 .. 258 nodes at up to 1024 chains (777: two rounds of workgroups) run the whole schedule in one launch, two
-    chains per workgroup, the factor streamed through the sweep's LDS ring (k_mh_chain_big.hip).  The same proposal, prior and sweep
+    """Trees of 65 .. 514 nodes at up to 1024 chains (777: two rounds of workgroups) run the whole schedule in one launch, two
+    chains per workgroup, the factor streamed through the sweep's LDS ring (k_mh_chain_big.hip; 150 / 193 / 257 leaves = 299 / 385 /
+    513 nodes: six and eight 64-row blocks per lane).  The same proposal, prior and sweep
     code on the same numbers as the two-launch path (MCD_MH_PER_PHASE=1) -- odd batches (a chain wave without a chain), two clock
     models, calibrations and a constraint, runs continued by the other path.
     MCD_MH_INCREMENTAL=0 (every proposal through the full sweep): bit-identical traces, states, posteriors, tuning counters, age
@@ -271,6 +272,7 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
     bit, ln acceptance ratios and ln likelihoods within the twin's tolerance."""
     from mcmc_date_amd import synthetic as S
 
+    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")              # (399 nodes would otherwise take the streaming chain kernel)
     topo = S.random_topology(n_leaves, seed=61)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=61)
