@@ -230,27 +230,15 @@ def sparse_measure(dev_index, n, B, steps, warm, band=3, extra=4):
     """The sparse form (csrc/k_sparse.hip; logDensitySparseMultivariateNormal, app/Probability.hs:178-184): a synthetic symmetric,
     diagonally dominant precision matrix with a band and `extra` random entries per row -- the density a graphical-lasso estimate of a
     large tree has -- B chains, device resident.  HBM-priced: the CSR stream (12 bytes per nonzero) once per launch plus the chain vectors."""
-    import scipy.sparse as sps
     import torch
 
     import mcmc_date_amd as M
+    from mcmc_date_amd import synthetic as S
 
     rng = np.random.default_rng(n)
-    rows, cols, vals = [], [], []
-    for d in range(1, band + 1):
-        i = np.arange(n - d)
-        v = rng.uniform(-1.0, 1.0, n - d)
-        rows += [i, i + d]; cols += [i + d, i]; vals += [v, v]
-    i = rng.integers(0, n, n * extra); j = rng.integers(0, n, n * extra)
-    keep = np.abs(i - j) > band
-    i, j = i[keep], j[keep]
-    v = rng.uniform(-0.5, 0.5, len(i))
-    rows += [i, j]; cols += [j, i]; vals += [v, v]
-    A = sps.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
-    A.sum_duplicates()
-    P = ((A + sps.diags(np.abs(A).sum(axis=1).A1 + 1.0)) * 1e3).tocoo()
+    _, assoc = S.banded_precision(n, n, band, extra)
     mu = rng.uniform(0.01, 0.2, n)
-    sp = M.SparseLikelihood(M.Sparse(mu, [((int(a), int(b)), float(c)) for a, b, c in zip(P.row, P.col, P.data)], 0.0), device=dev_index)
+    sp = M.SparseLikelihood(M.Sparse(mu, assoc, 0.0), device=dev_index)
     dev = torch.device("cuda", dev_index)
     X = torch.as_tensor(mu + 0.01 * rng.standard_normal((B, n)), device=dev)
     ll = torch.empty(B, dtype=torch.float64, device=dev)

@@ -311,6 +311,15 @@ typedef struct mcd_mh mcd_mh_t;
 int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
                   const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
                   const double* p0, const double* p1, int64_t batch, uint64_t seed);
+/* The same driver over a likelihood whose precision matrix stays sparse on the device (mcd_sparse_tree_create): the reference's
+ * configuration for trees with thousands of branches -- `mhg` with likelihoodFunction (Sparse ...) (app/Main.hs:474, 333-347;
+ * app/Probability.hs:178-184, 279).  Trees of 321 .. 2048 nodes (smaller ones take the dense handle); two launches per lock step: the
+ * step kernel leaves the proposed states' distances, the sparse product runs on them.  Everything else (mcd_mh_set_state, _run,
+ * _tune, _mc3_*, ...) as for mcd_mh_create.  The mcd_sparse_tree_t type is declared with the sparse form below. */
+struct mcd_sparse_tree;
+int mcd_mh_create_sparse(mcd_mh_t** out, const struct mcd_sparse_tree* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
+                         const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
+                         const double* p0, const double* p1, int64_t batch, uint64_t seed);
 void mcd_mh_destroy(mcd_mh_t* m);
 /* first_chain: global index of this handle's chain 0 (chain shards on several GPUs draw disjoint random streams). */
 int mcd_mh_set_chain_offset(mcd_mh_t* m, int64_t first_chain);
@@ -343,6 +352,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t ste
 #define MCD_MH_PATH_TWO_LAUNCH 4              /* step (prior inside) + likelihood launch */
 #define MCD_MH_PATH_STEP_WG_X 5               /* workgroup-per-chain step leaving distances + plain-vector likelihood launch */
 #define MCD_MH_PATH_STEP_WG_INCREMENTAL 6     /* the same, the likelihood launch only for proposals that move many distances (k_mh_inc.hip) */
+#define MCD_MH_PATH_STEP_WG_SPARSE 7          /* workgroup-per-chain step leaving distances + the sparse product on them (mcd_mh_create_sparse) */
 int mcd_mh_last_path(const mcd_mh_t* m);
 /* Auto tuning at the end of a tuning period [mcmc]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3). */
 int mcd_mh_tune(mcd_mh_t* m);

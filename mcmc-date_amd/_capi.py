@@ -81,6 +81,7 @@ SYMBOLS = {
     "mcd_hmc_nuts_run": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp, _dp, _dp]),
     "mcd_hmc_nuts_warmup": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp]),
     "mcd_mh_create": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
+    "mcd_mh_create_sparse": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, C.c_int64, C.c_uint64]),
     "mcd_mh_destroy": (None, [_vp]),
     "mcd_mh_set_chain_offset": (C.c_int, [_vp, C.c_int64]),
     "mcd_mh_set_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int64]),

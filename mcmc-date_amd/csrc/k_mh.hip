@@ -24,6 +24,8 @@
 #include <stdlib.h>
 
 #include "mh_inc_device.hpp"
+
+#include <atomic>
 #include "prior_device.hpp"
 
 namespace mcd {
@@ -503,7 +505,7 @@ bool mh_step_wg_active(const MhDev& M, int prior_inline)
     const char* env = getenv("MCD_MH_STEP_WG");
     const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > 320);
     const int NIT = (M.n_nodes - 1 + 63) / 64;
-    return wg && sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 48) <= 64 * 1024;
+    return wg && sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 48) + sizeof(IncShared) <= 144 * 1024;   // (above 64 KiB: allowed at launch)
 }
 
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& r, int draw_slot,
@@ -515,6 +517,16 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
         const int NIT = (M.n_nodes - 1 + 63) / 64;
         const size_t lds = sizeof(double) * (4 * (size_t)M.n_nodes + 2 * (size_t)NIT * 64 + 48);
         const bool dist = T != nullptr && X1 != nullptr;
+        if (lds > 64 * 1024) {                               // trees beyond about 1 300 nodes: more than 64 KiB of LDS has to be allowed once per device
+            static std::atomic<unsigned long long> allowed{0};
+            int dev = 0;
+            if (hipError_t e = hipGetDevice(&dev)) return e;
+            if (dev < 0 || dev >= 64 || lds + sizeof(IncShared) > 160 * 1024) return hipErrorInvalidValue;
+            if (!((allowed.load(std::memory_order_acquire) >> dev) & 1ull)) {
+                if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_step_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)) return e;
+                allowed.fetch_or(1ull << dev, std::memory_order_release);
+            }
+        }
         hipLaunchKernelGGL(k_mh_step_wg, dim3((unsigned)M.batch), dim3(64 * MHW), lds, st, M, P, p_acc, jac_root_acc, p_prop, row_, draw_slot,
                            step_acc, seed, accumulate_now, trace_alpha, trace_accept, prior_inline, dist ? *T : TreeDev{}, n_dim,
                            dist ? X1 : (double*)nullptr, ldx, (dist && inc && V) ? *inc : MhInc{}, (dist && inc && V) ? *V : MvnDev{});

@@ -16,6 +16,11 @@
 #include "mvn_kernels.h"
 
 extern "C" int mcd_set_last_error_(int code, const char* msg);   // mvn_capi.cpp
+struct mcd_sparse;
+struct mcd_sparse_tree;
+int mcd_sparse_tree_internal_(const mcd_sparse_tree* t, const mcd_sparse** sp, const mcd::SparseDev** dev, const mcd::SparseTreeDev** tree, int* device,
+                              const int32_t** host_parent);   // sparse_capi.cpp
+int mcd_sparse_scratch_(const mcd_sparse* h, hipStream_t st, int64_t batch, double** out);
 
 namespace {
 
@@ -42,6 +47,12 @@ struct mcd_mh {
     const mcd::MvnDev* mvn = nullptr;
     const mcd::TreeDev* tree = nullptr;
     const mcd::PriorDev* prior = nullptr;
+    // a likelihood over a SPARSE precision matrix instead (mcd_mh_create_sparse): mvn stays null, tree points at tree_shim (the slot
+    // tables the step kernel needs for the distances)
+    const mcd_sparse* sp_handle = nullptr;
+    const mcd::SparseDev* sp = nullptr;
+    const mcd::SparseTreeDev* sp_tree = nullptr;
+    mcd::TreeDev tree_shim{};
     mcd::MhDev dev{};
     uint64_t seed = 0, step = 0;
     int64_t n_samples = 0;
@@ -105,6 +116,12 @@ int eval_posterior(mcd_mh* m, const double* sc, const double* H, const double* R
     const int64_t B = D.batch;
     MHIP_TRY(mcd::launch_prior(*m->prior, sc + 0 * B, sc + 1 * B, sc + 2 * B, H, sc + 3 * B, sc + 4 * B, R, D.ld, B, post, D.pcomp,
                                m->stream));
+    if (m->sp) {
+        double* scr = nullptr;
+        if (int rc = mcd_sparse_scratch_(m->sp_handle, m->stream, B, &scr)) return rc;
+        MHIP_TRY(mcd::launch_sparse_tree_logpdf(*m->sp, *m->sp_tree, H, R, D.ld, sc + 2 * B, sc + 3 * B, B, post + B, post + 2 * B, scr, m->stream));
+        return MCD_OK;
+    }
     MHIP_TRY(mcd::launch_tree_logpdf(*m->mvn, *m->tree, H, R, D.ld, sc + 2 * B, sc + 3 * B, B, post + B, post + 2 * B, m->stream));
     return MCD_OK;
 }
@@ -113,22 +130,16 @@ int eval_posterior(mcd_mh* m, const double* sc, const double* H, const double* R
 
 extern "C" {
 
-int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
-                  const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
-                  const double* p0, const double* p1, int64_t batch, uint64_t seed)
+}  // extern "C"
+
+namespace {
+
+// the part of mcd_mh_create / mcd_mh_create_sparse behind the handles: m->mvn / m->tree (dense) or m->sp / m->sp_tree / m->tree
+// (= &m->tree_shim, sparse) and m->prior are set, `parent` is the host copy of the topology, host_L the host factor (dense) or null
+int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t* prior, int dev_t, int dev_p, const int32_t* parent, const double* host_L,
+                   int n_prop, const int32_t* kind, const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root,
+                   const int32_t* dim, const double* p0, const double* p1, int64_t batch, uint64_t seed)
 {
-    if (!out) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: out is NULL");
-    *out = nullptr;
-    if (!tree || !prior) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: NULL tree or prior handle");
-    if (n_prop <= 0 || !kind || !node || !n1 || !n2 || !jac_root || !dim || !p0 || !p1)
-        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: empty or NULL proposal table");
-    if (batch <= 0 || batch > (int64_t)1 << 31) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: batch must be in [1, 2^31]");
-    std::unique_ptr<mcd_mh> m(new mcd_mh());
-    int dev_t = 0, dev_p = 0;
-    const int32_t* parent = nullptr;
-    const double* host_L = nullptr;
-    if (mcd_tree_internal_(tree, &m->mvn, &m->tree, &dev_t, &parent, &host_L) || mcd_prior_internal_(prior, &m->prior, &dev_p))
-        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: invalid handle");
     if (dev_t != dev_p) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree (device %d) and prior (device %d) live on different GPUs", dev_t, dev_p);
     const int n = m->tree->n_nodes;
     if (m->prior->n_nodes != n) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: tree has %d nodes, prior %d", n, m->prior->n_nodes);
@@ -261,7 +272,7 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     D.batch = batch;
     D.ld = (n + 7) / 8 * 8;
     D.chain0 = 0;
-    D.parent = m->tree->parent;
+    D.parent = m->mvn ? m->tree->parent : m->prior->parent;
     D.brace_ptr = m->prior->brace_ptr;
     D.brace_nodes = m->prior->brace_nodes;
     D.n_brace = nbr;
@@ -285,8 +296,8 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     // trees of at most 64 nodes: the whole schedule runs in one launch with the factor staged in LDS (k_mh_chain.hip).
     // MCD_MH_PER_PHASE=1 (diagnostic) keeps the two-launches-per-step path that larger trees use.
     const char* per_phase = getenv("MCD_MH_PER_PHASE");
-    const int nd = m->mvn->n;
-    if (n <= 64 && !(per_phase && per_phase[0] == '1') && mcd::mh_chain_lds_bytes(nd, n_prop, 4) <= 64 * 1024) {
+    const int nd = m->mvn ? m->mvn->n : m->sp->n;
+    if (m->mvn && n <= 64 && !(per_phase && per_phase[0] == '1') && mcd::mh_chain_lds_bytes(nd, n_prop, 4) <= 64 * 1024) {
         std::vector<double> Fp((size_t)nd * 64, 0.0);
         for (int i = 0; i < nd; ++i) {
             const double inv = 1.0 / host_L[(size_t)i * nd + i];
@@ -302,6 +313,56 @@ int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* pri
     }
     *out = m.release();
     return MCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
+                  const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
+                  const double* p0, const double* p1, int64_t batch, uint64_t seed)
+{
+    if (!out) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: out is NULL");
+    *out = nullptr;
+    if (!tree || !prior) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: NULL tree or prior handle");
+    if (n_prop <= 0 || !kind || !node || !n1 || !n2 || !jac_root || !dim || !p0 || !p1)
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: empty or NULL proposal table");
+    if (batch <= 0 || batch > (int64_t)1 << 31) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: batch must be in [1, 2^31]");
+    std::unique_ptr<mcd_mh> m(new mcd_mh());
+    int dev_t = 0, dev_p = 0;
+    const int32_t* parent = nullptr;
+    const double* host_L = nullptr;
+    if (mcd_tree_internal_(tree, &m->mvn, &m->tree, &dev_t, &parent, &host_L) || mcd_prior_internal_(prior, &m->prior, &dev_p))
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create: invalid handle");
+    return mh_create_impl(out, m, prior, dev_t, dev_p, parent, host_L, n_prop, kind, node, n1, n2, jac_root, dim, p0, p1, batch, seed);
+}
+
+// The same driver over a likelihood whose precision matrix stays sparse on the device (mcd_sparse_*): trees beyond the dense kernels'
+// 1024 branches.  Two launches per lock step -- the workgroup-per-chain step kernel leaving the proposed distances, the sparse
+// product on them (k_sparse.hip).
+int mcd_mh_create_sparse(mcd_mh_t** out, const mcd_sparse_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
+                         const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
+                         const double* p0, const double* p1, int64_t batch, uint64_t seed)
+{
+    if (!out) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create_sparse: out is NULL");
+    *out = nullptr;
+    if (!tree || !prior) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create_sparse: NULL tree or prior handle");
+    if (n_prop <= 0 || !kind || !node || !n1 || !n2 || !jac_root || !dim || !p0 || !p1)
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create_sparse: empty or NULL proposal table");
+    if (batch <= 0 || batch > (int64_t)1 << 31) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create_sparse: batch must be in [1, 2^31]");
+    std::unique_ptr<mcd_mh> m(new mcd_mh());
+    int dev_t = 0, dev_p = 0;
+    const int32_t* parent = nullptr;
+    if (mcd_sparse_tree_internal_(tree, &m->sp_handle, &m->sp, &m->sp_tree, &dev_t, &parent) || mcd_prior_internal_(prior, &m->prior, &dev_p))
+        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create_sparse: invalid handle");
+    if (m->sp_tree->n_nodes <= 320 || m->sp_tree->n_nodes > 2048)
+        return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_create_sparse: %d nodes (the sparse driver serves trees of 321 .. 2048 nodes; smaller ones take the dense handle)",
+                     m->sp_tree->n_nodes);
+    m->tree_shim = mcd::TreeDev{m->sp_tree->n_nodes, (m->sp_tree->n_nodes + 63) / 64 * 64, m->sp_tree->root_right, m->prior->parent, m->sp_tree->slot_node,
+                                m->sp_tree->slot_parent, nullptr, nullptr};
+    m->tree = &m->tree_shim;
+    return mh_create_impl(out, m, prior, dev_t, dev_p, parent, nullptr, n_prop, kind, node, n1, n2, jac_root, dim, p0, p1, batch, seed);
 }
 
 void mcd_mh_destroy(mcd_mh_t* m) { delete m; }
@@ -486,7 +547,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
     // larger trees at a sampler's batch: the whole schedule in one launch as well, the factor streamed once per step
     // (k_mh_chain_big.hip).  MCD_MH_PER_PHASE=1 keeps the two-launch path (tests, timing; read per call).
     const char* per_phase_env = getenv("MCD_MH_PER_PHASE");
-    const bool streaming = !m->chain_kernel && !(per_phase_env && per_phase_env[0] == '1') && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
+    const bool streaming = m->mvn && !m->chain_kernel && !(per_phase_env && per_phase_env[0] == '1') && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
                            mcd::mh_chain_big_available(D, *m->mvn);
     if (streaming) {
         m->last_path = MCD_MH_PATH_CHAIN_STREAMED;
@@ -525,12 +586,13 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         const char* env_prior = getenv("MCD_MH_PRIOR");
         // (A launch of its own for the prior with four waves per chain was measured for the larger trees: 58.9 -> 56.4 us per
         // lock step at 1025 nodes, 33.3 -> 35.4 at 513 -- the step kernel's other strided loops weigh more there; not kept.)
-        const bool beside = !(env_prior && atoi(env_prior) == 0) && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
+        const bool beside = m->mvn && !(env_prior && atoi(env_prior) == 0) && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
         const int prior_inline = beside ? 0 : 1;
         // large trees: the step kernel (a workgroup per chain) leaves the proposed states' DISTANCES, the likelihood launch takes
         // them as plain vectors (the row-split kernel's tree staging costs 6 us more at 1023 slots); same arithmetic, same bits
-        const int n_dim = m->mvn->n;
+        const int n_dim = m->mvn ? m->mvn->n : m->sp->n;
         const bool use_x = mcd::mh_step_wg_active(D, prior_inline) && !beside && D.n_nodes > 320;
+        if (m->sp && !use_x) return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_run: the sparse driver needs the workgroup-per-chain step kernel (MCD_MH_STEP_WG must not be 0)");
         if (use_x && m->d_X1 == nullptr) {
             MHIP_TRY(hipMalloc((void**)&m->d_X1, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
             m->allocs.push_back(m->d_X1);
@@ -541,7 +603,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // Large trees at a sampler's batch: the likelihood launch only for the proposals that move many distances (k_mh_inc.hip);
         // the others are evaluated from columns of L^-1 on the kept z.  MCD_MH_INCREMENTAL=0: the full evaluation at every step.
         const char* env_inc = getenv("MCD_MH_INCREMENTAL");
-        const bool inc = use_x && !(env_inc && env_inc[0] == '0') && m->mvn->Wc != nullptr && 64 * m->mvn->R <= 1024 &&
+        const bool inc = m->mvn && use_x && !(env_inc && env_inc[0] == '0') && m->mvn->Wc != nullptr && 64 * m->mvn->R <= 1024 &&
                          mcd::use_split(*m->mvn, D.batch);
         mcd::MhInc& I = m->inc;
         if (inc && I.X0 == nullptr) {
@@ -576,6 +638,10 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 I.mode = inc_mode(pa);                       // the step kernel evaluated modes 0 and 1 itself
                 if (I.mode == 2)
                     MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, &I.zt, &I.nr, m->stream));
+            } else if (m->sp) {
+                double* scr = nullptr;
+                if (int rc = mcd_sparse_scratch_(m->sp_handle, m->stream, D.batch, &scr)) return rc;
+                MHIP_TRY(mcd::launch_sparse_logpdf(*m->sp, X1, n_dim, D.batch, D.post1 + D.batch, scr, m->stream));
             } else if (use_x)
                 MHIP_TRY(mcd::launch_logpdf(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, m->stream));
             else if (beside)
@@ -600,6 +666,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
             if (accumulate && closes) m->n_samples += 1;
         }
         if (inc) m->last_path = MCD_MH_PATH_STEP_WG_INCREMENTAL;
+        if (m->sp) m->last_path = MCD_MH_PATH_STEP_WG_SPARSE;
     }
     if (trace_alpha) MHIP_TRY(hipMemcpyAsync(trace_alpha, m->d_trace_alpha, sizeof(double) * steps * B, hipMemcpyDeviceToHost, m->stream));
     if (trace_accept) MHIP_TRY(hipMemcpyAsync(trace_accept, m->d_trace_accept, steps * B, hipMemcpyDeviceToHost, m->stream));

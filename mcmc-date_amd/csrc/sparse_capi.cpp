@@ -59,6 +59,7 @@ struct mcd_sparse {
 struct mcd_sparse_tree {
     const mcd_sparse* sp = nullptr;
     mcd::SparseTreeDev dev{};
+    std::vector<int32_t> parent;   // host copy (the Metropolis-Hastings driver checks its proposal table against the topology)
     int32_t* d_slot = nullptr;
     ~mcd_sparse_tree()
     {
@@ -118,6 +119,23 @@ struct Scratch {
 };
 
 }  // namespace
+
+// for the Metropolis-Hastings driver (mh_capi.cpp)
+int mcd_sparse_tree_internal_(const mcd_sparse_tree* t, const mcd_sparse** sp, const mcd::SparseDev** dev, const mcd::SparseTreeDev** tree, int* device,
+                              const int32_t** host_parent)
+{
+    if (!t || !t->sp) return MCD_ERR_INVALID_ARG;
+    *sp = t->sp;
+    *dev = &t->sp->dev;
+    *tree = &t->dev;
+    *device = t->sp->device;
+    *host_parent = t->parent.data();
+    return MCD_OK;
+}
+int mcd_sparse_scratch_(const mcd_sparse* h, hipStream_t st, int64_t batch, double** out)
+{
+    return scratch_for(h, st, mcd::sparse_scratch_doubles(h->n, batch, false), out);
+}
 
 extern "C" {
 
@@ -258,6 +276,7 @@ int mcd_sparse_tree_create(mcd_sparse_tree_t** out, const mcd_sparse_t* h, int n
     for (size_t i = 0; i < n; ++i) slot[n + i] = parent[slot[i]];
     std::unique_ptr<mcd_sparse_tree> t(new mcd_sparse_tree());
     t->sp = h;
+    t->parent.assign(parent, parent + n_nodes);
     SHIP_TRY(hipSetDevice(h->device));
     SHIP_TRY(hipMalloc((void**)&t->d_slot, sizeof(int32_t) * slot.size()));
     SHIP_TRY(hipMemcpy(t->d_slot, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice));

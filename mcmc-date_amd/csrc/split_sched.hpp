@@ -13,7 +13,7 @@
 // 2 w).  A run is contiguous, so only its first and its last segment can be partial: 2 SP_NW - 2 slots.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SP_HD __host__ __device__ inline
 #else
 #define SP_HD inline

@@ -219,9 +219,11 @@ class Sampler:
         ip = lambda x: x.ctypes.data_as(_ip)
         dp = lambda x: x.ctypes.data_as(_dp)
         L = _capi.lib()
-        _capi.check(L.mcd_mh_create(C.byref(self._h), tree_lik._t, prior._p, len(self.table), ip(a["kind"]), ip(a["node"]),
-                                    ip(a["n1"]), ip(a["n2"]), ip(a["jac_root"]), ip(a["dim"]), dp(a["p0"]), dp(a["p1"]),
-                                    self.batch, C.c_uint64(seed)))
+        # a SparseTreeLikelihood (precision matrix kept sparse on the device: trees beyond 1024 branches) takes mcd_mh_create_sparse
+        create = L.mcd_mh_create_sparse if type(tree_lik).__name__ == "SparseTreeLikelihood" else L.mcd_mh_create
+        _capi.check(create(C.byref(self._h), tree_lik._t, prior._p, len(self.table), ip(a["kind"]), ip(a["node"]),
+                           ip(a["n1"]), ip(a["n2"]), ip(a["jac_root"]), ip(a["dim"]), dp(a["p0"]), dp(a["p1"]),
+                           self.batch, C.c_uint64(seed)))
         if first_chain:
             _capi.check(L.mcd_mh_set_chain_offset(self._h, int(first_chain)))
         self._sched_rng = np.random.default_rng([int(seed), 0x5EED])
@@ -356,7 +358,8 @@ MC3_STREAM_DOMAIN = 0x4D43335F53574150          # "MC3_SWAP": keeps the swap dra
 PATHS = {0: "none", 1: "whole schedule in one launch, factor resident in LDS", 2: "whole schedule in one launch, two chains per workgroup, the factor streamed once per step",
          3: "two launches per lock step, the ln prior of the proposal beside its likelihood", 4: "two launches per lock step (prior inside the step kernel)",
          5: "two launches per lock step: workgroup-per-chain step kernel leaving distances + plain-vector likelihood",
-         6: "workgroup-per-chain step kernel + a likelihood launch only for proposals that move many distances (the others: columns of L^-1 on the kept z)"}
+         6: "workgroup-per-chain step kernel + a likelihood launch only for proposals that move many distances (the others: columns of L^-1 on the kept z)",
+         7: "two launches per lock step: workgroup-per-chain step kernel leaving distances + the sparse product (precision matrix in CSR)"}
 
 
 def philox4x32(counter, key):

@@ -71,3 +71,30 @@ def random_states(topo: Topology, batch: int, seed: int, jitter: float = 0.05) -
     tH = np.exp(jitter * rng.standard_normal(batch))
     rMu = np.exp(jitter * rng.standard_normal(batch))
     return StateBatch(H, R, tH, rMu)
+
+
+def banded_precision(n: int, seed: int, band: int = 3, extra: int = 4, scale: float = 1e3):
+    """A symmetric, strictly diagonally dominant (hence positive definite) precision matrix: a band plus `extra` random
+    off-diagonal entries per row, values of mixed sign -- the density a graphical-lasso estimate of a large tree has
+    (the reference's `Sparse` likelihood data, app/Probability.hs:178-184).  Returns (scipy CSR matrix, association list
+    [((i, j), value)])."""
+    import scipy.sparse as sps
+
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for d in range(1, band + 1):
+        i = np.arange(n - d)
+        v = rng.uniform(-1.0, 1.0, n - d)
+        rows += [i, i + d]; cols += [i + d, i]; vals += [v, v]
+    i = rng.integers(0, n, n * extra)
+    j = rng.integers(0, n, n * extra)
+    keep = np.abs(i - j) > band
+    i, j = i[keep], j[keep]
+    v = rng.uniform(-0.5, 0.5, len(i))
+    rows += [i, j]; cols += [j, i]; vals += [v, v]
+    A = sps.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    diag = np.abs(A).sum(axis=1).A1 + rng.uniform(0.5, 1.5, n)
+    P = ((A + sps.diags(diag)) * scale).tocsr()              # precisions of branch lengths ~ 1e-2: like the fixtures
+    coo = P.tocoo()
+    return P, [((int(a), int(b)), float(c)) for a, b, c in zip(coo.row, coo.col, coo.data)]

@@ -15,28 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def banded_random_precision(n, seed, band=3, extra=4):
-    """A symmetric, strictly diagonally dominant (hence SPD) precision matrix: a band plus `extra` random off-diagonal entries per
-    row, values of mixed sign; returns (scipy CSR, association list)."""
-    rng = np.random.default_rng(seed)
-    rows, cols, vals = [], [], []
-    for d in range(1, band + 1):
-        i = np.arange(n - d)
-        v = rng.uniform(-1.0, 1.0, n - d)
-        rows += [i, i + d]; cols += [i + d, i]; vals += [v, v]
-    i = rng.integers(0, n, n * extra)
-    j = rng.integers(0, n, n * extra)
-    keep = np.abs(i - j) > band
-    i, j = i[keep], j[keep]
-    v = rng.uniform(-0.5, 0.5, len(i))
-    rows += [i, j]; cols += [j, i]; vals += [v, v]
-    A = sps.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
-    A.sum_duplicates()
-    diag = np.abs(A).sum(axis=1).A1 + rng.uniform(0.5, 1.5, n)
-    P = (A + sps.diags(diag)).tocsr()
-    P = P * 1e3                                              # precisions of branch lengths ~ 1e-2: like the fixtures
-    coo = P.tocoo()
-    assoc = [((int(a), int(b)), float(c)) for a, b, c in zip(coo.row, coo.col, coo.data)]
-    return P, assoc
+    from mcmc_date_amd import synthetic as S
+
+    return S.banded_precision(n, seed, band, extra)
 
 
 def test_reference_sparse_operands_mtcdnapri(gpu):
@@ -155,3 +136,61 @@ def test_structural_faults_and_duplicates(gpu):
         sp1.bind_tree(M.Topology(np.array([-1, 0, 0, 0], dtype=np.int32)))
     with pytest.raises(M.McdError):
         sp.bind_tree(M.Topology(np.array([-1, 0, 1, 1, 0, 4, 4], dtype=np.int32)))     # 7 nodes: dimension 5, not 3
+
+
+@pytest.mark.parametrize("n_leaves,B,n_steps", [(200, 16, 200), (1007, 8, 60)])
+def test_metropolis_hastings_over_a_sparse_likelihood(gpu, n_leaves, B, n_steps):
+    """The lock-step driver over a likelihood whose precision matrix stays sparse on the device (mcd_mh_create_sparse): the
+    reference's configuration for large trees -- `mhg` with likelihoodFunction (Sparse ...) -- at 399 nodes and at the size of its
+    1007-taxon example (2013 nodes, N = 2011: beyond the dense kernels).  Step by step against the CPU twin, which evaluates the
+    same precision matrix densely: identical accept / reject decisions, ln acceptance ratios within the twin's tolerance, final
+    states within 1e-9."""
+    from mcmc_date_amd import synthetic as S
+
+    topo = S.random_topology(n_leaves, seed=9)
+    n = topo.n_nodes - 2
+    P, assoc = banded_random_precision(n, seed=n)
+    rng = np.random.default_rng(10)
+    s0 = S.random_states(topo, B, seed=11)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    # the mean vector near the states' distances, so that ln likelihoods are of the size a sampler sees
+    D = np.array([O.distances(topo.parent, s0.heights[b], s0.rates[b], s0.time_height[b], s0.rate_mean[b]) for b in range(B)])
+    mu = D.mean(axis=0)
+    Pd = P.toarray()
+    logdet = -float(np.linalg.slogdet(Pd)[1])
+    sp = M.SparseLikelihood(M.Sparse(mu, assoc, logdet))
+    tl = sp.bind_tree(topo)
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    smp = M.Sampler(tl, pf, ps, B, seed=13)
+    smp.set_state(s0)
+    spec = O.PriorSpec(topo.parent, 1.0, "UncorrelatedGamma", [], [], [])
+    twin = O.MhChains(O.MhModel(topo.parent, mu, Pd, logdet, spec, M.table_arrays(ps)), s0.time_birth_rate, s0.time_death_rate,
+                      s0.time_height, s0.heights, s0.rate_mean, s0.rate_variance, s0.rates, seed=13)
+    post0 = smp.posterior()
+    assert np.allclose(post0[:, 1], twin_ll(topo, s0, mu, P, logdet), rtol=1e-11)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :n_steps]
+    tol = 1e-8 + 1e-12 * np.abs(post0[:, :2]).max()
+    ta, tk = smp.run_schedule(sched, trace=True)
+    assert "sparse product" in smp.last_path()
+    ra, rk = twin.run(sched, trace=True)
+    fin = np.isfinite(ra)
+    assert np.array_equal(np.isfinite(ta), fin) and np.all(np.abs(ta[fin] - ra[fin]) <= tol + 1e-10 * np.abs(ra[fin]))
+    assert np.array_equal(tk, rk) and 0.02 < tk.mean() < 0.98
+    s = smp.state()
+    for a, b in ((s.time_height, twin.tH), (s.heights, twin.H), (s.rate_mean, twin.rMu), (s.rates, twin.R)):
+        assert np.allclose(a, b, rtol=1e-9, atol=0)
+    assert np.allclose(smp.posterior(), twin.post, rtol=1e-11, atol=tol)
+    with pytest.raises(M.McdError):                          # small trees take the dense handle
+        small = S.random_topology(20, seed=1)
+        Ps, assoc_s = banded_random_precision(small.n_nodes - 2, seed=1)
+        tls = M.SparseLikelihood(M.Sparse(np.full(small.n_nodes - 2, 0.1), assoc_s, 0.0)).bind_tree(small)
+        pss, _ = M.proposals(small, [], calibrations_available=True)
+        M.Sampler(tls, M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], small), pss, 4, seed=1)
+
+
+def twin_ll(topo, st, mu, P, logdet):
+    n = len(mu)
+    D = np.array([O.distances(topo.parent, st.heights[b], st.rates[b], st.time_height[b], st.rate_mean[b]) for b in range(st.heights.shape[0])])
+    dd = D - mu
+    return -n * 0.9189385332046727 - 0.5 * (logdet + np.einsum("bi,bi->b", dd, (P @ dd.T).T))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Lock-step Metropolis-Hastings on a synthetic large tree (two launches per step): microseconds per lock step.
-Usage: python tools/bench_mh_large.py [n_leaves=128] [chains=512] [steps=2000]"""
+Usage: python tools/bench_mh_large.py [n_leaves=128] [chains=512] [steps=2000] [dense|sparse]
+`sparse`: the precision matrix kept sparse on the device (mcd_mh_create_sparse; trees up to 2048 nodes)."""
 import json
 import os
 import sys
@@ -21,8 +22,14 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
     topo = S.random_topology(n_leaves, seed=3)
     n = topo.n_nodes - 2
-    mu, sigma = S.random_spd_problem(n, seed=3)
-    lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+    form = sys.argv[4] if len(sys.argv) > 4 else "dense"
+    if form == "sparse":
+        _, assoc = S.banded_precision(n, seed=3)
+        mu = np.random.default_rng(3).uniform(0.01, 0.2, n)
+        lik = M.SparseLikelihood(M.Sparse(mu, assoc, 0.0)).bind_tree(topo)
+    else:
+        mu, sigma = S.random_spd_problem(n, seed=3)
+        lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
     pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
     ps, _ = M.proposals(topo, [], calibrations_available=True)
     s0 = S.random_states(topo, B, seed=4)
@@ -37,7 +44,7 @@ def main():
     smp.run_schedule(sched)
     dt = time.perf_counter() - t0
     print(json.dumps({"metric": "MH lock step, large tree", "n_nodes": topo.n_nodes, "chains": B, "steps": steps,
-                      "us_per_lockstep": 1e6 * dt / steps, "steps_per_s": B * steps / dt, "proposals_per_iteration": int(sum(p.weight for p in ps))}))
+                      "form": form, "path": smp.last_path(), "us_per_lockstep": 1e6 * dt / steps, "steps_per_s": B * steps / dt, "proposals_per_iteration": int(sum(p.weight for p in ps))}))
 
 
 if __name__ == "__main__":
