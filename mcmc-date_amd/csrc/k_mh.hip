@@ -236,6 +236,10 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
     double* tb = Rs + n;                                   // [NIT][64] summands of the birth-death block
     double* tc = tb + NIT * 64;                            // [NIT][64] summands of the clock block
     double* bc = tc + NIT * 64;                            // [48] wave 0 -> all: proposed scalars, flags, the per-node transform; workers -> wave 0: c0, hyper
+#ifdef MCD_MHSTEP_STAMP
+    unsigned long long mhs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    MHS_T(0);
     // ---- the decision (every wave for itself: the same bits)
     bool ok = false;
     if (p_acc >= 0) {
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
             if (trace_accept) trace_accept[b] = ok ? 1 : 0;
         }
     }
+    MHS_T(1);
     // the current state after the decision, into LDS (and back to global memory when it changed)
     double sc[5];
 #pragma unroll
@@ -274,6 +279,25 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
                 M.age_sum[b * n + w] += a;
                 M.age_sq[b * n + w] += a * a;
             }
+        }
+    }
+    // The per-node summands of the birth-death and the clock block of the CURRENT state are kept between launches (psum: two
+    // buffers per block and chain, psel says which is current): a proposal that moves a few heights or rates re-evaluates those
+    // nodes' summands only -- the same function results as a full evaluation, added in the same order: the same bits.  A launch
+    // that evaluates a block writes it to the other buffer; accepting the proposal flips the block's bit.  The first launch of a
+    // run (no pending proposal) evaluates the current state's summands in full.
+    const bool cached = prior_inline && M.psum != nullptr;
+    const bool cache_init = p_acc < 0;
+    const int NS = NIT * 64;
+    int sel = 0;
+    if (cached && !cache_init) {
+        sel = M.psel[b];
+        if (ok) sel ^= (M.pflags[b] >> 1) & 3;             // the accepted proposal's blocks become the current ones
+        const double* s_bd = M.psum + ((size_t)b * 4 + (size_t)(sel & 1)) * NS;
+        const double* s_cl = M.psum + ((size_t)b * 4 + 2 + (size_t)((sel >> 1) & 1)) * NS;
+        for (int i = tid; i < NS; i += NT) {
+            tb[i] = s_bd[i];
+            tc[i] = s_cl[i];
         }
     }
     double pc[3];
@@ -308,9 +332,28 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
             for (int i = tid; i < I.NPz; i += NT) zc[i] = (i < I.nr) ? zt[(int64_t)i * 16] : 0.0;
         }
     }
+    if (cached && tid == 0) M.psel[b] = sel;
     if (p_prop < 0) return;
     __syncthreads();                                       // the current state is in LDS
+    MHS_T(2);
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
+    if (cached && cache_init) {                            // the summands of the current state, in full, into buffer 0 of both blocks
+        const bool near0 = prior_bd_near(sc[0], sc[1]);
+        prior_clock_scalars(sc[4], cc);
+        double* s_bd = M.psum + (size_t)b * 4 * NS;
+        double* s_cl = s_bd + 2 * (size_t)NS;
+        for (int it = wave; it < NIT; it += MHW) {
+            const int v = 1 + lane + 64 * it;
+            if (v < n) {
+                const double t1 = prior_bd_term(P, v, near0, sc[0], sc[1], Hc);
+                const double t2 = prior_clock_term(P, v, sc[4], cc.lg_k, cc.log_t, Hc, Rc);
+                tb[it * 64 + lane] = t1;
+                tc[it * 64 + lane] = t2;
+                s_bd[it * 64 + lane] = t1;
+                s_cl[it * 64 + lane] = t2;
+            }
+        }
+    }
     double lnqj = 0.0;
     PropApply* Ap = reinterpret_cast<PropApply*>(bc + 16);  // the per-node transform of the proposal, wave 0 -> all
     if (wave == 0) {
@@ -327,14 +370,16 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
 #pragma unroll
             for (int i = 0; i < 5; ++i) bc[i] = sc[i];
             // which blocks of the ln prior the proposed SCALARS move (the heights and rates are compared below)
-            bc[6] = (double)((sc[2] != sc0[2] ? 1 : 0) | ((sc[0] != sc0[0] || sc[1] != sc0[1]) ? 2 : 0) | ((sc[3] != sc0[3] || sc[4] != sc0[4]) ? 4 : 0));
+            bc[6] = (double)((sc[2] != sc0[2] ? 1 : 0) | ((sc[0] != sc0[0] || sc[1] != sc0[1]) ? 2 : 0) | ((sc[3] != sc0[3] || sc[4] != sc0[4]) ? 4 : 0) |
+                             (!(sc[4] == sc0[4]) ? 8 : 0));   // (bit 3: the rate variance itself -- every summand of the clock block)
             bc[9] = 0.0;
             bc[10] = 0.0;
         }
-    } else {
+    } else if (!(cc.va == sc[4])) {
         prior_clock_scalars(sc[4], cc);                    // while wave 0 proposes: most proposals leave the rate variance alone
     }
     __syncthreads();                                       // the transform is in LDS
+    MHS_T(3);
     {
         const PropApply A = *Ap;
         bool mH = false, mR = false;
@@ -353,6 +398,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
         }
     }
     __syncthreads();                                       // the proposed state is in LDS
+    MHS_T(4);
     // only the blocks of the ln prior whose inputs the proposal moved are evaluated again
     const bool dH = bc[9] != 0.0, dR = bc[10] != 0.0;
     const int scf = (int)bc[6];
@@ -390,6 +436,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
             }
             X1[b * ldx + j] = d;
         }
+        MHS_T(5);
         if (I.X0 != nullptr && I.prop_mode != 2) {
             // incremental likelihood (k_mh_inc.hip): this proposal moves a few distances, or none -- its ln likelihood here, from the
             // current z and columns of L^-1, instead of a likelihood launch
@@ -402,27 +449,44 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
             }
         }
     }
+    MHS_T(6);
+    if (!prior_inline || cached) {
+        if (tid == 0) M.pflags[b] = flags;
+    }
     if (!prior_inline) {                                   // the ln prior is evaluated beside the likelihood (mh_prior_role.hpp)
-        if (tid == 0) {
-            M.lnqj[b] = lnqj;
-            M.pflags[b] = flags;
-        }
+        if (tid == 0) M.lnqj[b] = lnqj;
         return;
     }
     {                                                      // every wave takes its share of the 64-node iterations (wave 0 as well:
         const int wi = wave;                               // it would only wait)
         if (flags & 2) {
+            // a summand depends on its node's and the parent's height, and on the two rates: every one when those moved -- or near
+            // the critical case, where a summand is composed along a path to a tip
             const bool near = prior_bd_near(scn[0], scn[1]);
+            const bool all = !cached || (scf & 2) || near;
             for (int it = wi; it < NIT; it += MHW) {
                 const int v = 1 + lane + 64 * it;
-                if (v < n) tb[it * 64 + lane] = prior_bd_term(P, v, near, scn[0], scn[1], Hs);
+                if (v < n) {
+                    const int pv = P.parent[v];
+                    if (all || Hs[v] != Hc[v] || Hs[pv] != Hc[pv]) tb[it * 64 + lane] = prior_bd_term(P, v, near, scn[0], scn[1], Hs);
+                }
             }
         }
         if (flags & 4) {
+            // uncorrelated models: a summand depends on its node's rate and on the rate variance; the others also on the branch's duration
+            const bool all = !cached || (scf & 8);
+            const bool durations = P.clock_model >= 2;
             if (!(cc.va == scn[4])) prior_clock_scalars(scn[4], cc);
             for (int it = wi; it < NIT; it += MHW) {
                 const int v = 1 + lane + 64 * it;
-                if (v < n) tc[it * 64 + lane] = prior_clock_term(P, v, scn[4], cc.lg_k, cc.log_t, Hs, Rs);
+                if (v < n) {
+                    bool again = all || Rs[v] != Rc[v];
+                    if (durations && !again) {
+                        const int pv = P.parent[v];
+                        again = Hs[v] != Hc[v] || Hs[pv] != Hc[pv];
+                    }
+                    if (again) tc[it * 64 + lane] = prior_clock_term(P, v, scn[4], cc.lg_k, cc.log_t, Hs, Rs);
+                }
             }
             if (wi == 1 && lane == 0) bc[8] = cc.hyper;
         }
@@ -432,6 +496,15 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
         }
     }
     __syncthreads();                                       // the summands are in LDS
+    MHS_T(7);
+    if (cached && (flags & 6)) {                           // the proposal's blocks, whole, to the buffers that are not the current ones
+        double* s_bd = M.psum + ((size_t)b * 4 + (size_t)((sel & 1) ^ 1)) * NS;
+        double* s_cl = M.psum + ((size_t)b * 4 + 2 + (size_t)(((sel >> 1) & 1) ^ 1)) * NS;
+        if ((flags & 2) && wave != 0)                       // (wave 0 closes the sums meanwhile)
+            for (int i = tid - 64; i < NS; i += NT - 64) s_bd[i] = tb[i];
+        if ((flags & 4) && wave != 0)
+            for (int i = tid - 64; i < NS; i += NT - 64) s_cl[i] = tc[i];
+    }
     if (wave != 0) return;
     const double c0p = (flags & 1) ? bc[7] : pc[0];
     double c1p = pc[1], c2p = pc[2];
@@ -454,6 +527,15 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
         M.lnqj[b] = lnqj;
         M.post1[b] = c0p + c1p + c2p;
     }
+#ifdef MCD_MHSTEP_STAMP
+    __builtin_amdgcn_s_waitcnt(0);
+    MHS_T(8);
+    if (b == 0 && tid == 0) {
+        const int k = row_prop.kind & 31;
+        for (int i = 0; i < 8; ++i) g_mhs_acc[k * 10 + i] += mhs[i + 1] - mhs[i];
+        g_mhs_cnt[k] += 1;
+    }
+#endif
 }
 
 // The state-independent draws (gamma multipliers with ratio and logarithm, the uniforms) of up to 64 consecutive steps: one

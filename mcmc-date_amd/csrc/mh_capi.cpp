@@ -62,7 +62,9 @@ struct mcd_mh {
     double* d_inc_ll = nullptr;     // [batch] ln likelihood output of the refreshing full products (not used)
     mcd::MhInc inc{};               // incremental likelihood of that path (k_mh_inc.hip): X0, zcur, zprop allocated on first use
     std::vector<mcd::MhRow> rows;   // host copy of the proposal table
-    std::vector<int32_t> sparse_rows;   // per row: 1 = moves at most kMhSparseSlots distances (MhDev::sparse)
+    double* d_psum = nullptr;           // k_mh_step_wg's kept summands of the ln prior (MhDev::psum, psel)
+    int32_t* d_psel = nullptr;
+    std::vector<int32_t> sparse_rows;   // per row: 1 = moves at most kMhIncSlots distances (the two-launch path's incremental evaluation)
     const double* d_Fp = nullptr;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
@@ -218,8 +220,13 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
     // a distance changes where a node's height, its parent's height or its rate changes -- for the node kinds below the node
     // itself with its daughters, or its sub tree.  The root's two daughters share distance slot 0.  This is a performance hint
     // only: the kernel finds the moved distances from the data and is right for any number of them.
-    std::vector<int32_t> sparse((size_t)n_prop, 0);
-    {
+    // (sparse_inc: the same for the two-launch path's incremental evaluation, k_mh_inc.hip, whose list of moved distances is not bounded
+    // by registers: up to kMhIncSlots columns of L^-1 still cost less than a likelihood launch.)
+    std::vector<int32_t> sparse((size_t)n_prop, 0), sparse_inc((size_t)n_prop, 0);
+    const char* env_slots = getenv("MCD_MH_INC_SLOTS");
+    const int inc_slots = env_slots ? std::max(1, std::min(1024, atoi(env_slots))) : mcd::kMhIncSlots;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int limit = pass ? inc_slots : mcd::kMhSparseSlots;
         std::vector<std::vector<int>> kids((size_t)n);
         for (int v = 1; v < n; ++v) kids[(size_t)parent[v]].push_back(v);
         auto slots_of = [&](const std::vector<int>& nodes) {
@@ -245,7 +252,7 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
                 case MCD_PROP_SCALE_SUBTREE_TIME:
                 case MCD_PROP_SCALE_SUBTREE_RATE:
                 case MCD_PROP_SCALE_SUBTREE_CONTRA:
-                    if (size[v] > 2 * mcd::kMhSparseSlots) { known = false; break; }
+                    if (size[v] > 2 * limit) { known = false; break; }
                     for (int w = v; w < v + size[v]; ++w) touched.push_back(w);
                     break;
                 case MCD_PROP_SLIDE_BRACE:
@@ -257,10 +264,10 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
                     break;
                 default: known = false; break;                         // scalars, whole-tree scalings, pulley, root slide
             }
-            sparse[(size_t)i] = (known && slots_of(touched) <= mcd::kMhSparseSlots) ? 1 : 0;
+            (pass ? sparse_inc : sparse)[(size_t)i] = (known && slots_of(touched) <= limit) ? 1 : 0;
         }
     }
-    m->sparse_rows = sparse;
+    m->sparse_rows = sparse_inc;
     m->device = dev_t;
     m->seed = seed;
     for (int i = 0; i < n_prop; ++i) m->rows.push_back(mcd::MhRow{kind[i], node[i], n1[i], n2[i], jac_root[i], p0[i], p1[i]});
@@ -596,6 +603,21 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         if (use_x && m->d_X1 == nullptr) {
             MHIP_TRY(hipMalloc((void**)&m->d_X1, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
             m->allocs.push_back(m->d_X1);
+        }
+        // the workgroup-per-chain step kernel keeps the per-node summands of the ln prior between launches (k_mh.hip: psum);
+        // MCD_MH_PRIOR_CACHE=0: every summand at every step
+        {
+            const char* env_cache = getenv("MCD_MH_PRIOR_CACHE");
+            const bool keep = prior_inline && mcd::mh_step_wg_active(D, prior_inline) && !(env_cache && env_cache[0] == '0');
+            if (keep && m->d_psum == nullptr) {
+                const size_t NS = (size_t)((D.n_nodes - 1 + 63) / 64) * 64;
+                MHIP_TRY(hipMalloc((void**)&m->d_psum, sizeof(double) * (size_t)D.batch * 4 * NS));
+                m->allocs.push_back(m->d_psum);
+                MHIP_TRY(hipMalloc((void**)&m->d_psel, sizeof(int32_t) * (size_t)D.batch));
+                m->allocs.push_back(m->d_psel);
+            }
+            D.psum = keep ? m->d_psum : nullptr;
+            D.psel = keep ? m->d_psel : nullptr;
         }
         m->last_path = use_x ? MCD_MH_PATH_STEP_WG_X : beside ? MCD_MH_PATH_TWO_LAUNCH_PRIOR_BESIDE : MCD_MH_PATH_TWO_LAUNCH;
         const mcd::TreeDev* Tx = use_x ? m->tree : nullptr;

@@ -96,8 +96,13 @@ struct MhDev {
     double* draws;
     int32_t* pflags;           // [batch] which blocks of the ln prior the pending proposal moved (bit 0 nodes, 1 birth-death, 2 clock)
     const int32_t* sparse;     // [n_prop] 1: the proposal moves at most kMhSparseSlots distances (k_mh_chain_big: z updated by columns of L^-1)
+    // k_mh_step_wg: the per-node summands of the birth-death and the clock block kept between launches, [batch][4][64 ceil((n_nodes - 1) / 64)]
+    // (birth-death buffers 0 / 1, clock buffers 0 / 1), and which buffer of each block is the current state's (bit 0, bit 1); null: not kept
+    double* psum;
+    int32_t* psel;
 };
 constexpr int kMhSparseSlots = 8;
+constexpr int kMhIncSlots = 16;       // the same bound for the two-launch path's incremental evaluation (k_mh_inc.hip; MCD_MH_INC_SLOTS)
 
 // The sparse form (k_sparse.hip): the precision matrix in CSR, any N up to kSparseMaxDim; all pointers are device memory.
 struct SparseDev {

@@ -44,7 +44,7 @@ def main():
     smp.run_schedule(sched)
     dt = time.perf_counter() - t0
     print(json.dumps({"metric": "MH lock step, large tree", "n_nodes": topo.n_nodes, "chains": B, "steps": steps,
-                      "form": form, "path": smp.last_path(), "us_per_lockstep": 1e6 * dt / steps, "steps_per_s": B * steps / dt, "proposals_per_iteration": int(sum(p.weight for p in ps))}))
+                      "us_per_lockstep": 1e6 * dt / steps, "steps_per_s": B * steps / dt, "proposals_per_iteration": int(sum(p.weight for p in ps)), "form": form, "path": smp.last_path()}))
 
 
 if __name__ == "__main__":
