@@ -613,7 +613,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 const size_t NS = (size_t)((D.n_nodes - 1 + 63) / 64) * 64;
                 MHIP_TRY(hipMalloc((void**)&m->d_psum, sizeof(double) * (size_t)D.batch * 4 * NS));
                 m->allocs.push_back(m->d_psum);
-                MHIP_TRY(hipMalloc((void**)&m->d_psel, sizeof(int32_t) * (size_t)D.batch));
+                MHIP_TRY(hipMalloc((void**)&m->d_psel, sizeof(int32_t) * 2 * (size_t)D.batch));
                 m->allocs.push_back(m->d_psel);
             }
             D.psum = keep ? m->d_psum : nullptr;
@@ -651,6 +651,67 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         }
         auto moves_likelihood = [&](int p) { return !(m->rows[p].kind == MCD_PROP_SCALE_SCALAR && (m->rows[p].node == 0 || m->rows[p].node == 1 || m->rows[p].node == 4)); };
         auto inc_mode = [&](int p) { return p < 0 ? 0 : !moves_likelihood(p) ? 0 : m->sparse_rows[(size_t)p] ? 1 : 2; };
+        // Trees of 515 .. 1026 nodes: the runs of steps between two dense proposals as ONE launch each, every chain's state in LDS from
+        // the run's first step to its last (k_mh_chain_big.hip, SEG); a dense proposal as before: proposed by the step kernel, its
+        // likelihood by the row-split launch, accepted by the step kernel.  MCD_MH_SEGMENTS=0: every step by the two launches.
+        const char* env_seg = getenv("MCD_MH_SEGMENTS");
+        const bool segments = inc && !(env_seg && env_seg[0] == '0') && mcd::mh_segment_available(D, *m->mvn) && I.NPz == 64 * m->mvn->R;
+        if (segments) {
+            bool summands_kept = false;                      // MhDev::psum holds the current states' summands
+            int64_t draws_block = 0;                         // (draws_for(0) above)
+            auto need_draws = [&](int64_t idx) -> int {
+                if ((idx >> 6) != draws_block) {
+                    draws_block = idx >> 6;
+                    return draws_for(idx & ~(int64_t)63);
+                }
+                return MCD_OK;
+            };
+            int64_t gs = 0;
+            while (gs < total) {
+                if (inc_mode(schedule[gs]) != 2) {
+                    int64_t e = gs + 1;                      // ... up to the next recomputation of z (every 256 steps)
+                    while (e < total && inc_mode(schedule[e]) != 2 && (e & 255) != 0) ++e;
+                    MHIP_TRY(mcd::launch_mh_segment(D, *m->mvn, *m->tree, *m->prior, I, m->d_sched + gs, e - gs, S, accumulate ? 1 : 0, step_base + (uint64_t)gs,
+                                                    m->seed, trace ? m->d_trace_alpha + gs * B : nullptr, trace ? m->d_trace_accept + gs * B : nullptr, gs,
+                                                    summands_kept ? 1 : 0, m->stream));
+                    if (D.psum != nullptr) summands_kept = true;
+                    if (accumulate) m->n_samples += (e / S) - (gs / S);          // iterations closed by steps gs .. e - 1
+                    m->step += (uint64_t)(e - gs);
+                    gs = e;
+                    if ((gs & 255) == 0 && gs < total)
+                        if (int rc = refresh_z()) return rc;
+                    continue;
+                }
+                // a dense proposal (and those that follow it directly)
+                if (int rc = need_draws(gs)) return rc;
+                I.mode = 0;
+                I.prop_mode = 2;
+                MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[gs], m->rows[schedule[gs]], (int)(gs & 63), m->step, m->seed, 0, nullptr,
+                                             nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, m->mvn, summands_kept ? 0 : 1));
+                if (D.psum != nullptr) summands_kept = true;
+                while (true) {
+                    const int pa = schedule[gs];
+                    MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, &I.zt, &I.nr, m->stream));
+                    I.mode = 2;
+                    const bool closes = ((gs + 1) % S) == 0;
+                    const bool refresh_now = ((gs + 1) & 255) == 0;
+                    const int pn = (gs + 1 < total && inc_mode(schedule[gs + 1]) == 2) ? schedule[gs + 1] : -1;
+                    if (pn >= 0)
+                        if (int rc = need_draws(gs + 1)) return rc;
+                    I.prop_mode = 2;
+                    MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, (int)((gs + 1) & 63), m->step,
+                                                 m->seed, (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
+                                                 trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, m->mvn, 0));
+                    if (refresh_now && gs + 1 < total)
+                        if (int rc = refresh_z()) return rc;
+                    m->step += 1;
+                    if (accumulate && closes) m->n_samples += 1;
+                    gs += 1;
+                    if (pn < 0) break;
+                }
+            }
+            m->last_path = MCD_MH_PATH_SEGMENTS;
+        } else {
         I.prop_mode = inc ? inc_mode(schedule[0]) : 0;
         MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr,
                                      prior_inline, Tx, n_dim, X1, n_dim, m->stream, inc ? &I : nullptr, m->mvn));
@@ -689,6 +750,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         }
         if (inc) m->last_path = MCD_MH_PATH_STEP_WG_INCREMENTAL;
         if (m->sp) m->last_path = MCD_MH_PATH_STEP_WG_SPARSE;
+        }
     }
     if (trace_alpha) MHIP_TRY(hipMemcpyAsync(trace_alpha, m->d_trace_alpha, sizeof(double) * steps * B, hipMemcpyDeviceToHost, m->stream));
     if (trace_accept) MHIP_TRY(hipMemcpyAsync(trace_accept, m->d_trace_accept, steps * B, hipMemcpyDeviceToHost, m->stream));

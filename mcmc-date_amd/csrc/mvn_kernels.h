@@ -97,7 +97,8 @@ struct MhDev {
     int32_t* pflags;           // [batch] which blocks of the ln prior the pending proposal moved (bit 0 nodes, 1 birth-death, 2 clock)
     const int32_t* sparse;     // [n_prop] 1: the proposal moves at most kMhSparseSlots distances (k_mh_chain_big: z updated by columns of L^-1)
     // k_mh_step_wg: the per-node summands of the birth-death and the clock block kept between launches, [batch][4][64 ceil((n_nodes - 1) / 64)]
-    // (birth-death buffers 0 / 1, clock buffers 0 / 1), and which buffer of each block is the current state's (bit 0, bit 1); null: not kept
+    // (birth-death buffers 0 / 1, clock buffers 0 / 1); psel [batch][2]: which buffer of each block is the current state's (bit 0, bit 1), and
+    // the blocks the pending proposal wrote (the bits of pflags); null: not kept
     double* psum;
     int32_t* psel;
 };
@@ -150,6 +151,11 @@ struct MhInc {
     int mode;            // of the PENDING proposal: 0 likelihood not moved, 1 sparse (zprop), 2 dense (zt)
     int prop_mode;       // of the proposal k_mh_step_wg is about to make: 0 / 1: it writes ll' itself (1: by columns of L^-1), 2: the row-split launch follows
 };
+// a run of consecutive steps without a dense proposal, every chain's state in LDS from the first to the last (k_mh_chain_big.hip, SEG)
+bool mh_segment_available(const MhDev& M, const MvnDev& V);
+hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
+                             int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
+                             int64_t gs_base, int cache_valid, hipStream_t st);
 hipError_t launch_mh_inc_init(const MhDev& M, const TreeDev& T, const MhInc& I, int n_dim, int64_t ldx, hipStream_t st);   // X0 from the current states
 hipError_t launch_mh_inc_take_z(const MhDev& M, const MhInc& I, hipStream_t st);                                          // zcur <- zt, all chains
 
@@ -256,7 +262,8 @@ struct MhRow {
 // accept the pending step of proposal p_acc (< 0: none) and propose proposal p_prop (< 0: none) with the ln prior of its proposed state
 hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_root_acc, int p_prop, const MhRow& row_prop, int draw_slot,
                           uint64_t step_acc, uint64_t seed, int accumulate_now, double* trace_alpha, int8_t* trace_accept, int prior_inline,
-                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st, const MhInc* inc = nullptr, const MvnDev* V = nullptr);
+                          const TreeDev* T, int n_dim, double* X1, int64_t ldx, hipStream_t st, const MhInc* inc = nullptr, const MvnDev* V = nullptr,
+                          int summands_init = -1);   // 1: MhDev::psum does not hold the current states' summands yet (-1: when nothing is pending)
 // true: launch_mh_step takes the workgroup-per-chain kernel, which can also leave the proposed states' distances in X1 [batch][ldx]
 // (T, n_dim, X1 given) for a plain-vector likelihood launch
 bool mh_step_wg_active(const MhDev& M, int prior_inline);

@@ -282,24 +282,28 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
     ps, _ = M.proposals(topo, [], calibrations_available=True)
     sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :1500]
     runs = []
-    for inc in ("1", "0"):
+    for inc, seg in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("MCD_MH_INCREMENTAL", inc)
+        monkeypatch.setenv("MCD_MH_SEGMENTS", seg)
         lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
         smp = M.Sampler(lik, M.PriorFunction(1.0, "UncorrelatedGamma", cal, [], [], topo), ps, B, seed=13)
         smp.set_state(s0)
         tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
         a, k = smp.run_schedule(sched[:, :700], accumulate=True, trace=True)
         a2, k2 = smp.run_schedule(sched[:, 700:], accumulate=True, trace=True)       # a second call starts from a fresh full product
-        assert ("only for proposals that move many distances" in smp.last_path()) == (inc == "1"), smp.last_path()
+        # 1025 nodes: the runs between two dense proposals in one launch each (k_mh_chain_big.hip, SEG) unless switched off
+        want = "segments" if (inc == "1" and seg == "1" and topo.n_nodes > 514) else "only for proposals that move many distances" if inc == "1" else "plain-vector likelihood"
+        assert want in smp.last_path(), smp.last_path()
         runs.append((np.concatenate([a, a2]), np.concatenate([k, k2]), smp.state(), smp.posterior(), smp.tuning(), smp.age_sums()[:2]))
-    (a1, k1, s1, p1, t1, g1), (a2, k2, s2, p2, t2, g2) = runs
-    assert np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
-    fin = np.isfinite(a2)
-    assert np.array_equal(np.isfinite(a1), fin) and alpha_close(a1[fin], a2[fin], tol), np.max(np.abs(a1[fin] - a2[fin]))
-    for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
-        assert np.array_equal(getattr(s1, f), getattr(s2, f)), f
-    assert np.array_equal(p1[:, [0, 2]], p2[:, [0, 2]]) and np.allclose(p1[:, 1], p2[:, 1], rtol=1e-12, atol=tol)
-    assert all(np.array_equal(x, y) for x, y in zip(t1, t2)) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
+    (a2, k2, s2, p2, t2, g2) = runs[-1]
+    for (a1, k1, s1, p1, t1, g1) in runs[:-1]:
+        assert np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
+        fin = np.isfinite(a2)
+        assert np.array_equal(np.isfinite(a1), fin) and alpha_close(a1[fin], a2[fin], tol), np.max(np.abs(a1[fin] - a2[fin]))
+        for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
+            assert np.array_equal(getattr(s1, f), getattr(s2, f)), f
+        assert np.array_equal(p1[:, [0, 2]], p2[:, [0, 2]]) and np.allclose(p1[:, 1], p2[:, 1], rtol=1e-12, atol=tol)
+        assert all(np.array_equal(x, y) for x, y in zip(t1, t2)) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
 def test_streaming_chain_kernel_over_many_steps_against_the_twin(gpu):

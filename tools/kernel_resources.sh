@@ -4,13 +4,13 @@
 cd "$(dirname "$0")/../mcmc-date_amd/csrc" || exit 1
 files=("$@"); [ ${#files[@]} -eq 0 ] && files=(k_*.hip)
 for f in "${files[@]}"; do
-  extra=$(make -s -f Makefile print-flags-"${f%.hip}" 2>/dev/null)
+  case "$f" in k_mh.hip|k_mh_chain.hip|k_mh_chain_big.hip) extra="-mllvm -disable-machine-licm";; *) extra="";; esac   # (the Makefile's NOLICM)
   for g in 0 1 2 3; do
     case "$f" in k_logpdf.hip|k_grad.hip|k_tree_logpdf.hip|k_tree_grad.hip) def="-DMCD_RGROUP=$g";; *) def=""; [ $g -gt 0 ] && continue;; esac
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off --cuda-device-only $def $extra -c "$f" -o /dev/null \
       -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|AGPRs:|VGPRs Spill|ScratchSize|LDS Size|Occupancy" \
       | sed 's/.*remark: *//; s/ *\[-Rpass.*//' | paste - - - - - - - | while IFS=$'\t' read -r name v a sc oc sp lds; do
-        printf "%-14s %s | %s | %s | %s | %s | %s | %s\n" "$f" "$(echo "${name#Function Name: }" | /opt/rocm/lib/llvm/bin/llvm-cxxfilt | sed 's/(.*//' | cut -c1-70)" "$v" "$a" "$sp" "$sc" "$lds" "$oc"
+        printf "%-14s %s | %s | %s | %s | %s | %s | %s\n" "$f" "$(echo "${name#Function Name: }" | c++filt | sed 's/(.*//' | cut -c1-70)" "$v" "$a" "$sp" "$sc" "$lds" "$oc"
       done
   done
 done

@@ -43,8 +43,9 @@ acc = np.zeros(320, dtype=np.uint64); cnt = np.zeros(32, dtype=np.uint64)
 L.mcd_mhstep_debug_stamps(acc.ctypes.data, cnt.ctypes.data)
 acc = (acc - acc0).astype(np.float64).reshape(32, 10); cnt = (cnt - cnt0).astype(np.float64)
 print("us per lock step %.2f  (n_nodes %d, chains %d)" % (1e6 * dt / steps, topo.n_nodes, B))
-print("shader cycles per phase: decision | state->LDS | propose | changed? | nodes | bd | clock | stores     total  count")
+print("k_mh_step (<= 320 nodes), shader cycles per phase: decision | state->LDS | propose | changed? | nodes | bd | clock | stores | -")
+print("k_mh_step_wg: first loads landed | decision | state loads landed | state in LDS | proposal's scalars | transform | distances, summands | columns | sums    total  count")
 for k in range(32):
     if cnt[k] > 0:
-        r = acc[k, :8] / cnt[k]
+        r = acc[k, :9] / cnt[k]
         print("kind %2d: " % k + " ".join("%7.1f" % v for v in r) + "   %7.1f  %d" % (r.sum(), cnt[k]))
