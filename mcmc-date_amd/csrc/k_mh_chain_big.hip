@@ -51,8 +51,6 @@ __device__ __forceinline__ bool mhb_moves_likelihood(int kind, int node)
 // accept / try counters ([n_prop] each: 22 KiB per chain at 385 nodes) stay in global memory -- a step reads one tuning parameter and
 // bumps two counters -- which is what lets trees of up to 514 nodes (N <= 512, R = 6 and 8) fit beside the 64-KiB ring.
 __host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int /*n_prop*/) { return 9 * (size_t)n_nodes + 1; }
-// ... of a segment (k_mh_chain_big<R, true>): 4 state rows and the current summands of the two blocks
-__host__ __device__ inline size_t mhb_segment_doubles(int n_nodes) { return 6 * (size_t)n_nodes; }
 // ... and per workgroup: the tree tables (five int32 arrays of n_nodes, rounded up to doubles)
 __host__ __device__ inline size_t mhb_table_doubles(int n_nodes) { return (5 * (size_t)n_nodes + 1) / 2 + 1; }
 
@@ -90,36 +88,14 @@ __device__ __forceinline__ void mhb_stream_pass(const double* __restrict__ Ft, d
 
 template <int R> struct MhbCols { static constexpr int N = (R <= 4) ? 4 : 2; };   // columns of L^-1 in flight per batch of moved distances
 
-// SEG (trees of 515 .. 1026 nodes, R = 12 and 16): a SEGMENT of a schedule whose dense proposals take the two-launch path
-// (k_mh.hip + the row-split likelihood, mh_capi.cpp): a run of consecutive steps none of which needs a sweep -- the factor is not
-// streamed, there is no ring and there are no loader waves, which is what lets two chains of 1025 nodes fit a CU's LDS: 6 n_nodes
-// doubles per chain (state rows and the CURRENT summands of the two blocks of the ln prior; a proposal's few summands are
-// written in place and the old values kept in registers until the decision).  The launch takes every chain's state, z, and kept
-// summands from where the two-launch path keeps them (MhDev, MhInc, MhDev::psum) and leaves them there.
-template <bool SEG> struct MhbSegArgs {                    // what only a segment takes (kernel arguments cost scalar registers: the
-    MhInc I;                                               // whole-schedule instantiations keep theirs)
-    int64_t gs_base;
-    int cache_valid;
-};
-template <> struct MhbSegArgs<false> {};
-
-template <int R, bool SEG = false>
+template <int R>
 __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, TreeDev T, PriorDev P, const int32_t* __restrict__ sched,
                                                       int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed,
-                                                      double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept,
-                                                      MhbSegArgs<SEG> seg)
+                                                      double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
 {
-    MhInc I{};
-    int64_t gs_base = 0;
-    int cache_valid = 0;
-    if constexpr (SEG) {
-        I = seg.I;
-        gs_base = seg.gs_base;
-        cache_valid = seg.cache_valid;
-    }
-    constexpr int CW = 2, LW = SEG ? 2 : Cfg<R>::LW;
-    static_assert(SEG || LW == 2, "geometry of k_tree_logpdf<R, 1, 2, 2>");
-    __shared__ d2 ring[SEG ? 1 : 2 * Cfg<R>::SU * 64];
+    constexpr int CW = 2, LW = Cfg<R>::LW;
+    static_assert(LW == 2, "geometry of k_tree_logpdf<R, 1, 2, 2>");
+    __shared__ d2 ring[2 * Cfg<R>::SU * 64];
     extern __shared__ double dyn[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,7 +105,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 
     // ---- loader waves: one pass over the factor per step that needs the likelihood
     if (wave >= CW) {
-        if constexpr (!SEG) {
         const int lw = wave - CW;
         int p = sched[0];
         int kind = M.kind[p], node = M.node[p];
@@ -146,7 +121,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             kind = kind_next;
             node = node_next;
             sp = sp_next;
-        }
         }
         return;
     }
@@ -178,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     Pl.first_child = tb_first;
     Pl.n_children = tb_nch;
     Pl.second_child = tb_second;
-    double* Hc = dyn + mhb_table_doubles(nn) + (size_t)wave * (SEG ? mhb_segment_doubles(nn) : mhb_chain_doubles(nn, NP));
+    double* Hc = dyn + mhb_table_doubles(nn) + (size_t)wave * mhb_chain_doubles(nn, NP);
     double* Rc = Hc + nn;
     double* Hp = Rc + nn;
     double* Rp = Hp + nn;
@@ -186,16 +160,14 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     int32_t* acc = M.acc + b * NP;
     int32_t* tried = M.tried + b * NP;
     double* tbd_cur = Rp + nn;                               // summand of node v in the birth-death block, current state
-    double* tbd_prop = SEG ? nullptr : tbd_cur + nn;         // ... proposed state, valid where stamp_bd[v] = this step
-    double* tcl_cur = SEG ? tbd_cur + nn : tbd_prop + nn;    // the same for the clock block
-    double* tcl_prop = SEG ? nullptr : tcl_cur + nn;
-    int32_t* stamp_bd = SEG ? nullptr : reinterpret_cast<int32_t*>(tcl_prop + nn);
-    int32_t* stamp_cl = SEG ? nullptr : stamp_bd + nn;
+    double* tbd_prop = tbd_cur + nn;                         // ... proposed state, valid where stamp_bd[v] = this step
+    double* tcl_cur = tbd_prop + nn;                         // the same for the clock block
+    double* tcl_prop = tcl_cur + nn;
+    int32_t* stamp_bd = reinterpret_cast<int32_t*>(tcl_prop + nn);
+    int32_t* stamp_cl = stamp_bd + nn;
     for (int w = lane; w < nn; w += 64) {
-        if constexpr (!SEG) {
-            stamp_bd[w] = 0;
-            stamp_cl[w] = 0;
-        }
+        stamp_bd[w] = 0;
+        stamp_cl[w] = 0;
         Hc[w] = M.H[b * M.ld + w];
         Rc[w] = M.R[b * M.ld + w];
         Hp[w] = Hc[w];                                       // invariant between steps: proposed arrays = current arrays
@@ -234,37 +206,18 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         }
         return prior_clock_finish(Pl, pr_wave_sum(cl), rm_, va_, c.hyper);
     };
+    double c1 = bd_full(sc[0], sc[1], Hc, tbd_cur);
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
-    double c1, c2;
-    const int seg_sel = (SEG && cache_valid && M.psum != nullptr) ? reinterpret_cast<const int2*>(M.psel)[b].x : 0;
-    const size_t seg_NS = (size_t)((nn - 1 + 63) / 64) * 64;
-    if (SEG && cache_valid && M.psum != nullptr) {
-        // the step kernel's kept summands of the current state (summand of node v at v - 1) and the blocks' values
-        const double* s_bd = M.psum + ((size_t)b * 4 + (size_t)(seg_sel & 1)) * seg_NS;
-        const double* s_cl = M.psum + ((size_t)b * 4 + 2 + (size_t)((seg_sel >> 1) & 1)) * seg_NS;
-        for (int v = 1 + lane; v < nn; v += 64) {
-            tbd_cur[v] = s_bd[v - 1];
-            tcl_cur[v] = s_cl[v - 1];
-        }
-        c0 = M.pcomp[b * 3 + 0];
-        c1 = M.pcomp[b * 3 + 1];
-        c2 = M.pcomp[b * 3 + 2];
-        prior_clock_scalars(sc[4], cc);
-    } else {
-        c1 = bd_full(sc[0], sc[1], Hc, tbd_cur);
-        c2 = clock_full(sc[3], sc[4], Hc, Rc, cc, tcl_cur);
-    }
+    double c2 = clock_full(sc[3], sc[4], Hc, Rc, cc, tcl_cur);
     double lp = c0 + c1 + c2;
     // rows 64 k + lane of the solve: mean, 1 / L_ii, the node whose branch feeds the distance slot and that node's parent
-    double mu_r[SEG ? 1 : R], iv_r[SEG ? 1 : R];
+    double mu_r[R], iv_r[R];
     int sl_a[R], sl_pa[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int row = 64 * k + lane;
-        if constexpr (!SEG) {
-            mu_r[k] = V.mu[row];
-            iv_r[k] = V.invdiag[row];
-        }
+        mu_r[k] = V.mu[row];
+        iv_r[k] = V.invdiag[row];
         sl_a[k] = T.slot_node[row];                          // -1 for padded rows
         sl_pa[k] = T.slot_parent[row];                       // 0 for padded rows
     }
@@ -289,9 +242,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     };
     // z = L^-1 (v - mu) by the forward sweep against the ring (the loaders stream alongside); returns |z|^2
     auto sweep = [&](const double (&v)[R], double (&z)[R]) -> double {
-        if constexpr (SEG) {
-            return 0.0;                                       // (no sweeps in a segment)
-        } else {
         double d[R][1];
 #pragma unroll
         for (int k = 0; k < R; ++k) d[k][0] = (v[k] - mu_r[k]) * iv_r[k];
@@ -304,14 +254,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             sq = fma(d[k][0], d[k][0], sq);
         }
         return wave_sum(sq);
-        }
     };
     const bool inc = V.Wc != nullptr;                        // incremental evaluation of sparse proposals available
     const int NPad = 64 * R;
     double dcur[R], zc[R];                                   // distances and z = L^-1 (d - mu) of the CURRENT state
     (void)distances(Hc, Rc, sc[2] * sc[3], dcur);
 #pragma unroll
-    for (int k = 0; k < R; ++k) zc[k] = SEG ? I.zcur[b * I.NPz + 64 * k + lane] : 0.0;       // (SEG: z of the current state, kept by the two-launch path)
+    for (int k = 0; k < R; ++k) zc[k] = 0.0;
     const double beta = M.beta[b];
 #ifdef MCD_MHB_STAMP
     // diagnostic build (make stamp_mhbig): s_memtime ticks per phase, summed over the run, in the first rows of trace_alpha
@@ -345,12 +294,12 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     };
     int p = sched[0];
     PropRow row = mh_load_row(M, p);
-    int row_sparse = SEG ? 1 : inc ? M.sparse[p] : 0;      // (a segment holds no dense proposal: mh_capi.cpp cuts the schedule there)
+    int row_sparse = inc ? M.sparse[p] : 0;
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
         const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
         const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
-        const int sparse_next = SEG ? 1 : inc ? M.sparse[p_next] : 0;
+        const int sparse_next = inc ? M.sparse[p_next] : 0;
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
             // parameter (as k_mh_chain.hip, and as k_mh_draws does for the two-launch path)
@@ -473,38 +422,19 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const bool need_bd = dH || bd_scalars;
         const bool few_bd = need_bd && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
         double c1p = c1;
-        double old_bd = 0.0, old_cl = 0.0;                   // SEG: the summands this lane overwrites, until the decision
         if (few_bd) {
             const int v = cand_bd(lane);
-            if constexpr (SEG) {
-                // in place (a node may come twice: every lane reads the old value before any lane writes -- LDS keeps a wave's order)
-                const bool mine = lane < cnt_bd && v >= 1;
-                if (mine) old_bd = tbd_cur[v];
-                const double t = mine ? prior_bd_term(Pl, v, false, sc1[0], sc1[1], Hp) : 0.0;
-                if (mine) tbd_cur[v] = t;
-            } else if (lane < cnt_bd && v >= 1) {
+            if (lane < cnt_bd && v >= 1) {
                 tbd_prop[v] = prior_bd_term(Pl, v, false, sc1[0], sc1[1], Hp);
                 stamp_bd[v] = st;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
             double bd = 0.0;
-            if constexpr (SEG) {
-                for (int w = 1 + lane; w < nn; w += 64) bd += tbd_cur[w];
-            } else {
-                for (int w = 1 + lane; w < nn; w += 64) bd += (stamp_bd[w] == st) ? tbd_prop[w] : tbd_cur[w];
-            }
+            for (int w = 1 + lane; w < nn; w += 64) bd += (stamp_bd[w] == st) ? tbd_prop[w] : tbd_cur[w];
             c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
         } else if (need_bd) {
-            if constexpr (SEG) {
-                // every summand (the rates moved, or many heights): the sum alone; the summands are evaluated again if the proposal is accepted
-                const bool near = prior_bd_near(sc1[0], sc1[1]);
-                double bd = 0.0;
-                for (int v = 1 + lane; v < nn; v += 64) bd += prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
-                c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
-            } else {
-                c1p = bd_full(sc1[0], sc1[1], Hp, tbd_prop);
-            }
+            c1p = bd_full(sc1[0], sc1[1], Hp, tbd_prop);
         }
         const bool cl_heights = dH && P.clock_model >= 2;    // white noise / autocorrelated: the summands also hold branch durations
         const bool need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
@@ -512,33 +442,17 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         double c2p = c2;
         if (few_cl) {
             const int v = cand_cl(lane);
-            if constexpr (SEG) {
-                const bool mine = lane < cnt_cl && v >= 1;
-                if (mine) old_cl = tcl_cur[v];
-                const double t = mine ? prior_clock_term(Pl, v, sc1[4], cc.lg_k, cc.log_t, Hp, Rp) : 0.0;
-                if (mine) tcl_cur[v] = t;
-            } else if (lane < cnt_cl && v >= 1) {
+            if (lane < cnt_cl && v >= 1) {
                 tcl_prop[v] = prior_clock_term(Pl, v, sc1[4], cc.lg_k, cc.log_t, Hp, Rp);
                 stamp_cl[v] = st;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
             double cl = 0.0;
-            if constexpr (SEG) {
-                for (int w = 1 + lane; w < nn; w += 64) cl += tcl_cur[w];
-            } else {
-                for (int w = 1 + lane; w < nn; w += 64) cl += (stamp_cl[w] == st) ? tcl_prop[w] : tcl_cur[w];
-            }
+            for (int w = 1 + lane; w < nn; w += 64) cl += (stamp_cl[w] == st) ? tcl_prop[w] : tcl_cur[w];
             c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
         } else if (need_cl) {
-            if constexpr (SEG) {
-                if (ccp.va != sc1[4]) prior_clock_scalars(sc1[4], ccp);
-                double cl = 0.0;
-                for (int v = 1 + lane; v < nn; v += 64) cl += prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
-                c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
-            } else {
-                c2p = clock_full(sc1[3], sc1[4], Hp, Rp, ccp, tcl_prop);
-            }
+            c2p = clock_full(sc1[3], sc1[4], Hp, Rp, ccp, tcl_prop);
         }
         const double lp1 = c0p + c1p + c2p;
         MHB_TICK(2)
@@ -547,8 +461,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         // The sweeps of this step, ONE call site (the sweep is a long unrolled body): first z of the CURRENT state when it is due
         // (start of the launch, then every 256 steps: the loaders stream for it under the same condition), then the step's own if its
         // proposal is dense.
-        const bool refresh_now = !SEG && inc && (gs & (kMhbRefresh - 1)) == 0;      // (segments: mh_capi.cpp refreshes between two of them)
-        const bool dense_step = !SEG && moves && !sparse_step;
+        const bool refresh_now = inc && (gs & (kMhbRefresh - 1)) == 0;
+        const bool dense_step = moves && !sparse_step;
         for (int pass = 0; pass < 2; ++pass) {
             const bool rf = pass == 0 && refresh_now;
             if (!rf && !(pass == 1 && dense_step)) continue;
@@ -599,15 +513,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             });
 #pragma unroll
             for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
-            if constexpr (SEG) {
-                // (few: already in place)  every summand: evaluated again, now to be kept -- the same function results as the sum's
-                if (!few_bd && need_bd) {
-                    const bool near = prior_bd_near(sc1[0], sc1[1]);
-                    for (int v = 1 + lane; v < nn; v += 64) tbd_cur[v] = prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
-                }
-                if (!few_cl && need_cl)
-                    for (int v = 1 + lane; v < nn; v += 64) tcl_cur[v] = prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
-            } else {
             if (few_bd) {
                 const int v = cand_bd(lane);
                 if (lane < cnt_bd && v >= 1) tbd_cur[v] = tbd_prop[v];
@@ -619,7 +524,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                 if (lane < cnt_cl && v >= 1) tcl_cur[v] = tcl_prop[v];
             } else if (need_cl) {
                 for (int w = 1 + lane; w < nn; w += 64) tcl_cur[w] = tcl_prop[w];
-            }
             }
             c0 = c0p;
             c1 = c1p;
@@ -641,16 +545,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                 Hp[w] = Hc[w];
                 Rp[w] = Rc[w];
             });
-            if constexpr (SEG) {                              // the overwritten summands back
-                if (few_bd) {
-                    const int v = cand_bd(lane);
-                    if (lane < cnt_bd && v >= 1) tbd_cur[v] = old_bd;
-                }
-                if (few_cl) {
-                    const int v = cand_cl(lane);
-                    if (lane < cnt_cl && v >= 1) tcl_cur[v] = old_cl;
-                }
-            }
         }
         if (lane == 0) {
             if (valid) {
@@ -661,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (accumulate && valid && (gs_base + gs + 1) % S == 0) {      // once per iteration of the cycle: straight into the running sums
+        if (accumulate && valid && (gs + 1) % S == 0) {      // once per iteration of the cycle: straight into the running sums
             for (int w = lane; w < nn; w += 64) {
                 const double a = sc[2] * Hc[w];
                 M.age_sum[b * nn + w] += a;
@@ -697,24 +591,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         M.pcomp[b * 3 + 1] = c1;
         M.pcomp[b * 3 + 2] = c2;
     }
-    if constexpr (SEG) {
-        // ... and what the two-launch path keeps beside the state: distances and z of the current state, the kept summands
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int row = 64 * k + lane;
-            if (row < V.n) I.X0[b * (int64_t)V.n + row] = dcur[k];
-            I.zcur[b * I.NPz + row] = zc[k];
-        }
-        if (M.psum != nullptr) {
-            double* s_bd = M.psum + ((size_t)b * 4 + (size_t)(seg_sel & 1)) * seg_NS;
-            double* s_cl = M.psum + ((size_t)b * 4 + 2 + (size_t)((seg_sel >> 1) & 1)) * seg_NS;
-            for (int v = 1 + lane; v < nn; v += 64) {
-                s_bd[v - 1] = tbd_cur[v];
-                s_cl[v - 1] = tcl_cur[v];
-            }
-            if (lane == 0) reinterpret_cast<int2*>(M.psel)[b] = make_int2(seg_sel, 0);
-        }
-    }
 }
 
 static size_t mhb_lds_bytes(int n_nodes, int n_prop)
@@ -744,49 +620,8 @@ static hipError_t launch_big_R(const MhDev& M, const MvnDev& V, const TreeDev& T
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_mh_chain_big<R>, dim3((unsigned)((M.batch + 1) / 2)), dim3(256), dynb, st, M, V, T, P, sched, n_steps, S, accumulate,
-                       step0, seed, trace_alpha, trace_accept, MhbSegArgs<false>{});
+                       step0, seed, trace_alpha, trace_accept);
     return hipGetLastError();
-}
-
-// ---- segments of the two-launch path's schedule on trees of 515 .. 1026 nodes (k_mh_chain_big<R, true>)
-static size_t mhb_segment_lds_bytes(int n_nodes) { return sizeof(double) * (mhb_table_doubles(n_nodes) + 2 * mhb_segment_doubles(n_nodes)); }
-
-bool mh_segment_available(const MhDev& M, const MvnDev& V)
-{
-    if ((V.R != 12 && V.R != 16) || V.Wc == nullptr || M.n_nodes > 64 * V.R + 2 || M.batch > 1024) return false;
-    return mhb_segment_lds_bytes(M.n_nodes) + 1024 <= 160 * 1024;
-}
-
-template <int R>
-static hipError_t launch_segment_R(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
-                                   int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha,
-                                   int8_t* trace_accept, int64_t gs_base, int cache_valid, hipStream_t st)
-{
-    const size_t dynb = mhb_segment_lds_bytes(M.n_nodes);
-    static std::atomic<unsigned long long> allowed{0};       // more than 64 KiB of LDS has to be allowed once per device
-    int dev = 0;
-    if (hipError_t e = hipGetDevice(&dev)) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!((allowed.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_chain_big<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)) return e;
-        allowed.fetch_or(1ull << dev, std::memory_order_release);
-    }
-    // two chain waves per workgroup and nothing else
-    hipLaunchKernelGGL((k_mh_chain_big<R, true>), dim3((unsigned)((M.batch + 1) / 2)), dim3(128), dynb, st, M, V, T, P, sched, n_steps, S, accumulate,
-                       step0, seed, trace_alpha, trace_accept, MhbSegArgs<true>{I, gs_base, cache_valid});
-    return hipGetLastError();
-}
-
-// steps [0, n_steps) of `sched` (device memory), none of which moves many distances; step0 = the step number of sched[0], gs_base its
-// position in the run's schedule (iterations close at multiples of S); cache_valid: MhDev::psum holds the current states' summands
-hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
-                             int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
-                             int64_t gs_base, int cache_valid, hipStream_t st)
-{
-    if (n_steps <= 0) return hipSuccess;
-    if (!mh_segment_available(M, V) || I.X0 == nullptr || I.zcur == nullptr || I.NPz != 64 * V.R) return hipErrorInvalidValue;
-    if (V.R == 12) return launch_segment_R<12>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, cache_valid, st);
-    return launch_segment_R<16>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, cache_valid, st);
 }
 
 hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const int32_t* sched, int64_t n_steps,

@@ -24,6 +24,14 @@ smp = M.Sampler(tl, pf, ps, B, seed=13)
 smp.set_state(s0)
 cyc = M.cycle_schedule(ps, 1, np.random.default_rng(0))
 sched = np.tile(cyc, (1, steps // cyc.shape[1] + 1))[:, :steps]
+if len(sys.argv) > 4:
+    # one SEGMENT of a large tree's schedule (k_mh_chain_big<R, true>): only proposals of the given kinds, at most 250 steps (one launch)
+    kinds = [int(k) for k in sys.argv[4].split(",")]
+    tab = M.table_arrays(ps)
+    keep = np.isin(tab["kind"][cyc[0]], kinds)
+    steps = min(steps, 250)
+    sched = cyc[:, keep][:, :steps]
+    steps = sched.shape[1]
 smp.run_schedule(sched[:, :200])
 t0 = time.perf_counter()
 ta, _ = smp.run_schedule(sched, trace=True)
