@@ -37,7 +37,7 @@
 
 namespace mcd {
 
-constexpr int kSegList = 256;      // moved distances of one proposal at most (mh_capi.cpp: proposals that may move more are dense)
+constexpr int kSegList = kMhSegList;   // moved distances of one proposal at most (mh_capi.cpp: proposals that may move more are dense)
 
 __device__ __forceinline__ bool seg_moves_likelihood(int kind, int node)
 {
@@ -80,11 +80,26 @@ __device__ __forceinline__ void seg_post(volatile int* w, int value)
     *w = value;
 }
 
+// Does the pending DENSE proposal of chain b (proposed by k_mh_step_wg, its ln likelihood by the row-split launch) become the
+// current state?  The decision of k_mh_step_wg's accept half, bit for bit; both waves of a chain take it for themselves.
+__device__ __forceinline__ bool seg_accept_pending(const MhDev& M, const MhSegPending& Q, int64_t b, uint64_t seed, double& la_out)
+{
+    const int64_t B = M.batch;
+    const double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
+    const double lp1 = M.post1[b], ll1 = M.post1[B + b], lj1 = M.post1[2 * B + b];
+    double la = M.beta[b] * ((lp1 + ll1) - (lp + ll)) + M.lnqj[b];
+    if (Q.jac_root) la += (double)Q.jac_root * (lj1 - lj);
+    double ua, ub;
+    philox_block(mh_rng(seed, M.chain0 + b, Q.step), 0xFFFFFFFFu, ua, ub);
+    la_out = la;
+    return (la >= 0) || (ua < exp(la));
+}
+
 template <int R>
 __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDev T, PriorDev P, MhInc I, const int32_t* __restrict__ sched,
                                                     int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed,
                                                     double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int64_t gs_base,
-                                                    int summands_kept)
+                                                    int summands_kept, MhSegPending Q)
 {
     extern __shared__ double dyn[];
     const int lane = threadIdx.x & 63;
@@ -153,8 +168,16 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     // ================================================================ likelihood waves
     if (wave >= 2) {
         double zc[R];                                        // z = L^-1 (d - mu) of the current state, rows 64 k + lane
+        double la_pending;
+        const bool took = Q.p_acc >= 0 && seg_accept_pending(M, Q, b, seed, la_pending);
+        if (took) {                                          // z' of the accepted dense proposal: the row-split kernel's tiles
+            const double* zt = I.zt + ((b >> 4) * I.nr) * 16 + (b & 15);
 #pragma unroll
-        for (int k = 0; k < R; ++k) zc[k] = I.zcur[b * I.NPz + 64 * k + lane];
+            for (int k = 0; k < R; ++k) zc[k] = (64 * k + lane < I.nr) ? zt[(int64_t)(64 * k + lane) * 16] : 0.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) zc[k] = I.zcur[b * I.NPz + 64 * k + lane];
+        }
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int tag = (int)gs + 1;
             (void)seg_poll(w_req, tag, 0);
@@ -167,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int m = (m0 + u < cnt) ? m0 + u : cnt - 1;   // (past the end: the last column again with weight 0: exact)
-                    const int j = l_j[m];
+                    const int j = __builtin_amdgcn_readfirstlane(l_j[m]);
                     dl[u] = (m0 + u < cnt) ? l_delta[m] : 0.0;
                     const double* wc = V.Wc + (size_t)j * NPad + lane;
 #pragma unroll
@@ -198,9 +221,22 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     }
 
     // ================================================================ chain waves
-    for (int j = lane; j < NPad; j += 64) {
-        mark[j] = 0;
-        dcur[j] = (j < V.n) ? I.X0[b * (int64_t)V.n + j] : 0.0;
+    // a pending dense proposal is decided here (instead of by a launch of k_mh_step_wg that would do nothing else): the chain then
+    // starts from the proposed state
+    double la_pending = 0.0;
+    const bool took = Q.p_acc >= 0 && seg_accept_pending(M, Q, b, seed, la_pending);
+    if (Q.p_acc >= 0 && lane == 0 && valid) {
+        atomicAdd(&M.tried[b * NPr + Q.p_acc], 1);
+        if (took) atomicAdd(&M.acc[b * NPr + Q.p_acc], 1);
+        if (Q.trace_alpha) Q.trace_alpha[b] = la_pending;
+        if (Q.trace_accept) Q.trace_accept[b] = took ? 1 : 0;
+    }
+    {
+        const double* xsrc = (took ? Q.X1 : I.X0) + b * (int64_t)V.n;
+        for (int j = lane; j < NPad; j += 64) {
+            mark[j] = 0;
+            dcur[j] = (j < V.n) ? xsrc[j] : 0.0;
+        }
     }
     MhDev Ml = M;
     Ml.parent = tb_parent;
@@ -213,8 +249,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     const double* tune = M.tune + b * NPr;                   // (constant during a launch: mcd_mh_tune is a call of its own)
     int32_t* acc = M.acc + b * NPr;
     int32_t* tried = M.tried + b * NPr;
+    const double* Hsrc = (took ? M.H1 : M.H) + b * M.ld;
+    const double* Rsrc = (took ? M.R1 : M.R) + b * M.ld;
     for (int w = lane; w < nn; w += 64) {
-        const double h = M.H[b * M.ld + w], r = M.R[b * M.ld + w];
+        const double h = Hsrc[w], r = Rsrc[w];
         Hc[w] = h;
         Rc[w] = r;
         Hp[w] = h;                                           // invariant between steps: proposed arrays = current arrays
@@ -222,8 +260,9 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     }
     double sc[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) sc[i] = M.sc[i * B + b];
-    double lp = M.post[b], ll = M.post[B + b], lj = M.post[2 * B + b];
+    for (int i = 0; i < 5; ++i) sc[i] = (took ? M.sc1 : M.sc)[i * B + b];
+    const double* psrc = took ? M.post1 : M.post;
+    double lp = psrc[b], ll = psrc[B + b], lj = psrc[2 * B + b];
     const double beta = M.beta[b];
     __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes have landed (one wave: in order)
     __builtin_amdgcn_wave_barrier();
@@ -232,7 +271,11 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
     double c0, c1, c2;
     const bool from_kept = summands_kept && M.psum != nullptr;
-    const int seg_sel = from_kept ? reinterpret_cast<const int2*>(M.psel)[b].x : 0;
+    int seg_sel = 0;
+    if (from_kept) {
+        const int2 sp = reinterpret_cast<const int2*>(M.psel)[b];
+        seg_sel = took ? (sp.x ^ ((sp.y >> 1) & 3)) : sp.x;  // (the accepted proposal's blocks are the current ones)
+    }
     const size_t NS = (size_t)((nn - 1 + 63) / 64) * 64;
     if (from_kept) {
         const double* s_bd = M.psum + ((size_t)b * 4 + (size_t)(seg_sel & 1)) * NS;
@@ -241,9 +284,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             tbd[v] = s_bd[v - 1];
             tcl[v] = s_cl[v - 1];
         }
-        c0 = M.pcomp[b * 3 + 0];
-        c1 = M.pcomp[b * 3 + 1];
-        c2 = M.pcomp[b * 3 + 2];
+        const double* pc = (took ? M.pcomp1 : M.pcomp) + b * 3;
+        c0 = pc[0];
+        c1 = pc[1];
+        c2 = pc[2];
         prior_clock_scalars(sc[4], cc);
     } else {
         c0 = prior_nodes_wave(Pl, lane, sc[2], Hc);
@@ -264,6 +308,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    if (Q.p_acc >= 0 && Q.accumulate && valid) {             // the pending step closed an iteration of the cycle
+        for (int w = lane; w < nn; w += 64) {
+            const double a = sc[2] * Hc[w];
+            M.age_sum[b * nn + w] += a;
+            M.age_sq[b * nn + w] += a * a;
+        }
+    }
     // The nodes a proposal writes (PropApply: up to three pre-order ranges, five single nodes, the braced nodes with their
     // daughters): f(w) for each of them, lanes in parallel (a node may come twice).  Between steps the proposed arrays equal the
     // current ones, so a step applies, commits or takes back its proposal on these nodes only.
@@ -281,6 +332,20 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         }
     };
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#ifdef MCD_SEG_STAMP
+    // diagnostic build (make stamp_seg): s_memtime ticks per phase of the chain wave, summed over the launch, in the first rows of
+    // trace_alpha: 0 loop head + draws, 1 propose, 2 list of moved distances, 3 ln prior, 4 waiting for |z'|^2, 5 decision + commit
+    uint64_t tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SEG_TICK(i)                                       \
+    {                                                     \
+        const uint64_t now_ = __builtin_readcyclecounter(); \
+        tk[i] += now_ - t_last;                           \
+        t_last = now_;                                    \
+    }
+    uint64_t t_last = __builtin_readcyclecounter();
+#else
+#define SEG_TICK(i)
+#endif
     int p = sched[0];
     PropRow row = mh_load_row(M, p);
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
@@ -303,6 +368,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         double sc1[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
+        SEG_TICK(0)
         PropApply A;
         const double lnqj = mh_propose_params(Ml, row, tune[p], dr, lane, sc1, Hc, Rc, A);
         for_write_set(A, [&](int w) {
@@ -313,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         });
         __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the writes above have landed before any lane reads them
         __builtin_amdgcn_wave_barrier();
+        SEG_TICK(1)
         // ---- the distances the written nodes feed: a written node's own slot, and its daughters' when its height is written.  Each
         // slot once (the first lane to exchange the slot's mark for this step's lists it), with its new distance and the delta.
         const bool moves = seg_moves_likelihood(row.kind, row.node);
@@ -322,7 +389,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             const double s1 = sc1[2] * sc1[3];
             double d0 = 0.0;                                 // the new distance of slot 0, in the lane that listed it
             bool have0 = false;
-            auto emit = [&](bool active, int node_) {        // (every lane calls it: the ballot is the wave's)
+            auto emit = [&](bool active, int node_) {        // (every lane calls it: the ballots are the wave's)
+                if (__builtin_amdgcn_ballot_w64(active) == 0) return;
                 const int slot = active ? (int)ts_of[node_] : -1;
                 bool mine = false;
                 if (slot >= 0) mine = atomicExch(&mark[slot], tag) != tag;
@@ -357,10 +425,17 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
             for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
             {
-                const int pth = (lane == 0) ? A.pt1 : (lane == 1) ? A.pt2 : -1;
-                const int ptr_ = (lane == 2) ? A.rp1 : (lane == 3) ? A.rp2 : (lane == 4) ? A.rp3 : -1;
-                emit_height(pth >= 0, pth >= 0 ? pth : 0);
-                emit(ptr_ >= 0, ptr_ >= 0 ? ptr_ : 0);
+                // the single nodes in ONE pass: lanes 0 .. 2 the first height-written node with its daughters, 3 .. 5 the second, 6 .. 8
+                // the three rate-written ones
+                const int g = lane / 3, r = lane - 3 * g;
+                int cand = -1;
+                if (lane < 6) {
+                    const int base = (g == 0) ? A.pt1 : A.pt2;
+                    if (base >= 0) cand = (r == 0) ? base : (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+                } else if (lane < 9) {
+                    cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
+                }
+                emit(cand >= 0, cand >= 0 ? cand : 0);
             }
             for (int i = A.brace_lo; i < A.brace_hi; ++i) {
                 const int x = M.brace_nodes[i];
@@ -372,6 +447,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         }
         if (lane == 0) *w_cnt = cnt > 0 ? cnt : 0;
         seg_post(w_req, tag);                                // (every lane stores the same word: the fence is the wave's)
+        SEG_TICK(2)
         // ---- ln prior: only the blocks whose inputs the proposal writes (a superset of "changed": a block re-evaluated on unchanged
         // inputs returns the same bits)
         const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
@@ -456,8 +532,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
         }
         const double lp1 = c0p + c1p + c2p;
+        SEG_TICK(3)
         // ---- the likelihood wave's answer
         (void)seg_poll(w_resp, tag, 0);
+        SEG_TICK(4)
         double ll1 = ll;
         if (moves) {
             const double q = *w_q;
@@ -498,8 +576,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             if (mine_cl) tcl[v_cl] = old_cl;
         }
         if (lane == 0 && valid) {
-            tried[p] += 1;                                   // (global memory; nothing waits for it)
-            if (ok) acc[p] += 1;
+            atomicAdd(&tried[p], 1);                         // (global memory, no value returned: nothing waits for it)
+            if (ok) atomicAdd(&acc[p], 1);
             if (trace_alpha) trace_alpha[gs * B + b] = la;
             if (trace_accept) trace_accept[gs * B + b] = ok ? 1 : 0;
         }
@@ -514,7 +592,12 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         }
         p = p_next;
         row = row_next;
+        SEG_TICK(5)
     }
+#ifdef MCD_SEG_STAMP
+    if (trace_alpha && lane == 0 && valid)
+        for (int i = 0; i < 8; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];
+#endif
     if (!valid) return;
     // ---- back to where the two-launch path keeps a chain
     for (int w = lane; w < nn; w += 64) {
@@ -556,7 +639,7 @@ bool mh_segment_available(const MhDev& M, const MvnDev& V)
 template <int R>
 static hipError_t launch_segment_R(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
                                    int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha,
-                                   int8_t* trace_accept, int64_t gs_base, int summands_kept, hipStream_t st)
+                                   int8_t* trace_accept, int64_t gs_base, int summands_kept, const MhSegPending& Q, hipStream_t st)
 {
     const size_t dynb = seg_lds_bytes(M.n_nodes, 64 * R);
     static std::atomic<unsigned long long> allowed{0};       // more than 64 KiB of LDS has to be allowed once per device
@@ -568,22 +651,26 @@ static hipError_t launch_segment_R(const MhDev& M, const MvnDev& V, const TreeDe
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_mh_segment<R>, dim3((unsigned)((M.batch + 1) / 2)), dim3(256), dynb, st, M, V, T, P, I, sched, n_steps, S, accumulate, step0,
-                       seed, trace_alpha, trace_accept, gs_base, summands_kept);
+                       seed, trace_alpha, trace_accept, gs_base, summands_kept, Q);
     return hipGetLastError();
 }
 
 // steps [0, n_steps) of `sched` (device memory), none of which moves more than kSegList distances; step0 = the step number of
 // sched[0], gs_base its position in the run's schedule (iterations close at multiples of S); summands_kept: MhDev::psum holds the
-// current states' summands
+// current states' summands; pending (may be null): a dense proposal whose likelihood has been evaluated and which is decided here
 hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
                              int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
-                             int64_t gs_base, int summands_kept, hipStream_t st)
+                             int64_t gs_base, int summands_kept, const MhSegPending* pending, hipStream_t st)
 {
-    if (n_steps <= 0) return hipSuccess;
+    MhSegPending Q{};
+    Q.p_acc = -1;
+    if (pending) Q = *pending;
+    if (n_steps <= 0) return Q.p_acc >= 0 ? hipErrorInvalidValue : hipSuccess;
+    if (Q.p_acc >= 0 && (Q.X1 == nullptr || I.zt == nullptr || !summands_kept)) return hipErrorInvalidValue;
     if (n_steps > (1 << 28)) return hipErrorInvalidValue;    // (the hand-over words count steps in 30 bits)
     if (!mh_segment_available(M, V) || I.X0 == nullptr || I.zcur == nullptr || I.NPz != 64 * V.R) return hipErrorInvalidValue;
-    if (V.R == 12) return launch_segment_R<12>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, st);
-    return launch_segment_R<16>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, st);
+    if (V.R == 12) return launch_segment_R<12>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
+    return launch_segment_R<16>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
 }
 
 }  // namespace mcd

@@ -224,7 +224,13 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
     // by registers: up to kMhIncSlots columns of L^-1 still cost less than a likelihood launch.)
     std::vector<int32_t> sparse((size_t)n_prop, 0), sparse_inc((size_t)n_prop, 0);
     const char* env_slots = getenv("MCD_MH_INC_SLOTS");
-    const int inc_slots = env_slots ? std::max(1, std::min(1024, atoi(env_slots))) : mcd::kMhIncSlots;
+    // (where the segment kernel runs the sparse proposals, k_mh_segment.hip, many more: a likelihood launch there also costs the whole
+    // state's way through memory twice; measured at 1025 nodes x 512 chains: 16 -> 22.5, 64 -> 14.2, 128 -> 12.7, 192 -> 12.5 us per lock step)
+    mcd::MhDev probe{};
+    probe.n_nodes = n;
+    probe.batch = batch;
+    const bool seg_capable = m->mvn != nullptr && mcd::mh_segment_available(probe, *m->mvn);
+    const int inc_slots = env_slots ? std::max(1, std::min(mcd::kMhSegList, atoi(env_slots))) : seg_capable ? mcd::kMhSegSlots : mcd::kMhIncSlots;
     for (int pass = 0; pass < 2; ++pass) {
         const int limit = pass ? inc_slots : mcd::kMhSparseSlots;
         std::vector<std::vector<int>> kids((size_t)n);
@@ -666,6 +672,10 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 }
                 return MCD_OK;
             };
+            // a dense proposal followed by a segment is decided by that segment's launch (k_mh_segment.hip: MhSegPending), not by a
+            // launch of the step kernel that would do nothing else
+            mcd::MhSegPending pending{};
+            bool have_pending = false;
             int64_t gs = 0;
             while (gs < total) {
                 if (inc_mode(schedule[gs]) != 2) {
@@ -673,7 +683,8 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                     while (e < total && inc_mode(schedule[e]) != 2 && (e & 255) != 0) ++e;
                     MHIP_TRY(mcd::launch_mh_segment(D, *m->mvn, *m->tree, *m->prior, I, m->d_sched + gs, e - gs, S, accumulate ? 1 : 0, step_base + (uint64_t)gs,
                                                     m->seed, trace ? m->d_trace_alpha + gs * B : nullptr, trace ? m->d_trace_accept + gs * B : nullptr, gs,
-                                                    summands_kept ? 1 : 0, m->stream));
+                                                    summands_kept ? 1 : 0, have_pending ? &pending : nullptr, m->stream));
+                    have_pending = false;
                     if (D.psum != nullptr) summands_kept = true;
                     if (accumulate) m->n_samples += (e / S) - (gs / S);          // iterations closed by steps gs .. e - 1
                     m->step += (uint64_t)(e - gs);
@@ -698,6 +709,20 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                     const int pn = (gs + 1 < total && inc_mode(schedule[gs + 1]) == 2) ? schedule[gs + 1] : -1;
                     if (pn >= 0)
                         if (int rc = need_draws(gs + 1)) return rc;
+                    if (pn < 0 && gs + 1 < total && !refresh_now && D.psum != nullptr && summands_kept) {
+                        pending.p_acc = pa;
+                        pending.jac_root = m->rows[pa].jac_root;
+                        pending.accumulate = (accumulate && closes) ? 1 : 0;
+                        pending.step = m->step;
+                        pending.trace_alpha = trace ? m->d_trace_alpha + gs * B : nullptr;
+                        pending.trace_accept = trace ? m->d_trace_accept + gs * B : nullptr;
+                        pending.X1 = X1;
+                        have_pending = true;
+                        m->step += 1;
+                        if (accumulate && closes) m->n_samples += 1;
+                        gs += 1;
+                        break;
+                    }
                     I.prop_mode = 2;
                     MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, (int)((gs + 1) & 63), m->step,
                                                  m->seed, (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,

@@ -103,7 +103,9 @@ struct MhDev {
     int32_t* psel;
 };
 constexpr int kMhSparseSlots = 8;
-constexpr int kMhIncSlots = 16;       // the same bound for the two-launch path's incremental evaluation (k_mh_inc.hip; MCD_MH_INC_SLOTS)
+constexpr int kMhIncSlots = 32;       // the same bound for the two-launch path's incremental evaluation (k_mh_inc.hip; MCD_MH_INC_SLOTS)
+constexpr int kMhSegSlots = 192;      // ... where the segment kernel runs the sparse proposals (k_mh_segment.hip)
+constexpr int kMhSegList = 256;       // ... and what its list of moved distances holds: no proposal of a segment may move more
 
 // The sparse form (k_sparse.hip): the precision matrix in CSR, any N up to kSparseMaxDim; all pointers are device memory.
 struct SparseDev {
@@ -151,11 +153,20 @@ struct MhInc {
     int mode;            // of the PENDING proposal: 0 likelihood not moved, 1 sparse (zprop), 2 dense (zt)
     int prop_mode;       // of the proposal k_mh_step_wg is about to make: 0 / 1: it writes ll' itself (1: by columns of L^-1), 2: the row-split launch follows
 };
-// a run of consecutive steps without a dense proposal, every chain's state in LDS from the first to the last (k_mh_chain_big.hip, SEG)
+// a run of consecutive steps without a dense proposal, every chain's state in LDS from the first to the last (k_mh_segment.hip)
+struct MhSegPending {          // a dense proposal that is still to be decided when the segment starts (k_mh_step_wg proposed it into H1 / R1 /
+    int p_acc;                 // sc1 / X1 / post1 / pcomp1 / lnqj, the row-split launch left its ln likelihood and its z tiles): -1 = none
+    int jac_root;
+    int accumulate;            // that step closes an iteration: the node ages go into the running sums
+    uint64_t step;             // its step number (the acceptance uniform's stream)
+    double* trace_alpha;       // [batch] or null
+    int8_t* trace_accept;
+    const double* X1;          // [batch][n] its distances
+};
 bool mh_segment_available(const MhDev& M, const MvnDev& V);
 hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
                              int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
-                             int64_t gs_base, int cache_valid, hipStream_t st);
+                             int64_t gs_base, int summands_kept, const MhSegPending* pending, hipStream_t st);
 hipError_t launch_mh_inc_init(const MhDev& M, const TreeDev& T, const MhInc& I, int n_dim, int64_t ldx, hipStream_t st);   // X0 from the current states
 hipError_t launch_mh_inc_take_z(const MhDev& M, const MhInc& I, hipStream_t st);                                          // zcur <- zt, all chains
 

@@ -263,13 +263,14 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
         assert all(np.allclose(x, y, rtol=1e-13, atol=0) for x, y in zip(g1, g2))      # (sums formed per run, then added: not bitwise)
 
 
-@pytest.mark.parametrize("n_leaves,B", [(200, 40), (513, 64)])
+@pytest.mark.parametrize("n_leaves,B", [(200, 40), (513, 64), (513, 5), (300, 33)])
 def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
-    """Trees of more than 320 nodes at a sampler's batch (399 and 1025 nodes here): the workgroup-per-chain step kernel with the
-    likelihood launch only for the proposals that move many distances (k_mh_inc.hip; the others: columns of L^-1 on a z kept in
-    global memory, refreshed by a full product every 256 steps) against the same path with the full evaluation at every step
-    (MCD_MH_INCREMENTAL=0): 1 500 lock steps, identical accept / reject decisions, states, ln priors and ln Jacobians bit for
-    bit, ln acceptance ratios and ln likelihoods within the twin's tolerance."""
+    """Trees of more than 320 nodes at a sampler's batch (399, 599 and 1025 nodes here; an odd batch leaves a workgroup of the segment
+    kernel with one chain): the workgroup-per-chain step kernel with the likelihood launch only for the proposals that move many
+    distances (k_mh_inc.hip; the others: columns of L^-1 on a z kept in global memory, refreshed by a full product every 256 steps)
+    and, from 515 nodes, the runs between two dense proposals in one launch each (k_mh_segment.hip), against the same path with the
+    full evaluation at every step (MCD_MH_INCREMENTAL=0): 1 500 lock steps, identical accept / reject decisions, states, ln priors
+    and ln Jacobians bit for bit, ln acceptance ratios and ln likelihoods within the twin's tolerance."""
     from mcmc_date_amd import synthetic as S
 
     monkeypatch.setenv("MCD_MH_PER_PHASE", "1")              # (399 nodes would otherwise take the streaming chain kernel)

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r03
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-MCD_MH_INC_SLOTS=${SLOTS:-96} rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/r03/prof_seg" -- python3 "$ROOT/tools/bench_mh_large.py" 513 512 3000 > "$ROOT/gpurun_out/r03/prof_seg.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/r03/prof_seg" -- python3 "$ROOT/tools/bench_mh_large.py" 513 512 3000 > "$ROOT/gpurun_out/r03/prof_seg.log" 2>&1
 cd "$ROOT"
 f=$(find gpurun_out/r03/prof_seg -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/r03/r_seg_kernel_stats.csv
