@@ -236,7 +236,7 @@ def sparse_measure(dev_index, n, B, steps, warm, band=3, extra=4):
     from mcmc_date_amd import synthetic as S
 
     rng = np.random.default_rng(n)
-    _, assoc = S.banded_precision(n, n, band, extra)
+    P, assoc = S.banded_precision(n, n, band, extra)
     mu = rng.uniform(0.01, 0.2, n)
     sp = M.SparseLikelihood(M.Sparse(mu, assoc, 0.0), device=dev_index)
     dev = torch.device("cuda", dev_index)
@@ -336,6 +336,15 @@ def main():
             elapsed = float(t.item())
         if rank == 0:
             nd = r["dimension"]
+            mh_traffic, mh_traffic_source = None, None
+            try:                                             # measured once per round by tools/collect_profiles_r03.sh
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+                key = {(257, 512): "mh_257x512", (1025, 512): "mh_1025x512_segments"}.get((r["n_nodes"], B))
+                if key and key in tr:
+                    mh_traffic = tr[key]["fetch_bytes_per_lock_step_corrected"] + tr[key].get("write_bytes_per_lock_step", 0.0)
+                    mh_traffic_source = f"profiles/r03_pmc_traffic.json[{key}]"
+            except (OSError, ValueError, KeyError):
+                pass
             alg_b = (8.0 * (2 * r["n_nodes"] + 2) + 8.0 + (8.0 * nd + 4.0 * nd * (nd + 1)) / B) * B   # SURVEY.md 8(d), tree-state kernel
             print(json.dumps({
                 "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes",
@@ -350,8 +359,10 @@ def main():
                                            f"chains sharded x{world}; MC3 swap phase every {r['mc3']['period_lock_steps']} lock steps: one all-gather of "
                                            f"{r['mc3']['bytes_gathered_per_phase']} bytes + swaps of temperatures")},
                 "roofline": {"bound": "hbm", "achieved": alg_b / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": alg_b / (elapsed / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "note": "algorithmic bytes of the likelihood launch only; the step also runs the proposal + prior launch"},
+                             "frac": alg_b / (elapsed / K) / 1e9 / HBM_PEAK_GBS, "traffic": mh_traffic, "traffic_source": mh_traffic_source,
+                             "note": "achieved: SURVEY.md 8(d)'s bytes of ONE FULL likelihood evaluation of the batch per lock step; most proposals are "
+                                     "evaluated incrementally (columns of L^-1 on a kept z) and move less -- traffic: memory-side bytes per lock step of "
+                                     "the whole run, every kernel (PMC, profiles/)"},
                 "mh": r}))
         if world > 1:
             dist.destroy_process_group()

@@ -28,6 +28,7 @@ module McmcDate.Gpu
     c_prior_create,
     c_prior_logprior_batch,
     c_mh_create,
+    c_mh_create_sparse,
     c_mh_set_state,
     c_mh_run,
     c_mh_tune,
@@ -283,6 +284,13 @@ foreign import ccall unsafe "mcd_mh_get_state"
 
 foreign import ccall unsafe "mcd_mh_get_age_sums"
   c_mh_get_age_sums :: Ptr McdMh -> Ptr CDouble -> Ptr CDouble -> Ptr Int64 -> IO CInt
+
+-- | The lock-step driver over a likelihood whose precision matrix stays sparse on the device (@likelihoodFunction (Sparse ...)@,
+-- app/Probability.hs:279; trees of 321 .. 2048 nodes): same arguments as 'c_mh_create' with the sparse tree handle.
+foreign import ccall unsafe "mcd_mh_create_sparse"
+  c_mh_create_sparse ::
+    Ptr (Ptr McdMh) -> Ptr McdSparseTree -> Ptr McdPrior -> CInt -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 ->
+    Ptr Int32 -> Ptr CDouble -> Ptr CDouble -> Int64 -> Word64 -> IO CInt
 
 -- | Which launch structure the last 'c_mh_run' took (MCD_MH_PATH_*), for logs.
 foreign import ccall unsafe "mcd_mh_last_path"

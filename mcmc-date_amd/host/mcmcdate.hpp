@@ -206,6 +206,9 @@ public:
         return ll;
     }
 
+    const Topology& topology() const { return topo_; }
+    const mcd_sparse_tree_t* treeHandle() const { return tree_.get(); }
+
 private:
     Topology topo_;
     std::shared_ptr<mcd_sparse_t> sp_;
@@ -415,6 +418,24 @@ public:
         mcd_mh_t* m = nullptr;
         detail::check(mcd_mh_create(&m, lik.treeHandle(), prior.handle(), (int)table_.size(), kind.data(), node.data(), n1.data(), n2.data(),
                                     jac.data(), dim.data(), p0.data(), p1.data(), batch, seed));
+        mh_.reset(m);
+        stepsPerIteration_ = 0;
+        for (auto& p : table_) stepsPerIteration_ += p.weight;
+    }
+    // the same sampler over a likelihood whose precision matrix stays sparse on the device (likelihoodFunction (Sparse ...),
+    // app/Probability.hs:279): trees of 321 .. 2048 nodes (mcd_mh_create_sparse)
+    Sampler(const SparseLikelihood& lik, const PriorFunction& prior, std::vector<Proposal> table, int64_t batch, uint64_t seed)
+        : topo_(lik.topology()), table_(std::move(table)), batch_(batch)
+    {
+        std::vector<int32_t> kind, node, n1, n2, jac, dim;
+        Vec p0, p1;
+        for (auto& p : table_) {
+            kind.push_back(p.kind); node.push_back(p.node); n1.push_back(p.n1); n2.push_back(p.n2); jac.push_back(p.jacRoot); dim.push_back(p.dim);
+            p0.push_back(p.p0); p1.push_back(p.p1);
+        }
+        mcd_mh_t* m = nullptr;
+        detail::check(mcd_mh_create_sparse(&m, lik.treeHandle(), prior.handle(), (int)table_.size(), kind.data(), node.data(), n1.data(), n2.data(),
+                                           jac.data(), dim.data(), p0.data(), p1.data(), batch, seed));
         mh_.reset(m);
         stepsPerIteration_ = 0;
         for (auto& p : table_) stepsPerIteration_ += p.weight;

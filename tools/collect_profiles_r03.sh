@@ -26,6 +26,11 @@ MCD_MH_INCREMENTAL=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format c
 echo "mh done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5_trace -- python3 $ROOT/bench.py --kind mh --dim 1024 --chains 512 --swap-period 2 --swap-steps 500 --steps 2000 --warmup 200 > $OUT/cfg5_bench_trace.json 2> $OUT/cfg5_trace.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sparse_trace -- python3 $ROOT/bench.py --kind sparse --dim 2011 --chains 512 --steps 300 --warmup 30 > $OUT/sparse_bench_trace.json 2> $OUT/sparse_trace.log
+CFG5="python3 $ROOT/bench.py --kind mh --dim 1024 --chains 512 --steps 4000 --warmup 400"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cfg5_pmc_fetch -- $CFG5 > /dev/null 2> $OUT/cfg5_pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cfg5_pmc_write -- $CFG5 > /dev/null 2> $OUT/cfg5_pmc_write.log
+MCD_MH_SEGMENTS=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cfg5ns_pmc_fetch -- $CFG5 > /dev/null 2> $OUT/cfg5ns_pmc_fetch.log
+MCD_MH_SEGMENTS=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cfg5ns_pmc_write -- $CFG5 > /dev/null 2> $OUT/cfg5ns_pmc_write.log
 echo "traces done"
 cd $ROOT
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log
@@ -88,6 +93,12 @@ for tag, key in (("mh", "mh_257x512"), ("mh0", "mh_257x512_full_sweeps")):
         traffic[key] = {"FETCH_SIZE_kib_of_the_timed_launch": max(fe), "lock_steps": steps, "fetch_bytes_per_lock_step_corrected": 2 * big / steps}
 wr = counter("mh_pmc_write", "WRITE_SIZE", "k_mh_chain_big")
 if wr: traffic["mh_257x512"]["write_bytes_per_lock_step"] = max(wr) * 1024 / steps
+# config 5's share of one GPU (1025 nodes x 512 chains): every kernel of the run, per lock step -- with the segment kernel and with two launches per step
+for tag, key in (("cfg5", "mh_1025x512_segments"), ("cfg5ns", "mh_1025x512_two_launches_per_step")):
+    fe, wr = counter(tag + "_pmc_fetch", "FETCH_SIZE", "mcd::k_"), counter(tag + "_pmc_write", "WRITE_SIZE", "mcd::k_")
+    if fe and wr:
+        n = 4400
+        traffic[key] = {"lock_steps_incl_warmup": n, "fetch_bytes_per_lock_step_corrected": 2 * sum(fe) * 1024 / n, "write_bytes_per_lock_step": sum(wr) * 1024 / n}
 traffic["note"] = ("rocprofv3 --pmc, separate passes per counter; KiB per dispatch; corrected = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: gfx950 tallies 128-B "
                    "requests at 64 B).  mh_*: the whole schedule is ONE k_mh_chain_big launch; per lock step = counter of the timed launch / its lock steps")
 json.dump(traffic, open(os.path.join(out, "r03_pmc_traffic.json"), "w"), indent=1)

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r03
 for rep in 1 2; do
 for lib in A B; do
   if [ $lib = A ]; then export MCD_LIB_PATH=$(pwd)/tools/microbench/libtri.so; else unset MCD_LIB_PATH; fi
-  for nl in 513 129 257 400; do
+  for nl in 129 136 257; do
     echo -n "$lib $nl "; python tools/bench_mh_large.py $nl 512 3000 | python -c "import sys,json; print('%.2f' % json.loads(sys.stdin.read())['us_per_lockstep'])"
   done
 done
