@@ -335,7 +335,7 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  * accumulate != 0: after every iteration add the absolute node ages tH * h_v to the running sums.
  * trace_alpha / trace_accept (host, may be NULL): [n_iter * steps_per_iter][batch] ln acceptance ratio / decision.
  * Trees of at most 64 nodes: the whole schedule in one launch, the factor of Sigma in LDS; up to 514 nodes (N <= 512) and 1024 chains: the
- * same with the factor streamed through LDS once per step.  Trees of 515 .. 1026 nodes (up to 1024 chains): every run of steps between
+ * same with the factor streamed through LDS once per step (default up to 258 nodes).  Trees of 259 .. 1026 nodes (up to 1024 chains): every run of steps between
  * two proposals that move more than 192 branch distances in one launch, the chains' states in LDS (k_mh_segment.hip); such a dense
  * proposal by two launches.  Larger batches, and trees over a sparse likelihood: two launches per step -- accept the pending
  * proposal and propose the next one; then ln likelihood of the proposed states, which up to 256 dimensions also carries their ln
@@ -358,7 +358,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t ste
 #define MCD_MH_PATH_STEP_WG_X 5               /* workgroup-per-chain step leaving distances + plain-vector likelihood launch */
 #define MCD_MH_PATH_STEP_WG_INCREMENTAL 6     /* the same, the likelihood launch only for proposals that move many distances (k_mh_inc.hip) */
 #define MCD_MH_PATH_STEP_WG_SPARSE 7          /* workgroup-per-chain step leaving distances + the sparse product on them (mcd_mh_create_sparse) */
-#define MCD_MH_PATH_SEGMENTS 8                /* 515 .. 1026 nodes: every run of steps between two dense proposals in one launch (state in LDS), a dense proposal by path 6's launches */
+#define MCD_MH_PATH_SEGMENTS 8                /* 259 .. 1026 nodes: every run of steps between two dense proposals in one launch (state in LDS), a dense proposal by path 6's launches */
 int mcd_mh_last_path(const mcd_mh_t* m);
 /* Auto tuning at the end of a tuning period [mcmc]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3). */
 int mcd_mh_tune(mcd_mh_t* m);

@@ -725,10 +725,10 @@ static size_t mh_step_wg_lds(int n_nodes)
     const size_t NS = (size_t)((n_nodes - 1 + 63) / 64) * 64;
     return sizeof(double) * (4 * (size_t)n_nodes + 2 * NS + 48) + sizeof(int) * 3 * (size_t)n_nodes;
 }
-bool mh_step_wg_active(const MhDev& M, int prior_inline)
+bool mh_step_wg_active(const MhDev& M, int prior_inline, int min_nodes)
 {
     const char* env = getenv("MCD_MH_STEP_WG");
-    const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > 320);
+    const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > min_nodes);
     return wg && M.n_nodes <= 2048 && mh_step_wg_lds(M.n_nodes) + sizeof(IncShared) <= 144 * 1024;   // (above 64 KiB: allowed at launch)
 }
 
@@ -738,7 +738,7 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
 {
     if (summands_init < 0) summands_init = p_acc < 0 ? 1 : 0;
     const PropRow row_{r.kind, r.node, r.n1, r.n2, r.jac_root, r.p0, r.p1};
-    if (mh_step_wg_active(M, prior_inline)) {
+    if (mh_step_wg_active(M, prior_inline, X1 != nullptr ? 0 : 320)) {      // (a caller that wants the distances has asked mh_step_wg_active itself)
         const bool dist = T != nullptr && X1 != nullptr;
         const TreeDev Tv = dist ? *T : TreeDev{};
         double* Xv = dist ? X1 : (double*)nullptr;

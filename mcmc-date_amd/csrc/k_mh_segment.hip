@@ -1,8 +1,9 @@
-// k_mh_segment.hip -- Metropolis-Hastings-Green on trees of 515 .. 1026 nodes at a sampler's batch (gfx950): a SEGMENT of a schedule
+// k_mh_segment.hip -- Metropolis-Hastings-Green on trees of 259 .. 1026 nodes at a sampler's batch (gfx950): a SEGMENT of a schedule
 // in one launch.  SURVEY.md 8(f) row f2.
 //
-// On these trees the factor of Sigma (4.2 MB at N = 1023) cannot be streamed per chain and step as k_mh_chain_big.hip does for
-// smaller ones: a proposal that moves many branch distances takes the two-launch path (k_mh.hip proposes, the row-split kernel
+// On the larger of these trees the factor of Sigma (4.2 MB at N = 1023) cannot be streamed per chain and step as k_mh_chain_big.hip
+// does up to 514 nodes (and from 259 nodes that stream, 1 MB per workgroup and dense step at 513 nodes, costs more than it saves:
+// 513 nodes x 512 chains 16.0 us per lock step there, 9.6 here): a proposal that moves many branch distances takes the two-launch path (k_mh.hip proposes, the row-split kernel
 // evaluates, k_mh.hip accepts).  But most proposals of the cycle move a few distances, and that path costs them the same two
 // trips of every chain's whole state through memory: 61 KB in and as much out per chain and step, 60 MB per lock step at 512
 // chains -- the memory system, not the arithmetic, set its 26 us.  mh_capi.cpp therefore cuts the schedule at the dense proposals
@@ -443,7 +444,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             }
             const uint64_t m0 = __builtin_amdgcn_ballot_w64(have0);
             if (m0 != 0) lj1 = log(1.0 / mh_readlane64(d0, (int)__builtin_ctzll(m0)));        // jacobianRootBranch, :393-410
-            if (cnt > kSegList) cnt = -1;                    // (cannot happen for a proposal mh_capi.cpp put into a segment: rejected below)
+            if (cnt > kSegList) {                            // cannot happen for a proposal mh_capi.cpp put into a segment; if it does, the
+                cnt = -1;                                    // chain says so: its ln likelihood is NaN from here on (nothing is accepted,
+                ll = __builtin_nan("");                      // mcd_mh_get_posterior shows it) instead of a silently wrong evaluation
+            }
         }
         if (lane == 0) *w_cnt = cnt > 0 ? cnt : 0;
         seg_post(w_req, tag);                                // (every lane stores the same word: the fence is the wave's)
@@ -628,11 +632,12 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
 
 static size_t seg_lds_bytes(int n_nodes, int np) { return sizeof(double) * (seg_table_doubles(n_nodes, np) + 2 * seg_chain_doubles(n_nodes, np)); }
 
-// trees whose factor takes 12 or 16 register blocks (515 .. 1026 nodes), columns of L^-1 on the device, at most two rounds of
-// workgroups, tables and two chains within a CU's LDS
+// trees whose factor takes 6 .. 16 register blocks (259 .. 1026 nodes: below that the streaming chain kernel's in-kernel sweeps of
+// the dense proposals cost less than two launches), columns of L^-1 on the device, at most two rounds of workgroups, tables and
+// two chains within a CU's LDS
 bool mh_segment_available(const MhDev& M, const MvnDev& V)
 {
-    if ((V.R != 12 && V.R != 16) || V.Wc == nullptr || M.n_nodes > 64 * V.R + 2 || M.n_nodes < 3 || M.batch > 1024) return false;
+    if ((V.R != 6 && V.R != 8 && V.R != 12 && V.R != 16) || V.Wc == nullptr || M.n_nodes > 64 * V.R + 2 || M.n_nodes < 3 || M.batch > 1024) return false;
     return seg_lds_bytes(M.n_nodes, 64 * V.R) <= 160 * 1024;
 }
 
@@ -669,6 +674,8 @@ hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, 
     if (Q.p_acc >= 0 && (Q.X1 == nullptr || I.zt == nullptr || !summands_kept)) return hipErrorInvalidValue;
     if (n_steps > (1 << 28)) return hipErrorInvalidValue;    // (the hand-over words count steps in 30 bits)
     if (!mh_segment_available(M, V) || I.X0 == nullptr || I.zcur == nullptr || I.NPz != 64 * V.R) return hipErrorInvalidValue;
+    if (V.R == 6) return launch_segment_R<6>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
+    if (V.R == 8) return launch_segment_R<8>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
     if (V.R == 12) return launch_segment_R<12>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
     return launch_segment_R<16>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
 }

@@ -560,8 +560,15 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
     // larger trees at a sampler's batch: the whole schedule in one launch as well, the factor streamed once per step
     // (k_mh_chain_big.hip).  MCD_MH_PER_PHASE=1 keeps the two-launch path (tests, timing; read per call).
     const char* per_phase_env = getenv("MCD_MH_PER_PHASE");
+    // From 259 nodes (R >= 6) the segment path below is ahead of it (271 nodes x 512 chains 11.3 -> 9.6 us per lock step, 513 nodes
+    // 16.0 -> 9.6): the factor streamed for every dense proposal costs more there than two launches for the few proposals that
+    // move more than 192 distances.  MCD_MH_SEGMENTS=0 / MCD_MH_INCREMENTAL=0 keep the streaming kernel.
+    const char* env_seg0 = getenv("MCD_MH_SEGMENTS");
+    const char* env_inc0 = getenv("MCD_MH_INCREMENTAL");
+    const bool prefer_segments = m->mvn && !m->chain_kernel && !(env_seg0 && env_seg0[0] == '0') && !(env_inc0 && env_inc0[0] == '0') &&
+                                 mcd::mh_segment_available(D, *m->mvn) && mcd::use_split(*m->mvn, D.batch);
     const bool streaming = m->mvn && !m->chain_kernel && !(per_phase_env && per_phase_env[0] == '1') && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
-                           mcd::mh_chain_big_available(D, *m->mvn);
+                           mcd::mh_chain_big_available(D, *m->mvn) && !prefer_segments;
     if (streaming) {
         m->last_path = MCD_MH_PATH_CHAIN_STREAMED;
         // (launches of at most ~64 k steps, whole iterations each: a second or so of kernel time; what a launch costs -- the chains'
@@ -604,7 +611,8 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // large trees: the step kernel (a workgroup per chain) leaves the proposed states' DISTANCES, the likelihood launch takes
         // them as plain vectors (the row-split kernel's tree staging costs 6 us more at 1023 slots); same arithmetic, same bits
         const int n_dim = m->mvn ? m->mvn->n : m->sp->n;
-        const bool use_x = mcd::mh_step_wg_active(D, prior_inline) && !beside && D.n_nodes > 320;
+        const int wg_from = prefer_segments ? 258 : 320;   // (the workgroup-per-chain step kernel: the only one that leaves distances)
+        const bool use_x = mcd::mh_step_wg_active(D, prior_inline, wg_from) && !beside && D.n_nodes > wg_from;
         if (m->sp && !use_x) return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_run: the sparse driver needs the workgroup-per-chain step kernel (MCD_MH_STEP_WG must not be 0)");
         if (use_x && m->d_X1 == nullptr) {
             MHIP_TRY(hipMalloc((void**)&m->d_X1, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
@@ -614,7 +622,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // MCD_MH_PRIOR_CACHE=0: every summand at every step
         {
             const char* env_cache = getenv("MCD_MH_PRIOR_CACHE");
-            const bool keep = prior_inline && mcd::mh_step_wg_active(D, prior_inline) && !(env_cache && env_cache[0] == '0');
+            const bool keep = prior_inline && mcd::mh_step_wg_active(D, prior_inline, wg_from) && !(env_cache && env_cache[0] == '0');
             if (keep && m->d_psum == nullptr) {
                 const size_t NS = (size_t)((D.n_nodes - 1 + 63) / 64) * 64;
                 MHIP_TRY(hipMalloc((void**)&m->d_psum, sizeof(double) * (size_t)D.batch * 4 * NS));
@@ -657,7 +665,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         }
         auto moves_likelihood = [&](int p) { return !(m->rows[p].kind == MCD_PROP_SCALE_SCALAR && (m->rows[p].node == 0 || m->rows[p].node == 1 || m->rows[p].node == 4)); };
         auto inc_mode = [&](int p) { return p < 0 ? 0 : !moves_likelihood(p) ? 0 : m->sparse_rows[(size_t)p] ? 1 : 2; };
-        // Trees of 515 .. 1026 nodes: the runs of steps between two dense proposals as ONE launch each, every chain's state in LDS from
+        // Trees of 259 .. 1026 nodes: the runs of steps between two dense proposals as ONE launch each, every chain's state in LDS from
         // the run's first step to its last (k_mh_chain_big.hip, SEG); a dense proposal as before: proposed by the step kernel, its
         // likelihood by the row-split launch, accepted by the step kernel.  MCD_MH_SEGMENTS=0: every step by the two launches.
         const char* env_seg = getenv("MCD_MH_SEGMENTS");

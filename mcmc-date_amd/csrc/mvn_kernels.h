@@ -277,7 +277,7 @@ hipError_t launch_mh_step(const MhDev& M, const PriorDev& P, int p_acc, int jac_
                           int summands_init = -1);   // 1: MhDev::psum does not hold the current states' summands yet (-1: when nothing is pending)
 // true: launch_mh_step takes the workgroup-per-chain kernel, which can also leave the proposed states' distances in X1 [batch][ldx]
 // (T, n_dim, X1 given) for a plain-vector likelihood launch
-bool mh_step_wg_active(const MhDev& M, int prior_inline);
+bool mh_step_wg_active(const MhDev& M, int prior_inline, int min_nodes = 320);   // (default: trees of more than min_nodes nodes)
 hipError_t launch_mh_tune(const MhDev& M, hipStream_t st);
 hipError_t launch_mc3_swap(const Mc3Dev& C, const double* lnpost, int world, int64_t per_rank, int n_swaps, uint64_t seed, uint64_t phase,
                            double* beta_local, int64_t chain0, int64_t batch, hipStream_t st);

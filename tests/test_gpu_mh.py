@@ -268,7 +268,7 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
     """Trees of more than 320 nodes at a sampler's batch (399, 599 and 1025 nodes here; an odd batch leaves a workgroup of the segment
     kernel with one chain): the workgroup-per-chain step kernel with the likelihood launch only for the proposals that move many
     distances (k_mh_inc.hip; the others: columns of L^-1 on a z kept in global memory, refreshed by a full product every 256 steps)
-    and, from 515 nodes, the runs between two dense proposals in one launch each (k_mh_segment.hip), against the same path with the
+    and the runs between two dense proposals in one launch each (k_mh_segment.hip; default from 259 nodes), against the same path with the
     full evaluation at every step (MCD_MH_INCREMENTAL=0): 1 500 lock steps, identical accept / reject decisions, states, ln priors
     and ln Jacobians bit for bit, ln acceptance ratios and ln likelihoods within the twin's tolerance."""
     from mcmc_date_amd import synthetic as S
@@ -292,8 +292,8 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
         tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
         a, k = smp.run_schedule(sched[:, :700], accumulate=True, trace=True)
         a2, k2 = smp.run_schedule(sched[:, 700:], accumulate=True, trace=True)       # a second call starts from a fresh full product
-        # 1025 nodes: the runs between two dense proposals in one launch each (k_mh_chain_big.hip, SEG) unless switched off
-        want = "segments" if (inc == "1" and seg == "1" and topo.n_nodes > 514) else "only for proposals that move many distances" if inc == "1" else "plain-vector likelihood"
+        # from 259 nodes: the runs between two dense proposals in one launch each (k_mh_segment.hip) unless switched off
+        want = "segments" if (inc == "1" and seg == "1" and topo.n_nodes > 258) else "only for proposals that move many distances" if inc == "1" else "plain-vector likelihood"
         assert want in smp.last_path(), smp.last_path()
         runs.append((np.concatenate([a, a2]), np.concatenate([k, k2]), smp.state(), smp.posterior(), smp.tuning(), smp.age_sums()[:2]))
     (a2, k2, s2, p2, t2, g2) = runs[-1]
