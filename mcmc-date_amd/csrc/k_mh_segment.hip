@@ -10,16 +10,19 @@
 // and runs every stretch between two of them (and between two recomputations of z, every 256 steps) as ONE launch of this kernel.
 //
 // A workgroup owns TWO chains for the whole segment, each with a CHAIN wave and a LIKELIHOOD wave:
-//   chain wave       state (heights, rates, scalars), the kept per-node summands of the ln prior, the current distances -- all in
-//                    LDS from the first step to the last; per step: propose (mh_device.hpp) on the nodes the proposal writes ->
-//                    the distance slots those nodes feed, each once (an LDS exchange per candidate slot), their new distances and
-//                    deltas as a list in LDS -> ln prior: the summands of the written nodes in place, the old values kept in
-//                    registers (prior_device.hpp; sums in the order of the full evaluation: the same bits as k_mh.hip) -> waits for
-//                    |z'|^2 -> accept / reject -> commit or take back on the written nodes and listed slots only
-//   likelihood wave  z = L^-1 (d - mu) of the current state in registers (R per lane); per step z' = z + sum_j delta_j W[:, j] over
-//                    the list, four columns of W = L^-1 (MvnDev::Wc, 8 KiB each at N = 1023) in flight, |z'|^2 back through LDS --
-//                    while the chain wave evaluates the ln prior; keeps z' when the chain wave says so
-// The two waves of a chain talk through four LDS words (request, reply, decision, count): no workgroup barrier after the tables
+//   chain wave       state (heights, rates, scalars) and the kept per-node summands of the ln prior -- all in LDS from the first step
+//                    to the last; per step: propose (mh_device.hpp) on the nodes the proposal writes, post the transform -> ln prior:
+//                    the summands of the written nodes in place, the old values kept in registers (prior_device.hpp; sums in the
+//                    order of the full evaluation: the same bits as k_mh.hip) -> wait for |z'|^2 -> accept / reject -> commit or
+//                    take back on the written nodes only
+//   likelihood wave  the current distances (LDS) and z = L^-1 (d - mu) of the current state (registers, R per lane); per step, while
+//                    the chain wave evaluates the ln prior: the distance slots the written nodes feed, each once (an LDS exchange per
+//                    candidate slot), their new distances and deltas as a list -> z' = z + sum_j delta_j W[:, j] over the list, four
+//                    columns of W = L^-1 (MvnDev::Wc, 8 KiB each at N = 1023, an L2 miss each) in flight -> |z'|^2 (and ln
+//                    jacobianRootBranch when slot 0 moved) back through LDS; keeps z' and the new distances when the chain wave says so
+//                    (measured: 3 / 4 / 6 / 8 columns in flight 11.27 / 11.21 / 11.62 / 12.03 us per lock step at 1025 nodes -- the
+//                    padding of a batch is loaded too, and most proposals move one to three distances)
+// The two waves of a chain talk through a few LDS words (request, reply, decision; count, |z'|^2, the transform): no workgroup barrier after the tables
 // are in LDS, nothing leaves the CU.  A chain's state, distances, z and summands come from where the two-launch path keeps them (MhDev, MhInc::X0 / zcur,
 // MhDev::psum) and go back there at the end: that path continues from them.
 //
@@ -38,6 +41,11 @@
 
 namespace mcd {
 
+constexpr int kSegApplyDoubles = (int)((sizeof(PropApply) + 7) / 8);   // the proposal's per-node transform, chain wave -> likelihood wave
+#ifndef MCD_SEG_COLS
+#define MCD_SEG_COLS 4
+#endif
+constexpr int kSegCols = MCD_SEG_COLS;   // columns of L^-1 in flight per batch
 constexpr int kSegList = kMhSegList;   // moved distances of one proposal at most (mh_capi.cpp: proposals that may move more are dense)
 
 __device__ __forceinline__ bool seg_moves_likelihood(int kind, int node)
@@ -49,20 +57,25 @@ __device__ __forceinline__ bool seg_moves_likelihood(int kind, int node)
 // of children), and three int16 ones of the distance slots (slot -> node, slot -> that node's parent, node -> slot).
 __host__ __device__ inline size_t seg_table_doubles(int n_nodes, int np) { return (5 * (size_t)n_nodes + 1) / 2 + 1 + ((size_t)n_nodes + 2 * (size_t)np + 3) / 4 + 1; }
 // Per chain: 4 state rows, the summands of the two blocks, the current distances [np]; the list (new distance, delta: doubles; slot:
-// int32); the slots' marks (int32 [np]); eight words of hand-over.
+// int32); the slots' marks (int32 [np]); eight words of hand-over; the proposal's per-node transform.
 __host__ __device__ inline size_t seg_chain_doubles(int n_nodes, int np)
 {
-    return 6 * (size_t)n_nodes + (size_t)np + 2 * (size_t)kSegList + (size_t)kSegList / 2 + (size_t)np / 2 + 8;
+    return 6 * (size_t)n_nodes + (size_t)np + 2 * (size_t)kSegList + (size_t)kSegList / 2 + (size_t)np / 2 + 8 + (size_t)kSegApplyDoubles;
 }
 
 struct SegWords {                  // the hand-over between a chain's two waves (LDS)
-    int req;                       // chain wave: step + 1 when the list of step `step` is complete
-    int cnt;                       // ... its length
-    int resp;                      // likelihood wave: step + 1 when q is
+    int req;                       // chain wave: step + 1 when the proposal of step `step` is applied (Hp, Rp) and its transform posted
+    int moves;                     // ... whether it can move the distances at all
+    int resp;                      // likelihood wave: step + 1 when q is there
     int dec;                       // chain wave: 2 (step + 1) + accepted
+    int cnt;                       // likelihood wave: moved distances (-1: more than the list holds)
+    int have0;                     // ... whether slot 0 is among them (then lj = ln jacobianRootBranch of the proposal)
     double q;                      // |z'|^2
-    double pad[5];
+    double lj;
+    double s1;                     // chain wave: tH * rMu of the proposal
+    double pad[2];
 };
+static_assert(sizeof(SegWords) == 64, "eight doubles of LDS");
 
 __device__ __forceinline__ int seg_poll(const volatile int* w, int want_shifted, int shift)
 {
@@ -134,11 +147,17 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     int32_t* l_j = reinterpret_cast<int32_t*>(l_delta + kSegList);
     int32_t* mark = l_j + kSegList;                          // [NPad] the step (+ 1) that last listed the slot
     SegWords* words = reinterpret_cast<SegWords*>(reinterpret_cast<double*>(mark + NPad));
+    PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(words) + 8);
     volatile int* w_req = &words->req;
-    volatile int* w_cnt = &words->cnt;
+    volatile int* w_moves = &words->moves;
     volatile int* w_resp = &words->resp;
     volatile int* w_dec = &words->dec;
+    volatile int* w_cnt = &words->cnt;
+    volatile int* w_have0 = &words->have0;
     volatile double* w_q = &words->q;
+    volatile double* w_lj = &words->lj;
+    volatile double* w_s1 = &words->s1;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     // ---- the tables, by all four waves (the only workgroup barriers of the kernel: before any wave polls a hand-over word)
     const int rr = T.root_right;
@@ -152,9 +171,11 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     }
     if (wave < 2 && lane == 0) {
         words->req = 0;
-        words->cnt = 0;
+        words->moves = 0;
         words->resp = 0;
         words->dec = 0;
+        words->cnt = 0;
+        words->have0 = 0;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < NPad; j += 256) {
@@ -179,17 +200,97 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
 #pragma unroll
             for (int k = 0; k < R; ++k) zc[k] = I.zcur[b * I.NPz + 64 * k + lane];
         }
+        // the current distances (this wave's: it lists the moved ones and commits them) and the slots' marks
+        {
+            const double* xsrc = (took ? Q.X1 : I.X0) + b * (int64_t)V.n;
+            for (int j = lane; j < NPad; j += 64) {
+                mark[j] = 0;
+                dcur[j] = (j < V.n) ? xsrc[j] : 0.0;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int tag = (int)gs + 1;
             (void)seg_poll(w_req, tag, 0);
-            const int cnt = *w_cnt;
+            // ---- the distances the written nodes feed: a written node's own slot, and its daughters' when its height is written.  Each
+            // slot once (the first lane to exchange the slot's mark for this step's lists it), with its new distance and the delta.
+            int cnt = 0;
+            if (*w_moves) {
+                const PropApply A = *A_lds;
+                const double s1 = *w_s1;
+                double d0 = 0.0;                             // the new distance of slot 0, in the lane that listed it
+                bool have0 = false;
+                auto emit = [&](bool active, int node_) {    // (every lane calls it: the ballots are the wave's)
+                    if (__builtin_amdgcn_ballot_w64(active) == 0) return;
+                    const int slot = active ? (int)ts_of[node_] : -1;
+                    bool mine = false;
+                    if (slot >= 0) mine = atomicExch(&mark[slot], tag) != tag;
+                    const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
+                    if (mine) {
+                        const int pos = cnt + (int)__builtin_popcountll(mk & lt_mask);
+                        // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)   (app/Probability.hs:195-207), the
+                        // arithmetic of load_tree (mvn_device.hpp) and of k_mh_step_wg's X1
+                        const int a = ts_node[slot], pa = ts_parent[slot];
+                        double x = (Hp[pa] - Hp[a]) * Rp[a];
+                        if (slot == 0) x = x + (Hp[0] - Hp[rr]) * Rp[rr];
+                        x = x * s1;
+                        if (pos < kSegList) {
+                            l_j[pos] = slot;
+                            l_dnew[pos] = x;
+                            l_delta[pos] = x - dcur[slot];
+                        }
+                        if (slot == 0) {
+                            d0 = x;
+                            have0 = true;
+                        }
+                    }
+                    cnt += (int)__builtin_popcountll(mk);
+                };
+                auto emit_height = [&](bool active, int w) {    // a node whose height is written: its branch and its daughters'
+                    emit(active, w);
+                    const int nc = active ? tb_nch[w] : 0;
+                    emit(nc > 0, active ? tb_first[w] : 0);
+                    emit(nc > 1, active ? tb_second[w] : 0);
+                };
+                for (int w0 = A.hlo; w0 < A.hhi; w0 += 64) emit_height(w0 + lane < A.hhi, w0 + lane);
+                for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
+                for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
+                {
+                    // the single nodes in ONE pass: lanes 0 .. 2 the first height-written node with its daughters, 3 .. 5 the second, 6 .. 8
+                    // the three rate-written ones
+                    const int g = lane / 3, r = lane - 3 * g;
+                    int cand = -1;
+                    if (lane < 6) {
+                        const int base = (g == 0) ? A.pt1 : A.pt2;
+                        if (base >= 0) cand = (r == 0) ? base : (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+                    } else if (lane < 9) {
+                        cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
+                    }
+                    emit(cand >= 0, cand >= 0 ? cand : 0);
+                }
+                for (int i = A.brace_lo; i < A.brace_hi; ++i) {
+                    const int x = M.brace_nodes[i];
+                    emit_height(lane == 0, x);               // (SLIDE_BRACE_CONTRA also writes the rates of x and its daughters: the same slots)
+                }
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(have0);
+                if (lane == 0) *w_have0 = (m0 != 0) ? 1 : 0;
+                if (m0 != 0) {
+                    const double lj1 = log(1.0 / mh_readlane64(d0, (int)__builtin_ctzll(m0)));     // jacobianRootBranch, :393-410
+                    if (lane == 0) *w_lj = lj1;
+                }
+                if (cnt > kSegList) cnt = -1;                // (cannot happen for a proposal mh_capi.cpp put into a segment: the chain wave says so)
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // the list is in LDS before any lane reads it
+                __builtin_amdgcn_wave_barrier();
+            }
             double zp[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) zp[k] = zc[k];
-            for (int m0 = 0; m0 < cnt; m0 += 4) {             // four columns in flight
-                double col[4][R], dl[4];
+            // kSegCols columns in flight: a column is an L2 miss (W is 8 MB at N = 1023), a batch costs its latency once
+            for (int m0 = 0; m0 < cnt; m0 += kSegCols) {
+                double col[kSegCols][R], dl[kSegCols];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kSegCols; ++u) {
                     const int m = (m0 + u < cnt) ? m0 + u : cnt - 1;   // (past the end: the last column again with weight 0: exact)
                     const int j = __builtin_amdgcn_readfirstlane(l_j[m]);
                     dl[u] = (m0 + u < cnt) ? l_delta[m] : 0.0;
@@ -198,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
                     for (int k = 0; k < R; ++k) col[u][k] = wc[64 * k];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kSegCols; ++u)
 #pragma unroll
                     for (int k = 0; k < R; ++k) zp[k] = fma(dl[u], col[u][k], zp[k]);
             }
@@ -206,17 +307,24 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
 #pragma unroll
             for (int k = 0; k < R; ++k) sq = fma(zp[k], zp[k], sq);
             const double q = wave_sum(sq);
-            if (lane == 0) *w_q = q;
+            if (lane == 0) {
+                *w_q = q;
+                *w_cnt = cnt;
+            }
             seg_post(w_resp, tag);                           // (every lane stores the same word: the fence is the wave's)
             const int d = seg_poll(w_dec, tag, 1);
             if ((d & 1) && cnt > 0) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) zc[k] = zp[k];
+                for (int m = lane; m < cnt; m += 64) dcur[l_j[m]] = l_dnew[m];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
             }
         }
         if (valid) {
 #pragma unroll
             for (int k = 0; k < R; ++k) I.zcur[b * I.NPz + 64 * k + lane] = zc[k];
+            for (int j = lane; j < V.n; j += 64) I.X0[b * (int64_t)V.n + j] = dcur[j];
         }
         return;
     }
@@ -231,13 +339,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         if (took) atomicAdd(&M.acc[b * NPr + Q.p_acc], 1);
         if (Q.trace_alpha) Q.trace_alpha[b] = la_pending;
         if (Q.trace_accept) Q.trace_accept[b] = took ? 1 : 0;
-    }
-    {
-        const double* xsrc = (took ? Q.X1 : I.X0) + b * (int64_t)V.n;
-        for (int j = lane; j < NPad; j += 64) {
-            mark[j] = 0;
-            dcur[j] = (j < V.n) ? xsrc[j] : 0.0;
-        }
     }
     MhDev Ml = M;
     Ml.parent = tb_parent;
@@ -332,7 +433,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             if (w >= 0) f(w);
         }
     };
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #ifdef MCD_SEG_STAMP
     // diagnostic build (make stamp_seg): s_memtime ticks per phase of the chain wave, summed over the launch, in the first rows of
     // trace_alpha: 0 loop head + draws, 1 propose, 2 list of moved distances, 3 ln prior, 4 waiting for |z'|^2, 5 decision + commit
@@ -381,75 +481,14 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the writes above have landed before any lane reads them
         __builtin_amdgcn_wave_barrier();
         SEG_TICK(1)
-        // ---- the distances the written nodes feed: a written node's own slot, and its daughters' when its height is written.  Each
-        // slot once (the first lane to exchange the slot's mark for this step's lists it), with its new distance and the delta.
+        // ---- the likelihood wave takes it from here: the transform (which nodes are written), Hp / Rp, tH * rMu
         const bool moves = seg_moves_likelihood(row.kind, row.node);
         double lj1 = lj;
-        int cnt = 0;
-        if (moves) {
-            const double s1 = sc1[2] * sc1[3];
-            double d0 = 0.0;                                 // the new distance of slot 0, in the lane that listed it
-            bool have0 = false;
-            auto emit = [&](bool active, int node_) {        // (every lane calls it: the ballots are the wave's)
-                if (__builtin_amdgcn_ballot_w64(active) == 0) return;
-                const int slot = active ? (int)ts_of[node_] : -1;
-                bool mine = false;
-                if (slot >= 0) mine = atomicExch(&mark[slot], tag) != tag;
-                const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
-                if (mine) {
-                    const int pos = cnt + (int)__builtin_popcountll(mk & lt_mask);
-                    // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)   (app/Probability.hs:195-207), the
-                    // arithmetic of load_tree (mvn_device.hpp) and of k_mh_step_wg's X1
-                    const int a = ts_node[slot], pa = ts_parent[slot];
-                    double x = (Hp[pa] - Hp[a]) * Rp[a];
-                    if (slot == 0) x = x + (Hp[0] - Hp[rr]) * Rp[rr];
-                    x = x * s1;
-                    if (pos < kSegList) {
-                        l_j[pos] = slot;
-                        l_dnew[pos] = x;
-                        l_delta[pos] = x - dcur[slot];
-                    }
-                    if (slot == 0) {
-                        d0 = x;
-                        have0 = true;
-                    }
-                }
-                cnt += (int)__builtin_popcountll(mk);
-            };
-            auto emit_height = [&](bool active, int w) {    // a node whose height is written: its branch and its daughters'
-                emit(active, w);
-                const int nc = active ? tb_nch[w] : 0;
-                emit(nc > 0, active ? tb_first[w] : 0);
-                emit(nc > 1, active ? tb_second[w] : 0);
-            };
-            for (int w0 = A.hlo; w0 < A.hhi; w0 += 64) emit_height(w0 + lane < A.hhi, w0 + lane);
-            for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
-            for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
-            {
-                // the single nodes in ONE pass: lanes 0 .. 2 the first height-written node with its daughters, 3 .. 5 the second, 6 .. 8
-                // the three rate-written ones
-                const int g = lane / 3, r = lane - 3 * g;
-                int cand = -1;
-                if (lane < 6) {
-                    const int base = (g == 0) ? A.pt1 : A.pt2;
-                    if (base >= 0) cand = (r == 0) ? base : (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
-                } else if (lane < 9) {
-                    cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
-                }
-                emit(cand >= 0, cand >= 0 ? cand : 0);
-            }
-            for (int i = A.brace_lo; i < A.brace_hi; ++i) {
-                const int x = M.brace_nodes[i];
-                emit_height(lane == 0, x);                   // (SLIDE_BRACE_CONTRA also writes the rates of x and its daughters: the same slots)
-            }
-            const uint64_t m0 = __builtin_amdgcn_ballot_w64(have0);
-            if (m0 != 0) lj1 = log(1.0 / mh_readlane64(d0, (int)__builtin_ctzll(m0)));        // jacobianRootBranch, :393-410
-            if (cnt > kSegList) {                            // cannot happen for a proposal mh_capi.cpp put into a segment; if it does, the
-                cnt = -1;                                    // chain says so: its ln likelihood is NaN from here on (nothing is accepted,
-                ll = __builtin_nan("");                      // mcd_mh_get_posterior shows it) instead of a silently wrong evaluation
-            }
+        if (lane == 0) {
+            *A_lds = A;
+            *w_s1 = sc1[2] * sc1[3];
+            *w_moves = moves ? 1 : 0;
         }
-        if (lane == 0) *w_cnt = cnt > 0 ? cnt : 0;
         seg_post(w_req, tag);                                // (every lane stores the same word: the fence is the wave's)
         SEG_TICK(2)
         // ---- ln prior: only the blocks whose inputs the proposal writes (a superset of "changed": a block re-evaluated on unchanged
@@ -543,6 +582,11 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         double ll1 = ll;
         if (moves) {
             const double q = *w_q;
+            const int cnt = *w_cnt;
+            if (*w_have0) lj1 = *w_lj;
+            if (cnt < 0) ll = __builtin_nan("");             // more moved distances than the list holds -- cannot happen for a proposal mh_capi.cpp
+                                                             // put into a segment; if it does, the chain says so: its ln likelihood is NaN from here
+                                                             // on (nothing is accepted, mcd_mh_get_posterior shows it), not a silently wrong value
             ll1 = (cnt < 0) ? __builtin_nan("") : V.c + (-0.5) * (V.logdet + q);      // :169 (finish_ll)
         }
         double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
@@ -563,7 +607,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
             }
             if (!few_cl && need_cl)
                 for (int v = 1 + lane; v < nn; v += 64) tcl[v] = prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
-            for (int m = lane; m < cnt; m += 64) dcur[l_j[m]] = l_dnew[m];
             c0 = c0p;
             c1 = c1p;
             c2 = c2p;
@@ -608,7 +651,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         M.H[b * M.ld + w] = Hc[w];
         M.R[b * M.ld + w] = Rc[w];
     }
-    for (int j = lane; j < V.n; j += 64) I.X0[b * (int64_t)V.n + j] = dcur[j];
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) M.sc[i * B + b] = sc[i];
