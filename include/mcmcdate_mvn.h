@@ -101,7 +101,8 @@ int mcd_mvn_release_stream(const mcd_mvn_t* h, void* stream /* hipStream_t */);
  * factor W with P = W^T W directly (a reverse Cholesky factorisation: nothing is inverted twice) and L = W^-1 for the sweeps.
  * Contract, stricter than the reference's: the matrix must be numerically positive definite -- MCD_ERR_NOT_SPD otherwise.  (The
  * reference evaluates dx^T P dx with whatever P the .data file holds; `prepare` itself refuses a covariance matrix whose
- * determinant is not positive, app/Main.hs:231, so an indefinite P only arises from a hand-made file.)
+ * determinant is not positive, app/Main.hs:231, so an indefinite P only arises from a hand-made file.  For such a matrix use the
+ * product form, mcd_sparse_create below, which takes P as given -- the host mirrors' likelihoodFunction do so by themselves.)
  */
 int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, int mat_kind,
                    double logdet_sigma, int device_id);

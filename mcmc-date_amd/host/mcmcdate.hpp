@@ -87,9 +87,13 @@ struct Univariate { Vec mu; Vec vs; };
 struct NoData {};
 using LikelihoodData = std::variant<Full, Sparse, Univariate, NoData>;
 
+// mcd_mvn_create refuses a matrix that has no Cholesky factor (MCD_ERR_NOT_SPD); likelihoodFunction then takes the product form
+struct NotPositiveDefinite : std::runtime_error { using std::runtime_error::runtime_error; };
+
 namespace detail {
 inline void check(int rc)
 {
+    if (rc == MCD_ERR_NOT_SPD) throw NotPositiveDefinite(std::string(mcd_last_error()));
     if (rc != MCD_OK) throw std::runtime_error(std::string(mcd_last_error()));
 }
 struct MvnDeleter { void operator()(mcd_mvn_t* p) const { mcd_mvn_destroy(p); } };
@@ -218,8 +222,28 @@ private:
 // likelihoodFunction :: LikelihoodData -> LikelihoodFunction I   (app/Probability.hs:277-281)
 inline std::function<double(const I&)> likelihoodFunction(const LikelihoodData& lhd, const Topology& topo, int device = 0)
 {
-    auto lik = std::make_shared<Likelihood>(lhd, topo, device);
-    return [lik](const I& x) { return (*lik)(x); };
+    try {
+        auto lik = std::make_shared<Likelihood>(lhd, topo, device);
+        return [lik](const I& x) { return (*lik)(x); };
+    } catch (const NotPositiveDefinite&) {
+        // The dense kernels need a factor; the reference evaluates dx . (P dx) with whatever P the record holds
+        // (app/Probability.hs:169, 183): an indefinite precision matrix takes the product form on the device (mcd_sparse_*).
+        Sparse sp;
+        if (const Full* f = std::get_if<Full>(&lhd)) {
+            const int n = (int)f->mu.size();
+            sp.mu = f->mu;
+            sp.logDetSigma = f->logDetSigma;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j)
+                    if (f->sigmaInv[(size_t)i * n + j] != 0.0) sp.sigmaInvAssoc.push_back({{i, j}, f->sigmaInv[(size_t)i * n + j]});
+        } else if (const Sparse* s = std::get_if<Sparse>(&lhd)) {
+            sp = *s;
+        } else {
+            throw;
+        }
+        auto lik = std::make_shared<SparseLikelihood>(sp, topo, device);
+        return [lik](const I& x) { return (*lik)(x); };
+    }
 }
 
 // ---- priorFunction -- app/Probability.hs:127-150 ----------------------------------------------------------------------

@@ -549,7 +549,19 @@ def likelihood_function(lhd: LikelihoodData, topo: Topology, device: int = 0) ->
     if isinstance(lhd, Sparse) and len(lhd.mu) > 1024:           # beyond the dense kernels: the precision matrix stays sparse on the device
         tl = SparseLikelihood(lhd, device).bind_tree(topo)
     else:
-        tl = MvnLikelihood(lhd, device).bind_tree(topo)
+        try:
+            tl = MvnLikelihood(lhd, device).bind_tree(topo)
+        except _capi.NotPositiveDefinite:
+            # The dense kernels need a factor of the matrix; the reference evaluates dx . (P dx) with whatever P the record holds
+            # (app/Probability.hs:169, 183).  An indefinite precision matrix therefore takes the product form on the device
+            # (csrc/k_sparse.hip: P as given, nothing factored) -- same value as the reference's, on the GPU.
+            if isinstance(lhd, Full):
+                P = _host(lhd.sigma_inv)
+                ii, jj = np.nonzero(P)
+                lhd = Sparse(lhd.mu, [((int(i), int(j)), float(P[i, j])) for i, j in zip(ii, jj)], lhd.logdet_sigma)
+            elif not isinstance(lhd, Sparse):
+                raise
+            tl = SparseLikelihood(lhd, device).bind_tree(topo)
 
     def f(x: State) -> float:
         ll, _ = tl.loglik(StateBatch.from_states([x]), want_jacobian=False)

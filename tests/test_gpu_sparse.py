@@ -194,3 +194,25 @@ def twin_ll(topo, st, mu, P, logdet):
     D = np.array([O.distances(topo.parent, st.heights[b], st.rates[b], st.time_height[b], st.rate_mean[b]) for b in range(st.heights.shape[0])])
     dd = D - mu
     return -n * 0.9189385332046727 - 0.5 * (logdet + np.einsum("bi,bi->b", dd, (P @ dd.T).T))
+
+
+def test_indefinite_precision_matrix_takes_the_product_form(gpu):
+    """The reference evaluates dx . (P dx) with whatever precision matrix the record holds (app/Probability.hs:169, 183); the dense
+    kernels need a factor and refuse a matrix without one (NotPositiveDefinite).  likelihood_function then evaluates the product form on
+    the device (no factor needed): the value of the oracle's restatement of the reference's formula, for a Full and for a Sparse record."""
+    topo = M.Topology(np.array([-1, 0, 1, 1, 0, 4, 4, 6, 6], dtype=np.int32))
+    n = topo.n_nodes - 2
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, n))
+    P = A + A.T                                              # symmetric, eigenvalues of both signs
+    assert np.linalg.eigvalsh(P).min() < 0 < np.linalg.eigvalsh(P).max()
+    mu = rng.uniform(0.05, 0.3, n)
+    with pytest.raises(M.NotPositiveDefinite):
+        M.MvnLikelihood(M.Full(mu, P, 1.7))
+    s = M.State(1.0, 0.8, 1.3, np.array([1.0, 0.6, 0.0, 0.0, 0.7, 0.0, 0.3, 0.0, 0.0]), 0.9, 0.3,
+                np.array([1.0, 1.1, 0.8, 1.2, 0.9, 1.05, 0.95, 1.3, 0.7]))
+    d = O.distances(topo.parent, s.time_tree, s.rate_tree, s.time_height, s.rate_mean)
+    want = O.logpdf_full(mu, P, 1.7, d)
+    for lhd in (M.Full(mu, P, 1.7), M.Sparse(mu, [((i, j), float(P[i, j])) for i in range(n) for j in range(n)], 1.7)):
+        f = M.likelihood_function(lhd, topo)
+        assert abs(f(s) - want) <= 1e-12 * max(1.0, abs(want)), (f(s), want)
