@@ -617,6 +617,13 @@ def main():
         if world == 1 and args.kind == "logpdf" and not args.no_mh:
             # the metric's "= MCMC steps/sec x chains": real Metropolis-Hastings steps on a tree of this size (secondary field)
             out["mh"] = mh_measure(dev_index, n, B, 4000, 400)
+            if n == 256 and B == 512:
+                # ... and on BASELINE config 5's share of one GPU (1025-node tree, 512 chains; `--kind mh --dim 1024` is the full line)
+                try:
+                    r5 = mh_measure(dev_index, 1024, 512, 4000, 400)
+                    out["mh_config5_share"] = {k: r5[k] for k in ("value", "unit", "us_per_lockstep", "n_nodes", "dimension", "chains", "lock_steps", "what")}
+                except Exception as e:                       # (a secondary field must not take the line down)
+                    out["mh_config5_share"] = {"error": repr(e)}
         if world == 1 and args.kind == "logpdf" and not args.no_mh and B <= 1024:
             out["full_gpu"] = full_gpu_measure(dev_index, n)
         if world == 1 and not args.no_cpu_baseline:
