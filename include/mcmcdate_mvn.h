@@ -336,9 +336,9 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  * accumulate != 0: after every iteration add the absolute node ages tH * h_v to the running sums.
  * trace_alpha / trace_accept (host, may be NULL): [n_iter * steps_per_iter][batch] ln acceptance ratio / decision.
  * Trees of at most 64 nodes: the whole schedule in one launch, the factor of Sigma in LDS; up to 514 nodes (N <= 512) and 1024 chains: the
- * same with the factor streamed through LDS once per step (default up to 258 nodes).  Trees of 259 .. 1026 nodes (up to 1024 chains): every run of steps between
+ * same with the factor streamed through LDS once per step (default up to 258 nodes).  Trees of 259 .. 1026 nodes: every run of steps between
  * two proposals that move more than 192 branch distances in one launch, the chains' states in LDS (k_mh_segment.hip); such a dense
- * proposal by two launches.  Larger batches, and trees over a sparse likelihood: two launches per step -- accept the pending
+ * proposal by two launches.  Trees of up to 258 nodes with more than 1024 chains, and trees over a sparse likelihood: two launches per step -- accept the pending
  * proposal and propose the next one; then ln likelihood of the proposed states, which up to 256 dimensions also carries their ln
  * prior as workgroups of a second role (both depend on the proposal only); from 321 nodes the likelihood launch only for proposals that
  * move more than 32 distances (the others: columns of L^-1 on a kept z).  Environment, read per call, for tests and timing:

@@ -40,12 +40,13 @@ __global__ __launch_bounds__(kIncT) void k_mh_inc_init(MhDev M, TreeDev T, MhInc
     }
 }
 
-// zcur <- the z tiles of a full product on X0 (all chains)
-__global__ __launch_bounds__(kIncT) void k_mh_inc_take_z(MhDev M, MhInc I)
+// dst[b0 + c] <- the z tiles of a full product on `count` chains starting at chain b0 (tile-major: the row-split kernel's scratch); dst = zcur
+// (a full product on X0) or zprop (a dense proposal of a batch beyond the row-split kernel's 1024 chains, taken chunk by chunk)
+__global__ __launch_bounds__(kIncT) void k_mh_inc_take_z(MhInc I, double* __restrict__ dst, int64_t b0)
 {
-    const int64_t b = blockIdx.x;
-    const double* zt = I.zt + ((b >> 4) * I.nr) * 16 + (b & 15);
-    double* zc = I.zcur + b * I.NPz;
+    const int64_t c = blockIdx.x;                            // chain within the chunk
+    const double* zt = I.zt + ((c >> 4) * I.nr) * 16 + (c & 15);
+    double* zc = dst + (b0 + c) * I.NPz;
     for (int i = threadIdx.x; i < I.NPz; i += kIncT) zc[i] = (i < I.nr) ? zt[(int64_t)i * 16] : 0.0;
 }
 
@@ -55,9 +56,10 @@ hipError_t launch_mh_inc_init(const MhDev& M, const TreeDev& T, const MhInc& I, 
     return hipGetLastError();
 }
 
-hipError_t launch_mh_inc_take_z(const MhDev& M, const MhInc& I, hipStream_t st)
+hipError_t launch_mh_inc_take_z(const MhInc& I, double* dst, int64_t b0, int64_t count, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mh_inc_take_z, dim3((unsigned)M.batch), dim3(kIncT), 0, st, M, I);
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mh_inc_take_z, dim3((unsigned)count), dim3(kIncT), 0, st, I, dst, b0);
     return hipGetLastError();
 }
 

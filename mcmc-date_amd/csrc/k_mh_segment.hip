@@ -46,6 +46,7 @@ constexpr int kSegApplyDoubles = (int)((sizeof(PropApply) + 7) / 8);   // the pr
 #define MCD_SEG_COLS 4
 #endif
 constexpr int kSegCols = MCD_SEG_COLS;   // columns of L^-1 in flight per batch
+constexpr int64_t kSegMaxBatch = 65536;   // (beyond 512 chains the workgroups run in rounds: a launch lasts rounds x steps)
 constexpr int kSegList = kMhSegList;   // moved distances of one proposal at most (mh_capi.cpp: proposals that may move more are dense)
 
 __device__ __forceinline__ bool seg_moves_likelihood(int kind, int node)
@@ -192,7 +193,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         double zc[R];                                        // z = L^-1 (d - mu) of the current state, rows 64 k + lane
         double la_pending;
         const bool took = Q.p_acc >= 0 && seg_accept_pending(M, Q, b, seed, la_pending);
-        if (took) {                                          // z' of the accepted dense proposal: the row-split kernel's tiles
+        if (took && Q.z_in_zprop) {                          // z' of the accepted dense proposal: copied chain-major (large batches)
+#pragma unroll
+            for (int k = 0; k < R; ++k) zc[k] = I.zprop[b * I.NPz + 64 * k + lane];
+        } else if (took) {                                   // ... or still in the row-split kernel's tiles
             const double* zt = I.zt + ((b >> 4) * I.nr) * 16 + (b & 15);
 #pragma unroll
             for (int k = 0; k < R; ++k) zc[k] = (64 * k + lane < I.nr) ? zt[(int64_t)(64 * k + lane) * 16] : 0.0;
@@ -675,11 +679,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
 static size_t seg_lds_bytes(int n_nodes, int np) { return sizeof(double) * (seg_table_doubles(n_nodes, np) + 2 * seg_chain_doubles(n_nodes, np)); }
 
 // trees whose factor takes 6 .. 16 register blocks (259 .. 1026 nodes: below that the streaming chain kernel's in-kernel sweeps of
-// the dense proposals cost less than two launches), columns of L^-1 on the device, at most two rounds of workgroups, tables and
-// two chains within a CU's LDS
+// the dense proposals cost less than two launches), columns of L^-1 on the device, tables and two chains within a CU's LDS
 bool mh_segment_available(const MhDev& M, const MvnDev& V)
 {
-    if ((V.R != 6 && V.R != 8 && V.R != 12 && V.R != 16) || V.Wc == nullptr || M.n_nodes > 64 * V.R + 2 || M.n_nodes < 3 || M.batch > 1024) return false;
+    if ((V.R != 6 && V.R != 8 && V.R != 12 && V.R != 16) || V.Wc == nullptr || M.n_nodes > 64 * V.R + 2 || M.n_nodes < 3 || M.batch > kSegMaxBatch) return false;
     return seg_lds_bytes(M.n_nodes, 64 * V.R) <= 160 * 1024;
 }
 
@@ -713,7 +716,7 @@ hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, 
     Q.p_acc = -1;
     if (pending) Q = *pending;
     if (n_steps <= 0) return Q.p_acc >= 0 ? hipErrorInvalidValue : hipSuccess;
-    if (Q.p_acc >= 0 && (Q.X1 == nullptr || I.zt == nullptr || !summands_kept)) return hipErrorInvalidValue;
+    if (Q.p_acc >= 0 && (Q.X1 == nullptr || (Q.z_in_zprop ? I.zprop == nullptr : I.zt == nullptr) || !summands_kept)) return hipErrorInvalidValue;
     if (n_steps > (1 << 28)) return hipErrorInvalidValue;    // (the hand-over words count steps in 30 bits)
     if (!mh_segment_available(M, V) || I.X0 == nullptr || I.zcur == nullptr || I.NPz != 64 * V.R) return hipErrorInvalidValue;
     if (V.R == 6) return launch_segment_R<6>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);

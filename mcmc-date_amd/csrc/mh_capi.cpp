@@ -566,7 +566,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
     const char* env_seg0 = getenv("MCD_MH_SEGMENTS");
     const char* env_inc0 = getenv("MCD_MH_INCREMENTAL");
     const bool prefer_segments = m->mvn && !m->chain_kernel && !(env_seg0 && env_seg0[0] == '0') && !(env_inc0 && env_inc0[0] == '0') &&
-                                 mcd::mh_segment_available(D, *m->mvn) && mcd::use_split(*m->mvn, D.batch);
+                                 mcd::mh_segment_available(D, *m->mvn) && mcd::use_split(*m->mvn, std::min<int64_t>(D.batch, mcd::kSplitMaxBatch));
     const bool streaming = m->mvn && !m->chain_kernel && !(per_phase_env && per_phase_env[0] == '1') && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
                            mcd::mh_chain_big_available(D, *m->mvn) && !prefer_segments;
     if (streaming) {
@@ -606,7 +606,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         const char* env_prior = getenv("MCD_MH_PRIOR");
         // (A launch of its own for the prior with four waves per chain was measured for the larger trees: 58.9 -> 56.4 us per
         // lock step at 1025 nodes, 33.3 -> 35.4 at 513 -- the step kernel's other strided loops weigh more there; not kept.)
-        const bool beside = m->mvn && !(env_prior && atoi(env_prior) == 0) && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
+        const bool beside = m->mvn && !prefer_segments && !(env_prior && atoi(env_prior) == 0) && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
         const int prior_inline = beside ? 0 : 1;
         // large trees: the step kernel (a workgroup per chain) leaves the proposed states' DISTANCES, the likelihood launch takes
         // them as plain vectors (the row-split kernel's tree staging costs 6 us more at 1023 slots); same arithmetic, same bits
@@ -639,8 +639,11 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // Large trees at a sampler's batch: the likelihood launch only for the proposals that move many distances (k_mh_inc.hip);
         // the others are evaluated from columns of L^-1 on the kept z.  MCD_MH_INCREMENTAL=0: the full evaluation at every step.
         const char* env_inc = getenv("MCD_MH_INCREMENTAL");
+        // (batches beyond the row-split kernel's 1024 chains: its z products chunk by chunk, z' of a dense proposal copied to zprop)
         const bool inc = m->mvn && use_x && !(env_inc && env_inc[0] == '0') && m->mvn->Wc != nullptr && 64 * m->mvn->R <= 1024 &&
-                         mcd::use_split(*m->mvn, D.batch);
+                         mcd::use_split(*m->mvn, std::min<int64_t>(D.batch, mcd::kSplitMaxBatch));
+        const bool chunked = D.batch > mcd::kSplitMaxBatch;
+        const int dense_mode = chunked ? 1 : 2;              // where the z' of a dense proposal is afterwards: zprop or the z tiles
         mcd::MhInc& I = m->inc;
         if (inc && I.X0 == nullptr) {
             I.NPz = 64 * m->mvn->R;
@@ -653,11 +656,17 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
             MHIP_TRY(hipMalloc((void**)&m->d_inc_ll, sizeof(double) * (size_t)D.batch));
             m->allocs.push_back(m->d_inc_ll);
         }
-        auto refresh_z = [&]() -> int {                      // zcur <- L^-1 (X0 - mu) by a full product (the row-split kernel's z tiles)
-            MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, I.X0, n_dim, D.batch, m->d_inc_ll, &I.zt, &I.nr, m->stream));   // (its ll is not used)
-            MHIP_TRY(mcd::launch_mh_inc_take_z(D, I, m->stream));
+        // ll and z = L^-1 (X - mu) of every chain by full products (the row-split kernel, at most 1024 chains per launch); z to dst
+        // (chain-major) -- or, for a batch of one launch and dst = null, left in that launch's z tiles
+        auto z_product = [&](const double* X, double* ll, double* dst) -> int {
+            for (int64_t c0 = 0; c0 < D.batch; c0 += mcd::kSplitMaxBatch) {
+                const int64_t cnt = std::min<int64_t>(mcd::kSplitMaxBatch, D.batch - c0);
+                MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, X + c0 * n_dim, n_dim, cnt, ll + c0, &I.zt, &I.nr, m->stream));
+                if (dst) MHIP_TRY(mcd::launch_mh_inc_take_z(I, dst, c0, cnt, m->stream));
+            }
             return MCD_OK;
         };
+        auto refresh_z = [&]() -> int { return z_product(I.X0, m->d_inc_ll, I.zcur); };      // (the ll of that product is not used)
         if (inc) {
             I.mode = 0;
             MHIP_TRY(mcd::launch_mh_inc_init(D, *m->tree, I, n_dim, n_dim, m->stream));
@@ -710,8 +719,8 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 if (D.psum != nullptr) summands_kept = true;
                 while (true) {
                     const int pa = schedule[gs];
-                    MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, &I.zt, &I.nr, m->stream));
-                    I.mode = 2;
+                    if (int rc = z_product(X1, D.post1 + D.batch, chunked ? I.zprop : nullptr)) return rc;
+                    I.mode = dense_mode;
                     const bool closes = ((gs + 1) % S) == 0;
                     const bool refresh_now = ((gs + 1) & 255) == 0;
                     const int pn = (gs + 1 < total && inc_mode(schedule[gs + 1]) == 2) ? schedule[gs + 1] : -1;
@@ -725,6 +734,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                         pending.trace_alpha = trace ? m->d_trace_alpha + gs * B : nullptr;
                         pending.trace_accept = trace ? m->d_trace_accept + gs * B : nullptr;
                         pending.X1 = X1;
+                        pending.z_in_zprop = chunked ? 1 : 0;
                         have_pending = true;
                         m->step += 1;
                         if (accumulate && closes) m->n_samples += 1;
@@ -752,8 +762,10 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
             const int pa = schedule[gs];
             if (inc) {
                 I.mode = inc_mode(pa);                       // the step kernel evaluated modes 0 and 1 itself
-                if (I.mode == 2)
-                    MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, X1, n_dim, D.batch, D.post1 + D.batch, &I.zt, &I.nr, m->stream));
+                if (I.mode == 2) {
+                    if (int rc = z_product(X1, D.post1 + D.batch, chunked ? I.zprop : nullptr)) return rc;
+                    I.mode = dense_mode;
+                }
             } else if (m->sp) {
                 double* scr = nullptr;
                 if (int rc = mcd_sparse_scratch_(m->sp_handle, m->stream, D.batch, &scr)) return rc;

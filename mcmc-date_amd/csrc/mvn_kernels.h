@@ -162,13 +162,14 @@ struct MhSegPending {          // a dense proposal that is still to be decided w
     double* trace_alpha;       // [batch] or null
     int8_t* trace_accept;
     const double* X1;          // [batch][n] its distances
+    int z_in_zprop;            // its z' is in MhInc::zprop (batches beyond 1024 chains: taken there chunk by chunk), not in the z tiles
 };
 bool mh_segment_available(const MhDev& M, const MvnDev& V);
 hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
                              int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
                              int64_t gs_base, int summands_kept, const MhSegPending* pending, hipStream_t st);
 hipError_t launch_mh_inc_init(const MhDev& M, const TreeDev& T, const MhInc& I, int n_dim, int64_t ldx, hipStream_t st);   // X0 from the current states
-hipError_t launch_mh_inc_take_z(const MhDev& M, const MhInc& I, hipStream_t st);                                          // zcur <- zt, all chains
+hipError_t launch_mh_inc_take_z(const MhInc& I, double* dst, int64_t b0, int64_t count, hipStream_t st);                 // dst[b0 ..] <- zt of `count` chains
 
 // Workspace of the device leapfrog (k_hmc.hip); all pointers are device memory.
 struct HmcDev {

@@ -263,10 +263,10 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
         assert all(np.allclose(x, y, rtol=1e-13, atol=0) for x, y in zip(g1, g2))      # (sums formed per run, then added: not bitwise)
 
 
-@pytest.mark.parametrize("n_leaves,B", [(200, 40), (513, 64), (513, 5), (300, 33)])
+@pytest.mark.parametrize("n_leaves,B", [(200, 40), (513, 64), (513, 5), (300, 33), (300, 1100), (200, 2100)])
 def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
     """Trees of more than 320 nodes at a sampler's batch (399, 599 and 1025 nodes here; an odd batch leaves a workgroup of the segment
-    kernel with one chain): the workgroup-per-chain step kernel with the likelihood launch only for the proposals that move many
+    kernel with one chain; 1100 chains: beyond one launch of the row-split kernel, its z products are taken chunk by chunk): the workgroup-per-chain step kernel with the likelihood launch only for the proposals that move many
     distances (k_mh_inc.hip; the others: columns of L^-1 on a z kept in global memory, refreshed by a full product every 256 steps)
     and the runs between two dense proposals in one launch each (k_mh_segment.hip; default from 259 nodes), against the same path with the
     full evaluation at every step (MCD_MH_INCREMENTAL=0): 1 500 lock steps, identical accept / reject decisions, states, ln priors
@@ -294,7 +294,8 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
         a2, k2 = smp.run_schedule(sched[:, 700:], accumulate=True, trace=True)       # a second call starts from a fresh full product
         # from 259 nodes: the runs between two dense proposals in one launch each (k_mh_segment.hip) unless switched off
         want = "segments" if (inc == "1" and seg == "1" and topo.n_nodes > 258) else "only for proposals that move many distances" if inc == "1" else "plain-vector likelihood"
-        assert want in smp.last_path(), smp.last_path()
+        if want == "segments" or B <= 1024:                  # (beyond 1024 chains the paths without segments follow the likelihood launch's form)
+            assert want in smp.last_path(), smp.last_path()
         runs.append((np.concatenate([a, a2]), np.concatenate([k, k2]), smp.state(), smp.posterior(), smp.tuning(), smp.age_sums()[:2]))
     (a2, k2, s2, p2, t2, g2) = runs[-1]
     for (a1, k1, s1, p1, t1, g1) in runs[:-1]:
