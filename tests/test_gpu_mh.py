@@ -289,6 +289,8 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
         lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
         smp = M.Sampler(lik, M.PriorFunction(1.0, "UncorrelatedGamma", cal, [], [], topo), ps, B, seed=13)
         smp.set_state(s0)
+        if B == 33:                                          # heated chains (MC3): posterior^beta in every path's acceptance ratio
+            smp.set_temperatures(np.linspace(1.0, 0.55, B))
         tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
         a, k = smp.run_schedule(sched[:, :700], accumulate=True, trace=True)
         a2, k2 = smp.run_schedule(sched[:, 700:], accumulate=True, trace=True)       # a second call starts from a fresh full product
