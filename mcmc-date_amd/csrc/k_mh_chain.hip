@@ -19,14 +19,29 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mh_device.hpp"
 #include "prior_device.hpp"
 
 namespace mcd {
 
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDev T, PriorDev P, const double* __restrict__ Fp,
+// LW (batches below 1024 chains: SIMDs to spare): a second wave per chain evaluates the ln likelihood of the proposed state --
+// distances, forward solve, dot: the same instructions on the same numbers -- while the chain's wave evaluates the ln prior: both depend
+// on the proposal only.  The two talk through four LDS words (request, reply, |z|^2, the root slot's distance); the second wave keeps
+// no state.  The same bits as the one-wave kernel (tests/test_gpu_mh.py::test_chain_kernel_with_a_likelihood_wave).
+struct MhcWords {
+    int req;                       // chain wave: count of likelihood requests so far (-1: the schedule is over)
+    int resp;                      // likelihood wave: the request it has answered
+    double s1;                     // chain wave: tH * rMu of the proposal
+    double q;                      // likelihood wave: |z|^2
+    double d0;                     // ... and the distance of slot 0 (ln jacobianRootBranch = ln (1 / d0))
+    double pad[4];
+};
+static_assert(sizeof(MhcWords) == 64, "eight doubles of LDS");
+
+template <int WPB, bool LW>
+__global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, MvnDev V, TreeDev T, PriorDev P, const double* __restrict__ Fp,
                                                        const int32_t* __restrict__ sched, int64_t n_steps, int32_t S,
                                                        int accumulate, uint64_t step0, uint64_t seed,
                                                        double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept)
@@ -36,12 +51,19 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* Fs = lds;                                   // [n][64]: Fs[j * 64 + i] = L_ij / L_ii (i > j), 0 otherwise
-    for (int i = threadIdx.x; i < n * 64; i += 64 * WPB) Fs[i] = Fp[i];
-    __syncthreads();                                    // the only workgroup barrier; waves are independent afterwards
-    const int64_t b = (int64_t)blockIdx.x * WPB + wave;
-    if (b >= M.batch) return;
+    static_assert(!LW || WPB == 1, "the likelihood wave comes with one chain per workgroup");
+    for (int i = threadIdx.x; i < n * 64; i += (int)blockDim.x) Fs[i] = Fp[i];
     const size_t per_wave = 4 * 64 + (size_t)NP + (size_t)NP;          // doubles: Hc Rc Hp Rp | tune | (acc, tried) as int32 pairs
-    double* Hc = lds + (size_t)n * 64 + (size_t)wave * per_wave;
+    MhcWords* words = reinterpret_cast<MhcWords*>(lds + (size_t)n * 64 + (size_t)WPB * per_wave);
+    if (LW && threadIdx.x == 0) {
+        words->req = 0;
+        words->resp = 0;
+    }
+    __syncthreads();                                    // the only workgroup barrier; waves are independent afterwards
+    const int cw = LW ? 0 : wave;                       // the chain's index in the workgroup
+    const int64_t b = (int64_t)blockIdx.x * WPB + cw;
+    if (b >= M.batch) return;
+    double* Hc = lds + (size_t)n * 64 + (size_t)cw * per_wave;
     double* Rc = Hc + 64;
     double* Hp = Rc + 64;
     double* Rp = Hp + 64;
@@ -49,6 +71,61 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
     int32_t* acc = reinterpret_cast<int32_t*>(tune + NP);
     int32_t* tried = acc + NP;
     const int64_t B = M.batch;
+    // row `lane` of the solve: mean, 1 / L_ii, the node whose branch feeds this distance slot and that node's parent
+    const double mu_l = V.mu[lane], iv_l = V.invdiag[lane];
+    const int slot = T.slot_node[lane];
+    const int slot_par = (slot >= 0) ? T.parent[slot] : 0;
+    const int rr = T.root_right;
+    // ln likelihood of the state in (Hx, Rx) with tH * rMu = s_: |z|^2 and the root slot's distance
+    // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207)
+    auto solve = [&](const double* Hx, const double* Rx, double s_, double& dist0) -> double {
+        double dist = 0.0;
+        if (slot >= 0) {
+            dist = (Hx[slot_par] - Hx[slot]) * Rx[slot];
+            if (lane == 0) dist = dist + (Hx[0] - Hx[rr]) * Rx[rr];
+            dist = dist * s_;
+        }
+        dist0 = mh_readlane64(dist, 0);
+        double d = (dist - mu_l) * iv_l;
+        // column sweep of L z = x - mu, row-scaled.  Eight columns per round: their LDS reads are issued together,
+        // then the dependent readlane -> fma chain runs; columns beyond n multiply a zero (z_j = 0 there: exact)
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            double f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[u] = (j0 + u < n) ? Fs[(j0 + u) * 64 + lane] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double zj = mh_readlane64(d, j0 + u);
+                d = fma(-f[u], zj, d);
+            }
+        }
+        return pr_wave_sum(fma(d, d, 0.0));
+    };
+    if (LW && wave == 1) {
+        // ---- the likelihood wave
+        volatile int* w_req = &words->req;
+        int last = 0;
+        while (true) {
+            int v = *w_req;
+            while (v == last) {
+                __builtin_amdgcn_s_sleep(1);
+                v = *w_req;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (v < 0) break;
+            double d0;
+            const double q = solve(Hp, Rp, words->s1, d0);
+            if (lane == 0) {
+                words->q = q;
+                words->d0 = d0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            *(volatile int*)&words->resp = v;
+            last = v;
+        }
+        return;
+    }
+    int n_req = 0;                                      // likelihood requests so far (LW)
     Hc[lane] = (lane < nn) ? M.H[b * M.ld + lane] : 0.0;
     Rc[lane] = (lane < nn) ? M.R[b * M.ld + lane] : 0.0;
     Hp[lane] = 0.0;                                     // lanes beyond the tree stay equal in both copies
@@ -69,11 +146,6 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};                    // variance-only pieces of the clock block, current state
     double c2 = prior_clock_wave(P, lane, sc[3], sc[4], Hc, Rc, &cc);
     double lp = c0 + c1 + c2;
-    // row `lane` of the solve: mean, 1 / L_ii, the node whose branch feeds this distance slot and that node's parent
-    const double mu_l = V.mu[lane], iv_l = V.invdiag[lane];
-    const int slot = T.slot_node[lane];
-    const int slot_par = (slot >= 0) ? T.parent[slot] : 0;
-    const int rr = T.root_right;
     double age_s = 0.0, age_q = 0.0;
     const double beta = M.beta[b];
 #ifdef MCD_MH_STAMP
@@ -117,6 +189,13 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
         MH_TICK(1)
         const bool dH = __builtin_amdgcn_ballot_w64(Hp[lane] != Hc[lane]) != 0;     // NaN != NaN: re-evaluated
         const bool dR = __builtin_amdgcn_ballot_w64(Rp[lane] != Rc[lane]) != 0;
+        const bool moves = dH || dR || sc1[2] != sc[2] || sc1[3] != sc[3];         // birth, death and rVar do not enter the likelihood
+        if (LW && moves) {                                                 // the likelihood wave starts on the proposed state now
+            n_req += 1;
+            if (lane == 0) words->s1 = sc1[2] * sc1[3];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            *(volatile int*)&words->req = n_req;
+        }
         ClockCache ccp = cc;                                               // refreshed only if the proposal moved rVar
         const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(P, lane, sc1[2], Hp) : c0;
         const double c1p = (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) ? prior_bd_wave(P, lane, sc1[0], sc1[1], Hp) : c1;
@@ -124,30 +203,19 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
                                ? prior_clock_wave(P, lane, sc1[3], sc1[4], Hp, Rp, &ccp) : c2;
         const double lp1 = c0p + c1p + c2p;
         MH_TICK(2)
-        // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)      (app/Probability.hs:195-207)
         double ll1 = ll, lj1 = lj;
-        if (dH || dR || sc1[2] != sc[2] || sc1[3] != sc[3]) {              // birth, death and rVar do not enter the likelihood
-            double dist = 0.0;
-            if (slot >= 0) {
-                dist = (Hp[slot_par] - Hp[slot]) * Rp[slot];
-                if (lane == 0) dist = dist + (Hp[0] - Hp[rr]) * Rp[rr];
-                dist = dist * (sc1[2] * sc1[3]);
+        if (moves) {
+            double q, dist0;
+            if (LW) {
+                volatile int* w_resp = &words->resp;
+                while (*w_resp != n_req) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                q = words->q;
+                dist0 = words->d0;
+            } else {
+                q = solve(Hp, Rp, sc1[2] * sc1[3], dist0);
             }
-            lj1 = log(1.0 / mh_readlane64(dist, 0));                       // jacobianRootBranch, :393-410
-            double d = (dist - mu_l) * iv_l;
-            // column sweep of L z = x - mu, row-scaled.  Eight columns per round: their LDS reads are issued together,
-            // then the dependent readlane -> fma chain runs; columns beyond n multiply a zero (z_j = 0 there: exact)
-            for (int j0 = 0; j0 < n; j0 += 8) {
-                double f[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) f[u] = (j0 + u < n) ? Fs[(j0 + u) * 64 + lane] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double zj = mh_readlane64(d, j0 + u);
-                    d = fma(-f[u], zj, d);
-                }
-            }
-            const double q = pr_wave_sum(fma(d, d, 0.0));
+            lj1 = log(1.0 / dist0);                                        // jacobianRootBranch, :393-410
             ll1 = V.c + (-0.5) * (V.logdet + q);                           // :169
         }
         MH_TICK(3)
@@ -183,6 +251,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
         row = row_next;
         MH_TICK(4)
     }
+    if (LW) {                                           // the schedule is over
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        *(volatile int*)&words->req = -1;
+    }
 #ifdef MCD_MH_STAMP
     if (trace_alpha && lane == 0)
         for (int i = 0; i < 5; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];   // cycles: loop head, propose, prior, likelihood, accept
@@ -215,7 +287,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mh_chain(MhDev M, MvnDev V, TreeDe
 
 size_t mh_chain_lds_bytes(int n, int n_prop, int wpb)
 {
-    return sizeof(double) * ((size_t)n * 64 + (size_t)wpb * (4 * 64 + 2 * (size_t)n_prop));
+    return sizeof(double) * ((size_t)n * 64 + (size_t)wpb * (4 * 64 + 2 * (size_t)n_prop) + 8);       // (+ the hand-over words of the two-wave form)
 }
 
 hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const double* Fp,
@@ -226,13 +298,18 @@ hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, co
     if (M.batch >= 1024) {
         constexpr int WPB = 4;
         const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB);
-        hipLaunchKernelGGL(k_mh_chain<WPB>, dim3((unsigned)((M.batch + WPB - 1) / WPB)), dim3(64 * WPB), sh, st, M, V, T, P, Fp, sched,
+        hipLaunchKernelGGL((k_mh_chain<WPB, false>), dim3((unsigned)((M.batch + WPB - 1) / WPB)), dim3(64 * WPB), sh, st, M, V, T, P, Fp, sched,
                            n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept);
     } else {
         constexpr int WPB = 1;
         const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB);
-        hipLaunchKernelGGL(k_mh_chain<WPB>, dim3((unsigned)M.batch), dim3(64), sh, st, M, V, T, P, Fp, sched, n_steps, S, accumulate,
-                           step0, seed, trace_alpha, trace_accept);
+        const char* env = getenv("MCD_MH_CHAIN_LW");      // 0: one wave per chain (tests, timing; read per call)
+        if (env && env[0] == '0')
+            hipLaunchKernelGGL((k_mh_chain<WPB, false>), dim3((unsigned)M.batch), dim3(64), sh, st, M, V, T, P, Fp, sched, n_steps, S, accumulate,
+                               step0, seed, trace_alpha, trace_accept);
+        else
+            hipLaunchKernelGGL((k_mh_chain<WPB, true>), dim3((unsigned)M.batch), dim3(128), sh, st, M, V, T, P, Fp, sched, n_steps, S, accumulate,
+                               step0, seed, trace_alpha, trace_accept);
     }
     return hipGetLastError();
 }

@@ -122,6 +122,27 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(fused.age_sums()[:2], phased.age_sums()[:2]))
 
 
+@pytest.mark.parametrize("dataset", ["12-leaves-variable-rate", "25-leaves-bastien"])
+def test_chain_kernel_with_a_likelihood_wave(gpu, golden, dataset, monkeypatch):
+    """Trees of at most 64 nodes, fewer than 1024 chains: a second wave per chain evaluates the ln likelihood of the proposed state while
+    the chain's wave evaluates the ln prior (k_mh_chain.hip, LW).  The same instructions on the same numbers as the one-wave kernel
+    (MCD_MH_CHAIN_LW=0): bit-identical traces, states, posteriors, counters and age sums -- with calibrations, constraints, braces."""
+    fx = golden[dataset]
+    runs = []
+    for lw in ("1", "0"):
+        monkeypatch.setenv("MCD_MH_CHAIN_LW", lw)
+        topo, ps, smp, _ = setup(fx, B=37, seed=5)
+        sched = M.cycle_schedule(ps, 3, np.random.default_rng(8))
+        a, k = smp.run_schedule(sched, accumulate=True, trace=True)
+        assert smp.last_path().startswith("whole schedule in one launch, factor resident in LDS")
+        runs.append((a, k, smp.state(), smp.posterior(), smp.tuning(), smp.age_sums()[:2]))
+    (a1, k1, s1, p1, t1, g1), (a2, k2, s2, p2, t2, g2) = runs
+    assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
+    for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
+        assert np.array_equal(getattr(s1, f), getattr(s2, f)), f
+    assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(t1, t2)) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
+
+
 @pytest.mark.parametrize("n_leaves,B", [(12, 10), (70, 6), (129, 512), (129, 700), (200, 40), (513, 96)])
 def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, monkeypatch):
     """Two-launch path: by default the likelihood launch carries the ln prior of the proposed states as workgroups of a second
