@@ -602,7 +602,7 @@ static size_t mhb_lds_bytes(int n_nodes, int n_prop)
 // workgroups (one workgroup per CU: 512 chains per round), state + tables + the 64 KiB ring within a CU's LDS
 bool mh_chain_big_available(const MhDev& M, const MvnDev& V)
 {
-    if (V.R < 2 || V.R > 8 || M.n_nodes > 64 * V.R + 2 || M.batch > 1024) return false;   // (1024 chains: two rounds of workgroups, still ahead of two launches per step)
+    if (V.R < 1 || V.R > 8 || M.n_nodes > 64 * V.R + 2 || M.batch > 1024) return false;   // (1024 chains: two rounds of workgroups, still ahead of two launches per step)
     return mhb_lds_bytes(M.n_nodes, M.n_prop) + 64 * 1024 <= 160 * 1024;
 }
 
@@ -635,6 +635,7 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
         MvnDev V0 = V;
         V0.Wc = nullptr;
         switch (V.R) {
+        case 1: return launch_big_R<1>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         case 2: return launch_big_R<2>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         case 3: return launch_big_R<3>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         case 4: return launch_big_R<4>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
@@ -644,6 +645,7 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
         }
     }
     switch (V.R) {
+    case 1: return launch_big_R<1>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);       // (65 and 66 nodes: one more than the small-tree kernel holds)
     case 2: return launch_big_R<2>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     case 3: return launch_big_R<3>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     case 4: return launch_big_R<4>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);

@@ -285,7 +285,7 @@ int mcd_mvn_create(mcd_mvn_t** out, int n, const double* mu, const double* mat, 
         HIP_TRY(hipMemcpy(h->d_Wtb, Wtb.data(), Wtb.size() * sizeof(double), hipMemcpyHostToDevice));
         h->dev.Wt = h->d_Wt;
         h->dev.Wtb = h->d_Wtb;
-        if (h->R >= 2) {                     // columns of W for the incremental evaluation of sparse Metropolis-Hastings proposals
+        if (h->R >= 1) {                     // columns of W for the incremental evaluation of sparse Metropolis-Hastings proposals
                                              // (k_mh_chain_big.hip at R <= 4, k_mh_inc.hip above)
             std::vector<double> Wc((size_t)n * NP, 0.0);
             for (int j = 0; j < n; ++j)

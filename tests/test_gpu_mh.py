@@ -107,12 +107,14 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
     launches per step (k_mh.hip + k_tree_logpdf.hip).  Same arithmetic in the same order: bit-identical chains."""
     fx = golden["25-leaves-bastien"]
     topo, ps, fused, _ = setup(fx, B=12, seed=5)
-    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
-    _, _, phased, _ = setup(fx, B=12, seed=5)
-    monkeypatch.delenv("MCD_MH_PER_PHASE")
     sched = M.cycle_schedule(ps, 3, np.random.default_rng(8))
     a1, k1 = fused.run_schedule(sched, accumulate=True, trace=True)
+    assert fused.last_path().startswith("whole schedule in one launch, factor resident in LDS")
+    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")             # (read when the handle is made and at every run)
+    _, _, phased, _ = setup(fx, B=12, seed=5)
     a2, k2 = phased.run_schedule(sched, accumulate=True, trace=True)
+    assert phased.last_path().startswith("two launches per lock step")
+    monkeypatch.delenv("MCD_MH_PER_PHASE")
     assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2)
     s1, s2 = fused.state(), phased.state()
     for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
@@ -221,7 +223,7 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
         assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
-@pytest.mark.parametrize("n_leaves,B", [(40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777), (150, 64), (193, 33), (257, 512)])
+@pytest.mark.parametrize("n_leaves,B", [(33, 9), (40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777), (150, 64), (193, 33), (257, 512)])
 @pytest.mark.parametrize("incremental", ["1", "0"])
 def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, incremental, monkeypatch):
     """Trees of 65 .. 514 nodes at up to 1024 chains (777: two rounds of workgroups) run the whole schedule in one launch, two
