@@ -55,6 +55,30 @@ __host__ __device__ inline size_t mhb_chain_doubles(int n_nodes, int /*n_prop*/)
 __host__ __device__ inline size_t mhb_table_doubles(int n_nodes) { return (5 * (size_t)n_nodes + 1) / 2 + 1; }
 
 constexpr int kMhbRefresh = 256;   // steps between two recomputations of z by a full sweep of the current state (a power of two)
+
+// R <= 4 (up to 258 nodes): on the steps whose proposal is sparse the loader waves have nothing to stream, and the chain wave spent a
+// quarter of such a step on the likelihood's side (all distances, which of them moved, their columns, z').  There the loader wave of a
+// chain acts as its LIKELIHOOD wave, as in k_mh_segment.hip: it derives the moved distance slots from the nodes the proposal writes,
+// forms z' = z + sum_j delta_j W[:, j] and hands |z'|^2 back while the chain wave evaluates the ln prior.  The current distances and z
+// live in LDS (both waves need them: dense proposals and the refreshes are still swept by the chain wave); a few LDS words carry the
+// hand-over (request, reply, decision, and `done`: the likelihood wave has committed, the chain wave may touch distances and z).
+template <int R> struct MhbHelp { static constexpr bool on = (R <= 4); };
+constexpr int kMhbList = 64;       // moved distances of one sparse proposal at most (mh_capi.cpp: kMhSparseSlots <= this)
+struct MhbWords {
+    int req, resp, dec, done;      // step + 1 | step + 1 | 2 (step + 1) + accepted | step + 1
+    int cnt, have0;                // moved distances (-1: more than the list holds); slot 0 among them
+    double q, lj, s1;              // |z'|^2; ln jacobianRootBranch of the proposal (have0); tH * rMu of the proposal
+    double pad[2];
+};
+static_assert(sizeof(MhbWords) == 64, "eight doubles of LDS");
+constexpr int kMhbApplyDoubles = (int)((sizeof(PropApply) + 7) / 8);
+// LDS of the likelihood-wave form, in doubles: per chain the current distances and z [np], the list (new distance, delta, slot),
+// the slots' marks, the words, the proposal's transform; shared: slot -> node, slot -> parent, node -> slot (int16)
+__host__ __device__ inline size_t mhb_help_chain_doubles(int np)
+{
+    return 2 * (size_t)np + 2 * (size_t)kMhbList + (size_t)kMhbList / 2 + (size_t)np / 2 + 8 + (size_t)kMhbApplyDoubles;
+}
+__host__ __device__ inline size_t mhb_help_table_doubles(int n_nodes, int np) { return ((size_t)n_nodes + 2 * (size_t)np + 3) / 4 + 1; }
 // One pass of the loader waves over the factor, as a function of its own: inside the kernel its staging registers were allocated
 // together with the chain role's code and spilled from R = 6 up (76 / 674 registers at R = 6 / 8); a call costs a few hundred cycles
 // per pass of some 14 000.
@@ -102,6 +126,36 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     const int nn = M.n_nodes, NP = M.n_prop;
     const int ncols = V.ncols;
     MCD_ACC_DECL
+    constexpr bool HLP = MhbHelp<R>::on;
+    constexpr int NPadC = 64 * R;
+    // (HLP) the likelihood-wave form's LDS, behind the tables and the two chains' arrays
+    const int cs_ = (wave >= CW) ? wave - CW : wave;         // the chain of the workgroup this wave works for
+    int16_t* ts_node = reinterpret_cast<int16_t*>(dyn + mhb_table_doubles(nn) + 2 * mhb_chain_doubles(nn, NP));
+    int16_t* ts_parent = ts_node + NPadC;
+    int16_t* ts_of = ts_parent + NPadC;
+    double* hc0 = dyn + mhb_table_doubles(nn) + 2 * mhb_chain_doubles(nn, NP) + mhb_help_table_doubles(nn, NPadC) + (size_t)cs_ * mhb_help_chain_doubles(NPadC);
+    double* dcur_l = hc0;                                    // [NPad] distances of the current state
+    double* z_l = dcur_l + NPadC;                            // [NPad] z = L^-1 (d - mu) of the current state
+    double* l_dnew = z_l + NPadC;
+    double* l_delta = l_dnew + kMhbList;
+    int32_t* l_j = reinterpret_cast<int32_t*>(l_delta + kMhbList);
+    int32_t* mark = l_j + kMhbList;
+    MhbWords* words = reinterpret_cast<MhbWords*>(reinterpret_cast<double*>(mark + NPadC));
+    PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(words) + 8);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    auto poll = [&](const volatile int* w, int want, int shift) -> int {
+        int v = *w;
+        while ((v >> shift) != want) {
+            __builtin_amdgcn_s_sleep(1);
+            v = *w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return v;
+    };
+    auto post = [&](volatile int* w, int value) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        *w = value;
+    };
 
     // ---- loader waves: one pass over the factor per step that needs the likelihood
     if (wave >= CW) {
@@ -110,6 +164,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         int kind = M.kind[p], node = M.node[p];
         const bool inc = V.Wc != nullptr;
         int sp = inc ? M.sparse[p] : 0;
+        // (HLP) this wave's chain: its proposed state, and the tables the chain waves put in LDS before their first barrier
+        const int32_t* tb_first_ = reinterpret_cast<const int32_t*>(dyn) + 2 * nn;
+        const int32_t* tb_nch_ = tb_first_ + nn;
+        const int32_t* tb_second_ = tb_nch_ + nn;
+        const double* Hp_ = dyn + mhb_table_doubles(nn) + (size_t)lw * mhb_chain_doubles(nn, NP) + 2 * (size_t)nn;
+        const double* Rp_ = Hp_ + nn;
+        const int rr_ = T.root_right;
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
@@ -118,6 +179,107 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             // (one call site: the stream is a long unrolled body)
             const int passes = ((inc && (gs & (kMhbRefresh - 1)) == 0) ? 1 : 0) + ((mhb_moves_likelihood(kind, node) && !sp) ? 1 : 0);
             for (int r = 0; r < passes; ++r) mhb_stream_pass<R, LW>(V.Ft, ring, lw, lane, ncols);
+            if constexpr (HLP) {
+                if (inc && sp && mhb_moves_likelihood(kind, node)) {
+                    // ---- the likelihood wave of a sparse step (k_mh_segment.hip has the same: the slots the written nodes feed, each once)
+                    const int tag = (int)gs + 1;
+                    (void)poll(&words->req, tag, 0);
+                    const PropApply A = *A_lds;
+                    const double s1 = words->s1;
+                    int cnt = 0;
+                    double d0 = 0.0;
+                    bool have0 = false;
+                    auto emit = [&](bool active, int node_) {
+                        if (__builtin_amdgcn_ballot_w64(active) == 0) return;
+                        const int slot = active ? (int)ts_of[node_] : -1;
+                        bool mine = false;
+                        if (slot >= 0) mine = atomicExch(&mark[slot], tag) != tag;
+                        const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
+                        if (mine) {
+                            const int pos = cnt + (int)__builtin_popcountll(mk & lt_mask);
+                            const int a = ts_node[slot], pa = ts_parent[slot];
+                            double x = (Hp_[pa] - Hp_[a]) * Rp_[a];                      // the arithmetic of `distances` below
+                            if (slot == 0) x = x + (Hp_[0] - Hp_[rr_]) * Rp_[rr_];
+                            x = x * s1;
+                            if (pos < kMhbList) {
+                                l_j[pos] = slot;
+                                l_dnew[pos] = x;
+                                l_delta[pos] = x - dcur_l[slot];
+                            }
+                            if (slot == 0) {
+                                d0 = x;
+                                have0 = true;
+                            }
+                        }
+                        cnt += (int)__builtin_popcountll(mk);
+                    };
+                    auto emit_height = [&](bool active, int w) {
+                        emit(active, w);
+                        const int nc = active ? tb_nch_[w] : 0;
+                        emit(nc > 0, active ? tb_first_[w] : 0);
+                        emit(nc > 1, active ? tb_second_[w] : 0);
+                    };
+                    for (int w0 = A.hlo; w0 < A.hhi; w0 += 64) emit_height(w0 + lane < A.hhi, w0 + lane);
+                    for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
+                    for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
+                    {
+                        const int g = lane / 3, r = lane - 3 * g;
+                        int cand = -1;
+                        if (lane < 6) {
+                            const int base = (g == 0) ? A.pt1 : A.pt2;
+                            if (base >= 0) cand = (r == 0) ? base : (tb_nch_[base] >= r) ? (r == 1 ? tb_first_[base] : tb_second_[base]) : -1;
+                        } else if (lane < 9) {
+                            cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
+                        }
+                        emit(cand >= 0, cand >= 0 ? cand : 0);
+                    }
+                    for (int i = A.brace_lo; i < A.brace_hi; ++i) emit_height(lane == 0, M.brace_nodes[i]);
+                    const uint64_t m0 = __builtin_amdgcn_ballot_w64(have0);
+                    if (lane == 0) words->have0 = (m0 != 0) ? 1 : 0;
+                    if (m0 != 0) {
+                        const double lj1 = log(1.0 / readlane64(d0, (int)__builtin_ctzll(m0)));      // jacobianRootBranch, :393-410
+                        if (lane == 0) words->lj = lj1;
+                    }
+                    if (cnt > kMhbList) cnt = -1;
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    double zp[R];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) zp[k] = z_l[64 * k + lane];
+                    for (int m0_ = 0; m0_ < cnt; m0_ += 4) {     // four columns in flight
+                        double col[4][R], dl[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int m = (m0_ + u < cnt) ? m0_ + u : cnt - 1;
+                            const int j = __builtin_amdgcn_readfirstlane(l_j[m]);
+                            dl[u] = (m0_ + u < cnt) ? l_delta[m] : 0.0;
+                            const double* wc = V.Wc + (size_t)j * NPadC + lane;
+#pragma unroll
+                            for (int k = 0; k < R; ++k) col[u][k] = wc[64 * k];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int k = 0; k < R; ++k) zp[k] = fma(dl[u], col[u][k], zp[k]);
+                    }
+                    double sq = 0.0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) sq = fma(zp[k], zp[k], sq);
+                    const double q = wave_sum(sq);
+                    if (lane == 0) {
+                        words->q = q;
+                        words->cnt = cnt;
+                    }
+                    post(&words->resp, tag);
+                    const int d = poll(&words->dec, tag, 1);
+                    if ((d & 1) && cnt > 0) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) z_l[64 * k + lane] = zp[k];
+                        for (int m = lane; m < cnt; m += 64) dcur_l[l_j[m]] = l_dnew[m];
+                    }
+                    post(&words->done, tag);                     // (the chain wave may sweep from / write to distances and z again)
+                }
+            }
             kind = kind_next;
             node = node_next;
             sp = sp_next;
@@ -165,6 +327,29 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     double* tcl_prop = tcl_cur + nn;
     int32_t* stamp_bd = reinterpret_cast<int32_t*>(tcl_prop + nn);
     int32_t* stamp_cl = stamp_bd + nn;
+    if constexpr (HLP) {
+        // (the likelihood waves use these after the first ring barrier -- a launch with columns of L^-1 begins with a sweep of the
+        // current state -- and both chain waves write the same shared values)
+        for (int v = lane; v < nn; v += 64) ts_of[v] = -1;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < NPadC; j += 64) {
+            const int a = T.slot_node[j];
+            ts_node[j] = (int16_t)a;
+            ts_parent[j] = (int16_t)T.slot_parent[j];
+            if (a >= 0) ts_of[a] = (int16_t)j;
+            mark[j] = 0;
+        }
+        if (lane == 0) {
+            ts_of[T.root_right] = 0;                         // the root's two daughters share slot 0 (sumFirstTwo)
+            words->req = 0;
+            words->resp = 0;
+            words->dec = 0;
+            words->done = 0;
+            words->cnt = 0;
+            words->have0 = 0;
+        }
+    }
     for (int w = lane; w < nn; w += 64) {
         stamp_bd[w] = 0;
         stamp_cl[w] = 0;
@@ -257,10 +442,24 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     };
     const bool inc = V.Wc != nullptr;                        // incremental evaluation of sparse proposals available
     const int NPad = 64 * R;
-    double dcur[R], zc[R];                                   // distances and z = L^-1 (d - mu) of the CURRENT state
-    (void)distances(Hc, Rc, sc[2] * sc[3], dcur);
+    double dcur[HLP ? 1 : R], zc[HLP ? 1 : R];               // distances and z = L^-1 (d - mu) of the CURRENT state (HLP: in LDS)
+    if constexpr (HLP) {
+        double d0_[R];
+        (void)distances(Hc, Rc, sc[2] * sc[3], d0_);
 #pragma unroll
-    for (int k = 0; k < R; ++k) zc[k] = 0.0;
+        for (int k = 0; k < R; ++k) {
+            dcur_l[64 * k + lane] = d0_[k];
+            z_l[64 * k + lane] = 0.0;
+        }
+    } else {
+        (void)distances(Hc, Rc, sc[2] * sc[3], dcur);
+#pragma unroll
+        for (int k = 0; k < R; ++k) zc[k] = 0.0;
+    }
+    int last_sparse = 0;                                     // (HLP) the last step + 1 the likelihood wave was asked about
+    auto wait_done = [&]() {                                 // ... it has committed that step: distances and z are the chain wave's to touch
+        if constexpr (HLP) (void)poll(&words->done, last_sparse, 0);
+    };
     const double beta = M.beta[b];
 #ifdef MCD_MHB_STAMP
     // diagnostic build (make stamp_mhbig): s_memtime ticks per phase, summed over the run, in the first rows of trace_alpha
@@ -332,16 +531,20 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         // distances of the proposed state; for a sparse row: which of them moved, and the first columns of L^-1 on their way
         const bool moves = mhb_moves_likelihood(row.kind, row.node);      // (a function of the row alone: the loaders decide alike)
         const bool sparse_step = moves && row_sparse != 0;
-        double vp[R], dl[R];
+        const int tag = (int)gs + 1;
+        double vp[R], dl[HLP ? 1 : R];
         double lj1 = lj;
-        uint64_t mk[R];
+        uint64_t mk[HLP ? 1 : R];
         int cj[MhbCols<R>::N];
-        double cd[MhbCols<R>::N], col[MhbCols<R>::N][R];
+        double cd[MhbCols<R>::N], col[HLP ? 1 : MhbCols<R>::N][HLP ? 1 : R];
         int ccnt = 0;
+        if constexpr (!HLP) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) mk[k] = 0;
+            for (int k = 0; k < R; ++k) mk[k] = 0;
+        }
         auto fetch_cols = [&]() {                             // up to MhbCols<R>::N moved distances, in row order: their columns requested
             ccnt = 0;
+            if constexpr (!HLP) {
 #pragma unroll
             for (int c = 0; c < MhbCols<R>::N; ++c) {
                 int j = (c > 0) ? cj[c - 1] : 0;
@@ -365,11 +568,27 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 #pragma unroll
                 for (int k = 0; k < R; ++k) col[c][k] = wc[64 * k];
             }
+            }
         };
-        if (moves) {
+        // (HLP) a sparse step: the likelihood wave takes it from here -- the transform (which nodes are written), Hp / Rp, tH * rMu.
+        // On a step that begins with a recomputation of z (every 256 steps) the request waits until that sweep has written z: the
+        // likelihood wave, which streams for the sweep first, must not read the old one (and the sweep waits for its last commit).
+        const bool refresh_first = inc && (gs & (kMhbRefresh - 1)) == 0;
+        auto request = [&]() {
+            if (lane == 0) {
+                *A_lds = A;
+                words->s1 = sc1[2] * sc1[3];
+            }
+            post(&words->req, tag);
+            last_sparse = tag;
+        };
+        if (HLP && sparse_step) {
+            if (!refresh_first) request();
+        } else if (moves) {
             const double dist0 = distances(Hp, Rp, sc1[2] * sc1[3], vp);
             lj1 = log(1.0 / readlane64(dist0, 0));          // jacobianRootBranch, :393-410
             MHB_TICK(9)
+            if constexpr (!HLP) {
             if (sparse_step) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -377,6 +596,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                     mk[k] = __builtin_amdgcn_ballot_w64(vp[k] != dcur[k]);   // NaN != x: counted, and the NaN then reaches q
                 }
                 fetch_cols();
+            }
             }
         }
         MHB_TICK(3)
@@ -467,23 +687,46 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             const bool rf = pass == 0 && refresh_now;
             if (!rf && !(pass == 1 && dense_step)) continue;
             double vin[R], zout[R];
+            if constexpr (HLP) {
+                if (rf) wait_done();                          // (the likelihood wave's last commit is in LDS)
 #pragma unroll
-            for (int k = 0; k < R; ++k) vin[k] = rf ? dcur[k] : vp[k];
+                for (int k = 0; k < R; ++k) vin[k] = rf ? dcur_l[64 * k + lane] : vp[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) vin[k] = rf ? dcur[k] : vp[k];
+            }
             const double q = sweep(vin, zout);
             if (rf) {
+                if constexpr (HLP) {
 #pragma unroll
-                for (int k = 0; k < R; ++k) zc[k] = zout[k];
+                    for (int k = 0; k < R; ++k) z_l[64 * k + lane] = zout[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) zc[k] = zout[k];
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) zp[k] = zout[k];
                 ll1 = V.c + (-0.5) * (V.logdet + q);         // :169 (finish_ll)
             }
         }
+        if constexpr (!HLP) {
         if (!dense_step) {
 #pragma unroll
             for (int k = 0; k < R; ++k) zp[k] = zc[k];
         }
-        if (sparse_step) {
+        }
+        if (HLP && sparse_step) {
+            // the likelihood wave's answer
+            if (refresh_first) request();
+            (void)poll(&words->resp, tag, 0);
+            const double q = words->q;
+            const int cnt = words->cnt;
+            if (words->have0) lj1 = words->lj;
+            if (cnt < 0) ll = __builtin_nan("");             // (more moved distances than the list holds: cannot happen for a row marked
+                                                             // sparse; if it does the chain says so -- its ln likelihood is NaN from here on)
+            ll1 = (cnt < 0) ? __builtin_nan("") : V.c + (-0.5) * (V.logdet + q);     // :169 (finish_ll)
+        } else if (sparse_step) {
             // z' = z + sum_j delta_j W[:, j] over the moved distances, in row order; q' = |z'|^2
             while (true) {
 #pragma unroll
@@ -506,6 +749,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
         if (row.jac_root) la += (double)row.jac_root * (lj1 - lj);
         const bool ok = (la >= 0) || (dr.Uacc < exp(la));
+        if (HLP && sparse_step) post(&words->dec, 2 * tag + (ok ? 1 : 0));
         if (ok) {
             for_write_set(A, [&](int w) {
                 Hc[w] = Hp[w];
@@ -532,7 +776,16 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             lp = lp1;
             ll = ll1;
             lj = lj1;
-            if (moves) {
+            if constexpr (HLP) {
+                if (dense_step) {                             // (a sparse proposal's distances and z': the likelihood wave's to commit)
+                    wait_done();
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        z_l[64 * k + lane] = zp[k];
+                        dcur_l[64 * k + lane] = vp[k];
+                    }
+                }
+            } else if (moves) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     zc[k] = zp[k];
@@ -593,9 +846,11 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     }
 }
 
-static size_t mhb_lds_bytes(int n_nodes, int n_prop)
+static size_t mhb_lds_bytes(int n_nodes, int n_prop, int R)
 {
-    return sizeof(double) * (mhb_table_doubles(n_nodes) + 2 * mhb_chain_doubles(n_nodes, n_prop));
+    size_t d = mhb_table_doubles(n_nodes) + 2 * mhb_chain_doubles(n_nodes, n_prop);
+    if (R <= 4) d += mhb_help_table_doubles(n_nodes, 64 * R) + 2 * mhb_help_chain_doubles(64 * R);      // (MhbHelp<R>::on)
+    return sizeof(double) * d;
 }
 
 // trees of 65 .. 514 nodes whose factor the sweep holds in 2 .. 8 register blocks (N <= 512), a batch of at most two rounds of
@@ -603,14 +858,14 @@ static size_t mhb_lds_bytes(int n_nodes, int n_prop)
 bool mh_chain_big_available(const MhDev& M, const MvnDev& V)
 {
     if (V.R < 1 || V.R > 8 || M.n_nodes > 64 * V.R + 2 || M.batch > 1024) return false;   // (1024 chains: two rounds of workgroups, still ahead of two launches per step)
-    return mhb_lds_bytes(M.n_nodes, M.n_prop) + 64 * 1024 <= 160 * 1024;
+    return mhb_lds_bytes(M.n_nodes, M.n_prop, V.R) + 64 * 1024 <= 160 * 1024;
 }
 
 template <int R>
 static hipError_t launch_big_R(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const int32_t* sched, int64_t n_steps,
                                int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
 {
-    const size_t dynb = mhb_lds_bytes(M.n_nodes, M.n_prop);
+    const size_t dynb = mhb_lds_bytes(M.n_nodes, M.n_prop, R);
     static std::atomic<unsigned long long> allowed{0};       // more than 64 KiB of LDS in total has to be allowed once per device
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;

@@ -233,7 +233,7 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
     const int inc_slots = env_slots ? std::max(1, std::min(mcd::kMhSegList, atoi(env_slots))) : seg_capable ? mcd::kMhSegSlots : mcd::kMhIncSlots;
     for (int pass = 0; pass < 2; ++pass) {
         const char* env_ss = getenv("MCD_MH_SPARSE_SLOTS");      // (the streaming chain kernel's threshold; tuning)
-        const int limit = pass ? inc_slots : env_ss ? std::max(1, std::min(256, atoi(env_ss))) : mcd::kMhSparseSlots;
+        const int limit = pass ? inc_slots : env_ss ? std::max(1, std::min(64, atoi(env_ss))) : mcd::kMhSparseSlots;      // (64: the kernel's list, kMhbList)
         std::vector<std::vector<int>> kids((size_t)n);
         for (int v = 1; v < n; ++v) kids[(size_t)parent[v]].push_back(v);
         auto slots_of = [&](const std::vector<int>& nodes) {
