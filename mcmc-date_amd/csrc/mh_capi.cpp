@@ -233,7 +233,10 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
     const int inc_slots = env_slots ? std::max(1, std::min(mcd::kMhSegList, atoi(env_slots))) : seg_capable ? mcd::kMhSegSlots : mcd::kMhIncSlots;
     for (int pass = 0; pass < 2; ++pass) {
         const char* env_ss = getenv("MCD_MH_SPARSE_SLOTS");      // (the streaming chain kernel's threshold; tuning)
-        const int limit = pass ? inc_slots : env_ss ? std::max(1, std::min(64, atoi(env_ss))) : mcd::kMhSparseSlots;      // (64: the kernel's list, kMhbList)
+        // (up to 258 nodes the chain's likelihood wave takes the columns four at a time beside the prior: 48; above, where the chain wave
+        // itself fetches them two at a time -- the sweep-only builds of the larger trees, which otherwise run in segments --: 16)
+        const int big_default = (m->mvn != nullptr && m->mvn->R <= 4) ? mcd::kMhSparseSlots : 16;
+        const int limit = pass ? inc_slots : env_ss ? std::max(1, std::min(64, atoi(env_ss))) : big_default;      // (64: the kernel's list, kMhbList)
         std::vector<std::vector<int>> kids((size_t)n);
         for (int v = 1; v < n; ++v) kids[(size_t)parent[v]].push_back(v);
         auto slots_of = [&](const std::vector<int>& nodes) {

@@ -102,7 +102,7 @@ struct MhDev {
     double* psum;
     int32_t* psel;
 };
-constexpr int kMhSparseSlots = 32;      // (measured at 257 nodes x 512 chains: 8 -> 8.96, 16 -> 8.69, 32 -> 8.35, 64 -> 8.36, 128 -> 8.52 us per lock step)
+constexpr int kMhSparseSlots = 48;      // (257 nodes x 512 chains, us per lock step: 8 -> 8.96, 32 -> 8.35 before the likelihood wave; with it 24 -> 7.70, 32 -> 7.52, 48 -> 7.44, 64 -> 7.44)
 constexpr int kMhIncSlots = 32;       // the same bound for the two-launch path's incremental evaluation (k_mh_inc.hip; MCD_MH_INC_SLOTS)
 constexpr int kMhSegSlots = 192;      // ... where the segment kernel runs the sparse proposals (k_mh_segment.hip)
 constexpr int kMhSegList = 256;       // ... and what its list of moved distances holds: no proposal of a segment may move more
