@@ -642,16 +642,29 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const bool need_bd = dH || bd_scalars;
         const bool few_bd = need_bd && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
         double c1p = c1;
+        // (HLP, as k_mh_segment.hip: a proposal's few summands are written IN PLACE, the old values wait in registers for the decision --
+        // the sum then reads one array instead of three, an accepted proposal has nothing to copy.  A node may come twice: every lane reads
+        // the old value before any lane writes, LDS keeps a wave's order)
+        double old_bd = 0.0, old_cl = 0.0;
+        const int v_bd = few_bd ? cand_bd(lane) : -1;
+        const bool mine_bd = few_bd && lane < cnt_bd && v_bd >= 1;
         if (few_bd) {
-            const int v = cand_bd(lane);
-            if (lane < cnt_bd && v >= 1) {
-                tbd_prop[v] = prior_bd_term(Pl, v, false, sc1[0], sc1[1], Hp);
-                stamp_bd[v] = st;
+            if constexpr (HLP) {
+                if (mine_bd) old_bd = tbd_cur[v_bd];
+                const double t = mine_bd ? prior_bd_term(Pl, v_bd, false, sc1[0], sc1[1], Hp) : 0.0;
+                if (mine_bd) tbd_cur[v_bd] = t;
+            } else if (mine_bd) {
+                tbd_prop[v_bd] = prior_bd_term(Pl, v_bd, false, sc1[0], sc1[1], Hp);
+                stamp_bd[v_bd] = st;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
             double bd = 0.0;
-            for (int w = 1 + lane; w < nn; w += 64) bd += (stamp_bd[w] == st) ? tbd_prop[w] : tbd_cur[w];
+            if constexpr (HLP) {
+                for (int w = 1 + lane; w < nn; w += 64) bd += tbd_cur[w];
+            } else {
+                for (int w = 1 + lane; w < nn; w += 64) bd += (stamp_bd[w] == st) ? tbd_prop[w] : tbd_cur[w];
+            }
             c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
         } else if (need_bd) {
             c1p = bd_full(sc1[0], sc1[1], Hp, tbd_prop);
@@ -660,16 +673,25 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const bool need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
         const bool few_cl = need_cl && sc1[4] == sc[4] && P.clock_model < 2 && cnt_cl <= 64;
         double c2p = c2;
+        const int v_cl = few_cl ? cand_cl(lane) : -1;
+        const bool mine_cl = few_cl && lane < cnt_cl && v_cl >= 1;
         if (few_cl) {
-            const int v = cand_cl(lane);
-            if (lane < cnt_cl && v >= 1) {
-                tcl_prop[v] = prior_clock_term(Pl, v, sc1[4], cc.lg_k, cc.log_t, Hp, Rp);
-                stamp_cl[v] = st;
+            if constexpr (HLP) {
+                if (mine_cl) old_cl = tcl_cur[v_cl];
+                const double t = mine_cl ? prior_clock_term(Pl, v_cl, sc1[4], cc.lg_k, cc.log_t, Hp, Rp) : 0.0;
+                if (mine_cl) tcl_cur[v_cl] = t;
+            } else if (mine_cl) {
+                tcl_prop[v_cl] = prior_clock_term(Pl, v_cl, sc1[4], cc.lg_k, cc.log_t, Hp, Rp);
+                stamp_cl[v_cl] = st;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
             double cl = 0.0;
-            for (int w = 1 + lane; w < nn; w += 64) cl += (stamp_cl[w] == st) ? tcl_prop[w] : tcl_cur[w];
+            if constexpr (HLP) {
+                for (int w = 1 + lane; w < nn; w += 64) cl += tcl_cur[w];
+            } else {
+                for (int w = 1 + lane; w < nn; w += 64) cl += (stamp_cl[w] == st) ? tcl_prop[w] : tcl_cur[w];
+            }
             c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
         } else if (need_cl) {
             c2p = clock_full(sc1[3], sc1[4], Hp, Rp, ccp, tcl_prop);
@@ -758,14 +780,16 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 #pragma unroll
             for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
             if (few_bd) {
-                const int v = cand_bd(lane);
-                if (lane < cnt_bd && v >= 1) tbd_cur[v] = tbd_prop[v];
+                if constexpr (!HLP) {
+                    if (mine_bd) tbd_cur[v_bd] = tbd_prop[v_bd];
+                }
             } else if (need_bd) {
                 for (int w = 1 + lane; w < nn; w += 64) tbd_cur[w] = tbd_prop[w];
             }
             if (few_cl) {
-                const int v = cand_cl(lane);
-                if (lane < cnt_cl && v >= 1) tcl_cur[v] = tcl_prop[v];
+                if constexpr (!HLP) {
+                    if (mine_cl) tcl_cur[v_cl] = tcl_prop[v_cl];
+                }
             } else if (need_cl) {
                 for (int w = 1 + lane; w < nn; w += 64) tcl_cur[w] = tcl_prop[w];
             }
@@ -798,6 +822,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                 Hp[w] = Hc[w];
                 Rp[w] = Rc[w];
             });
+            if constexpr (HLP) {                              // the overwritten summands back
+                if (mine_bd) tbd_cur[v_bd] = old_bd;
+                if (mine_cl) tcl_cur[v_cl] = old_cl;
+            }
         }
         if (lane == 0) {
             if (valid) {
