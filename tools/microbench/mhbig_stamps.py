@@ -40,7 +40,7 @@ tk = ta[:10].mean(axis=1)
 n_sparse = tk[7]
 tk = np.concatenate([tk[:7], tk[8:10]])
 print("us per lock step %.2f (n_nodes %d, chains %d; with tracing)" % (1e6 * dt / steps, topo.n_nodes, B))
-names = ["loop head", "propose", "prior", "distances + column requests", "barrier + sweep (dense steps)", "accept", "column update (sparse steps)", "draws of 64 steps (per step)", "distances + ln Jacobian"]
+names = ["loop head", "propose", "prior", "distances + column requests (R <= 4: the request to the likelihood wave)", "barrier + sweep (dense steps)", "accept", "column update (sparse steps; R <= 4: waiting for |z'|^2)", "draws of 64 steps (per step)", "distances + ln Jacobian (R <= 4: dense steps only)"]
 print("  sparse steps: %.1f %% of %d" % (100 * n_sparse / steps, steps))
 for nm, v in zip(names, tk):
-    print("  %-30s %5.1f %%   (%.0f ticks per step)" % (nm, 100 * v / tk.sum(), v / steps))
+    print("  %-60s %5.1f %%   (%.0f ticks per step)" % (nm, 100 * v / tk.sum(), v / steps))
