@@ -344,6 +344,8 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  * move more than 32 distances (the others: columns of L^-1 on a kept z).  Environment, read per call, for tests and timing:
  * MCD_MH_SEGMENTS=0 / MCD_MH_INCREMENTAL=0 switch the segments / every incremental evaluation off (the chains: same decisions and states),
  * MCD_MH_INC_SLOTS (read by mcd_mh_create) sets the number of moved distances up to which a proposal counts as sparse (at most 256),
+ * MCD_MH_SPARSE_SLOTS the same for the whole-schedule kernel of 65 .. 258 nodes (at most 64), MCD_MH_CHAIN_LW=0 runs the small-tree kernel with
+ * one wave per chain (the likelihood then after the prior instead of beside it: the same bits),
  * MCD_MH_PRIOR=0 evaluates the prior inside the first launch everywhere (the chains are the same bits either way),
  * MCD_MH_PER_PHASE=1 takes the two-launch path for small trees as well, MCD_MH_STEP_WG=1 / 0 forces / forbids the step kernel
  * with a workgroup per chain (default: trees of more than 320 nodes).
