@@ -493,11 +493,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     };
     int p = sched[0];
     PropRow row = mh_load_row(M, p);
+    double t_cur = tune[p];
     int row_sparse = inc ? M.sparse[p] : 0;
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
         const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
         const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
+        const double t_next = tune[p_next];                  // ... and its tuning parameter (global memory: a load at the point of use stalled the proposal)
         const int sparse_next = inc ? M.sparse[p_next] : 0;
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
         MHB_TICK(0)
         PropApply A;
-        const double lnqj = mh_propose_params(Ml, row, tune[p], dr, lane, sc1, Hc, Rc, A);
+        const double lnqj = mh_propose_params(Ml, row, t_cur, dr, lane, sc1, Hc, Rc, A);
         for_write_set(A, [&](int w) {
             double h, r;
             mh_propose_node(Ml, A, w, Hc, Rc, h, r);
@@ -845,6 +847,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         }
         p = p_next;
         row = row_next;
+        t_cur = t_next;
         row_sparse = sparse_next;
         MHB_TICK(5)
     }
