@@ -59,6 +59,9 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
         words->req = 0;
         words->resp = 0;
     }
+    PriorDev Pl = P;                                    // the calibration and constraint tables in LDS (prior_device.hpp)
+    if (prior_node_tables_doubles(P.n_cal, P.n_con) > 0)
+        prior_stage_node_tables(Pl, P, reinterpret_cast<double*>(words) + 8, (int)threadIdx.x, (int)blockDim.x);
     __syncthreads();                                    // the only workgroup barrier; waves are independent afterwards
     const int cw = LW ? 0 : wave;                       // the chain's index in the workgroup
     const int64_t b = (int64_t)blockIdx.x * WPB + cw;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
     double ll = M.post[B + b], lj = M.post[2 * B + b];
     // the three blocks of the ln prior of the current state; a step re-evaluates only the blocks whose inputs moved
     __builtin_amdgcn_wave_barrier();
-    double c0 = prior_nodes_wave(P, lane, sc[2], Hc);
+    double c0 = prior_nodes_wave(Pl, lane, sc[2], Hc);
     double c1 = prior_bd_wave(P, lane, sc[0], sc[1], Hc);
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};                    // variance-only pieces of the clock block, current state
     double c2 = prior_clock_wave(P, lane, sc[3], sc[4], Hc, Rc, &cc);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
             *(volatile int*)&words->req = n_req;
         }
         ClockCache ccp = cc;                                               // refreshed only if the proposal moved rVar
-        const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(P, lane, sc1[2], Hp) : c0;
+        const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
         const double c1p = (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) ? prior_bd_wave(P, lane, sc1[0], sc1[1], Hp) : c1;
         const double c2p = (dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2))
                                ? prior_clock_wave(P, lane, sc1[3], sc1[4], Hp, Rp, &ccp) : c2;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
 
 size_t mh_chain_lds_bytes(int n, int n_prop, int wpb)
 {
-    return sizeof(double) * ((size_t)n * 64 + (size_t)wpb * (4 * 64 + 2 * (size_t)n_prop) + 8);       // (+ the hand-over words of the two-wave form)
+    return sizeof(double) * ((size_t)n * 64 + (size_t)wpb * (4 * 64 + 2 * (size_t)n_prop) + 8);       // (+ the hand-over words of the two-wave form; the caller adds the node priors' tables)
 }
 
 hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const double* Fp,
@@ -297,12 +300,12 @@ hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, co
     if (n_steps <= 0) return hipSuccess;
     if (M.batch >= 1024) {
         constexpr int WPB = 4;
-        const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB);
+        const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB) + sizeof(double) * prior_node_tables_doubles(P.n_cal, P.n_con);
         hipLaunchKernelGGL((k_mh_chain<WPB, false>), dim3((unsigned)((M.batch + WPB - 1) / WPB)), dim3(64 * WPB), sh, st, M, V, T, P, Fp, sched,
                            n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept);
     } else {
         constexpr int WPB = 1;
-        const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB);
+        const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB) + sizeof(double) * prior_node_tables_doubles(P.n_cal, P.n_con);
         const char* env = getenv("MCD_MH_CHAIN_LW");      // 0: one wave per chain (tests, timing; read per call)
         if (env && env[0] == '0')
             hipLaunchKernelGGL((k_mh_chain<WPB, false>), dim3((unsigned)M.batch), dim3(64), sh, st, M, V, T, P, Fp, sched, n_steps, S, accumulate,

@@ -82,6 +82,19 @@ __host__ __device__ inline size_t mhb_help_table_doubles(int n_nodes, int np) { 
 // One pass of the loader waves over the factor, as a function of its own: inside the kernel its staging registers were allocated
 // together with the chain role's code and spilled from R = 6 up (76 / 674 registers at R = 6 / 8); a call costs a few hundred cycles
 // per pass of some 14 000.
+__host__ __device__ inline size_t mhb_lds_bytes(int n_nodes, int n_prop, int R)
+{
+    size_t d = mhb_table_doubles(n_nodes) + 2 * mhb_chain_doubles(n_nodes, n_prop);
+    if (R <= 4) d += mhb_help_table_doubles(n_nodes, 64 * R) + 2 * mhb_help_chain_doubles(64 * R);      // (MhbHelp<R>::on)
+    return sizeof(double) * d;
+}
+// ... and, where it still fits beside the 64-KiB ring, the calibration and constraint tables (prior_device.hpp: prior_stage_node_tables)
+__host__ __device__ inline size_t mhb_node_tables_bytes(int n_nodes, int n_prop, int R, int n_cal, int n_con)
+{
+    const size_t need = sizeof(double) * prior_node_tables_doubles(n_cal, n_con);
+    return (need > 0 && mhb_lds_bytes(n_nodes, n_prop, R) + need <= 94 * 1024) ? need : 0;
+}
+
 template <int R, int LW>
 __device__ __forceinline__ void mhb_stream_pass_body(const double* __restrict__ Ft, d2* ring, int lw, int lane, int ncols)
 {
@@ -310,6 +323,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     Ml.parent = tb_parent;
     Ml.size = tb_size;
     PriorDev Pl = P;
+    if (mhb_node_tables_bytes(nn, NP, R, P.n_cal, P.n_con) > 0)      // (each chain wave copies them: the same values; its own copies are what it reads)
+        prior_stage_node_tables(Pl, P, dyn + mhb_lds_bytes(nn, NP, R) / sizeof(double), lane, 64);
     Pl.parent = tb_parent;
     Pl.first_child = tb_first;
     Pl.n_children = tb_nch;
@@ -877,12 +892,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     }
 }
 
-static size_t mhb_lds_bytes(int n_nodes, int n_prop, int R)
-{
-    size_t d = mhb_table_doubles(n_nodes) + 2 * mhb_chain_doubles(n_nodes, n_prop);
-    if (R <= 4) d += mhb_help_table_doubles(n_nodes, 64 * R) + 2 * mhb_help_chain_doubles(64 * R);      // (MhbHelp<R>::on)
-    return sizeof(double) * d;
-}
+
 
 // trees of 65 .. 514 nodes whose factor the sweep holds in 2 .. 8 register blocks (N <= 512), a batch of at most two rounds of
 // workgroups (one workgroup per CU: 512 chains per round), state + tables + the 64 KiB ring within a CU's LDS
@@ -896,7 +906,7 @@ template <int R>
 static hipError_t launch_big_R(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const int32_t* sched, int64_t n_steps,
                                int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept, hipStream_t st)
 {
-    const size_t dynb = mhb_lds_bytes(M.n_nodes, M.n_prop, R);
+    const size_t dynb = mhb_lds_bytes(M.n_nodes, M.n_prop, R) + mhb_node_tables_bytes(M.n_nodes, M.n_prop, R, P.n_cal, P.n_con);
     static std::atomic<unsigned long long> allowed{0};       // more than 64 KiB of LDS in total has to be allowed once per device
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;

@@ -64,6 +64,14 @@ __host__ __device__ inline size_t seg_chain_doubles(int n_nodes, int np)
     return 6 * (size_t)n_nodes + (size_t)np + 2 * (size_t)kSegList + (size_t)kSegList / 2 + (size_t)np / 2 + 8 + (size_t)kSegApplyDoubles;
 }
 
+__host__ __device__ inline size_t seg_lds_bytes(int n_nodes, int np) { return sizeof(double) * (seg_table_doubles(n_nodes, np) + 2 * seg_chain_doubles(n_nodes, np)); }
+// ... and, where it still fits, the calibration and constraint tables behind them (prior_device.hpp: prior_stage_node_tables)
+__host__ __device__ inline size_t seg_node_tables_bytes(int n_nodes, int np, int n_cal, int n_con)
+{
+    const size_t need = sizeof(double) * prior_node_tables_doubles(n_cal, n_con);
+    return (need > 0 && seg_lds_bytes(n_nodes, np) + need <= 160 * 1024) ? need : 0;
+}
+
 struct SegWords {                  // the hand-over between a chain's two waves (LDS)
     int req;                       // chain wave: step + 1 when the proposal of step `step` is applied (Hp, Rp) and its transform posted
     int moves;                     // ... whether it can move the distances at all
@@ -186,6 +194,9 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         if (a >= 0) ts_of[a] = (int16_t)j;
     }
     if (threadIdx.x == 0) ts_of[rr] = 0;                     // the root's two daughters share slot 0 (sumFirstTwo); no slot feeds on rr itself
+    PriorDev Pst = P;                                        // (the node priors' tables in LDS where they fit)
+    if (seg_node_tables_bytes(nn, NPad, P.n_cal, P.n_con) > 0)
+        prior_stage_node_tables(Pst, P, dyn + seg_table_doubles(nn, NPad) + 2 * seg_chain_doubles(nn, NPad), (int)threadIdx.x, 256);
     __syncthreads();
 
     // ================================================================ likelihood waves
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     MhDev Ml = M;
     Ml.parent = tb_parent;
     Ml.size = tb_size;
-    PriorDev Pl = P;
+    PriorDev Pl = Pst;
     Pl.parent = tb_parent;
     Pl.first_child = tb_first;
     Pl.n_children = tb_nch;
@@ -679,8 +690,6 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     }
 }
 
-static size_t seg_lds_bytes(int n_nodes, int np) { return sizeof(double) * (seg_table_doubles(n_nodes, np) + 2 * seg_chain_doubles(n_nodes, np)); }
-
 // trees whose factor takes 6 .. 16 register blocks (259 .. 1026 nodes: below that the streaming chain kernel's in-kernel sweeps of
 // the dense proposals cost less than two launches), columns of L^-1 on the device, tables and two chains within a CU's LDS
 bool mh_segment_available(const MhDev& M, const MvnDev& V)
@@ -694,7 +703,7 @@ static hipError_t launch_segment_R(const MhDev& M, const MvnDev& V, const TreeDe
                                    int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha,
                                    int8_t* trace_accept, int64_t gs_base, int summands_kept, const MhSegPending& Q, hipStream_t st)
 {
-    const size_t dynb = seg_lds_bytes(M.n_nodes, 64 * R);
+    const size_t dynb = seg_lds_bytes(M.n_nodes, 64 * R) + seg_node_tables_bytes(M.n_nodes, 64 * R, P.n_cal, P.n_con);
     static std::atomic<unsigned long long> allowed{0};       // more than 64 KiB of LDS has to be allowed once per device
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;

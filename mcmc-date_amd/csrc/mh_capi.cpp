@@ -314,7 +314,7 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
     // MCD_MH_PER_PHASE=1 (diagnostic) keeps the two-launches-per-step path that larger trees use.
     const char* per_phase = getenv("MCD_MH_PER_PHASE");
     const int nd = m->mvn ? m->mvn->n : m->sp->n;
-    if (m->mvn && n <= 64 && !(per_phase && per_phase[0] == '1') && mcd::mh_chain_lds_bytes(nd, n_prop, 4) <= 64 * 1024) {
+    if (m->mvn && n <= 64 && !(per_phase && per_phase[0] == '1') && mcd::mh_chain_lds_bytes(nd, n_prop, 4) + sizeof(double) * mcd::prior_node_tables_doubles(m->prior->n_cal, m->prior->n_con) <= 64 * 1024) {
         std::vector<double> Fp((size_t)nd * 64, 0.0);
         for (int i = 0; i < nd; ++i) {
             const double inv = 1.0 / host_L[(size_t)i * nd + i];

@@ -71,6 +71,13 @@ struct PriorDev {
     const double* brace_sd;
 };
 
+// doubles of LDS for the calibration and constraint tables of a persistent sampler kernel (prior_device.hpp: prior_stage_node_tables); 0 = none
+__host__ __device__ inline size_t prior_node_tables_doubles(int n_cal, int n_con)
+{
+    if (n_cal + n_con == 0) return 0;
+    return 4 * (size_t)n_cal + (size_t)n_con + (3 * (size_t)n_cal + 2 * (size_t)n_con + 1) / 2;
+}
+
 // Lock-step Metropolis-Hastings workspace of one batch of chains (k_mh.hip); all pointers are device memory.
 struct MhDev {
     int n_nodes, n_prop;

@@ -133,6 +133,50 @@ __device__ __forceinline__ double prior_nodes_wave(const PriorDev& P, int lane, 
     return c0;
 }
 
+// The calibration and constraint tables (a dozen entries in a typical analysis) in LDS: a persistent sampler kernel evaluates the node
+// priors at every step that writes a height, and from global memory that is two dependent round trips per evaluation (8 calibrations +
+// 4 constraints: +0.35 us per lock step at 257 and at 1025 nodes).  Doubles of LDS needed; 0 = nothing to stage.
+// (prior_node_tables_doubles: mvn_kernels.h)
+// every calling thread copies its share (tid of nthreads); Pl's pointers are redirected; the caller synchronises before the first use
+__device__ __forceinline__ void prior_stage_node_tables(PriorDev& Pl, const PriorDev& P, double* lds, int tid, int nthreads)
+{
+    const int nc = P.n_cal, nk = P.n_con;
+    double* c_lo = lds;
+    double* c_lop = c_lo + nc;
+    double* c_hi = c_lop + nc;
+    double* c_hip = c_hi + nc;
+    double* k_p = c_hip + nc;
+    int32_t* c_node = reinterpret_cast<int32_t*>(k_p + nk);
+    int32_t* c_hl = c_node + nc;
+    int32_t* c_hh = c_hl + nc;
+    int32_t* k_y = c_hh + nc;
+    int32_t* k_o = k_y + nk;
+    for (int i = tid; i < nc; i += nthreads) {
+        c_lo[i] = P.cal_lo[i];
+        c_lop[i] = P.cal_lo_p[i];
+        c_hi[i] = P.cal_hi[i];
+        c_hip[i] = P.cal_hi_p[i];
+        c_node[i] = P.cal_node[i];
+        c_hl[i] = P.cal_has_lo[i];
+        c_hh[i] = P.cal_has_hi[i];
+    }
+    for (int i = tid; i < nk; i += nthreads) {
+        k_p[i] = P.con_p[i];
+        k_y[i] = P.con_young[i];
+        k_o[i] = P.con_old[i];
+    }
+    Pl.cal_lo = c_lo;
+    Pl.cal_lo_p = c_lop;
+    Pl.cal_hi = c_hi;
+    Pl.cal_hi_p = c_hip;
+    Pl.con_p = k_p;
+    Pl.cal_node = c_node;
+    Pl.cal_has_lo = c_hl;
+    Pl.cal_has_hi = c_hh;
+    Pl.con_young = k_y;
+    Pl.con_old = k_o;
+}
+
 // The birth-death and the clock blocks are sums over the nodes v = 1 .. n_nodes - 1, taken lane by lane over v = 1 + lane + 64 it
 // (it ascending) and then over the wave.  The summand of one node and the closing scalar terms are functions of their own, so
 // that a caller may deal the nodes to several waves and add the summands up in the same order (k_prior_grad.hip): the same

@@ -30,7 +30,18 @@ def main():
     else:
         mu, sigma = S.random_spd_problem(n, seed=3)
         lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
-    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
+    cal, con = [], []
+    if os.environ.get("MCD_BENCH_CAL"):                      # some node priors: calibrations on internal nodes, constraints between a node and an ancestor
+        k = int(os.environ["MCD_BENCH_CAL"])
+        inner = [v for v in range(1, topo.n_nodes) if (np.asarray(topo.parent) == v).any()]
+        rng = np.random.default_rng(5)
+        for i, v in enumerate(rng.choice(inner, size=min(k, len(inner)), replace=False)):
+            cal.append(M.Calibration(f"c{i}", int(v), 1e-3, 0.025, 10.0, 0.025))
+        for i, v in enumerate(rng.choice(inner, size=min(k // 2, len(inner)), replace=False)):
+            a = int(topo.parent[int(v)])
+            if a > 0:
+                con.append(M.Constraint(f"k{i}", int(v), a, 0.025))
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", cal, con, [], topo)
     ps, _ = M.proposals(topo, [], calibrations_available=True)
     s0 = S.random_states(topo, B, seed=4)
     s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
