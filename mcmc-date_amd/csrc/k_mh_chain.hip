@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
     };
     if (LW && wave == 1) {
         // ---- the likelihood wave
-        volatile int* w_req = &words->req;
+        lds_vint_t* w_req = lds_vint(&words->req);          // (mh_device.hpp: the words typed as LDS, fences that wait for LDS only)
         int last = 0;
         while (true) {
             int v = *w_req;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
                 __builtin_amdgcn_s_sleep(1);
                 v = *w_req;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            lds_acquire_fence();
             if (v < 0) break;
             double d0;
             const double q = solve(Hp, Rp, words->s1, d0);
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
                 words->q = q;
                 words->d0 = d0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            *(volatile int*)&words->resp = v;
+            lds_publish_fence();
+            *lds_vint(&words->resp) = v;
             last = v;
         }
         return;
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
         if (LW && moves) {                                                 // the likelihood wave starts on the proposed state now
             n_req += 1;
             if (lane == 0) words->s1 = sc1[2] * sc1[3];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            *(volatile int*)&words->req = n_req;
+            lds_publish_fence();
+            *lds_vint(&words->req) = n_req;
         }
         ClockCache ccp = cc;                                               // refreshed only if the proposal moved rVar
         const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
         if (moves) {
             double q, dist0;
             if (LW) {
-                volatile int* w_resp = &words->resp;
+                lds_vint_t* w_resp = lds_vint(&words->resp);
                 while (*w_resp != n_req) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                lds_acquire_fence();
                 q = words->q;
                 dist0 = words->d0;
             } else {
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
         MH_TICK(4)
     }
     if (LW) {                                           // the schedule is over
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        *(volatile int*)&words->req = -1;
+        lds_publish_fence();
+        *lds_vint(&words->req) = -1;
     }
 #ifdef MCD_MH_STAMP
     if (trace_alpha && lane == 0)

@@ -156,18 +156,19 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     MhbWords* words = reinterpret_cast<MhbWords*>(reinterpret_cast<double*>(mark + NPadC));
     PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(words) + 8);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    auto poll = [&](const volatile int* w, int want, int shift) -> int {
+    auto poll = [&](int* wp, int want, int shift) -> int {   // (mh_device.hpp: the words typed as LDS, fences that wait for LDS only)
+        lds_vint_t* w = lds_vint(wp);
         int v = *w;
         while ((v >> shift) != want) {
             __builtin_amdgcn_s_sleep(1);
             v = *w;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        lds_acquire_fence();
         return v;
     };
-    auto post = [&](volatile int* w, int value) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        *w = value;
+    auto post = [&](int* wp, int value) {
+        lds_publish_fence();
+        *lds_vint(wp) = value;
     };
 
     // ---- loader waves: one pass over the factor per step that needs the likelihood

@@ -86,20 +86,20 @@ struct SegWords {                  // the hand-over between a chain's two waves 
 };
 static_assert(sizeof(SegWords) == 64, "eight doubles of LDS");
 
-__device__ __forceinline__ int seg_poll(const volatile int* w, int want_shifted, int shift)
+__device__ __forceinline__ int seg_poll(lds_vint_t* w, int want_shifted, int shift)
 {
     int v = *w;
     while ((v >> shift) != want_shifted) {
         __builtin_amdgcn_s_sleep(1);
         v = *w;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // what the other wave wrote before the word is read after it
+    lds_acquire_fence();                                     // what the other wave wrote before the word is read after it
     return v;
 }
 // publish: everything this wave wrote to LDS so far is there before the word is
-__device__ __forceinline__ void seg_post(volatile int* w, int value)
+__device__ __forceinline__ void seg_post(lds_vint_t* w, int value)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    lds_publish_fence();
     *w = value;
 }
 
@@ -157,15 +157,15 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     int32_t* mark = l_j + kSegList;                          // [NPad] the step (+ 1) that last listed the slot
     SegWords* words = reinterpret_cast<SegWords*>(reinterpret_cast<double*>(mark + NPad));
     PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(words) + 8);
-    volatile int* w_req = &words->req;
-    volatile int* w_moves = &words->moves;
-    volatile int* w_resp = &words->resp;
-    volatile int* w_dec = &words->dec;
-    volatile int* w_cnt = &words->cnt;
-    volatile int* w_have0 = &words->have0;
-    volatile double* w_q = &words->q;
-    volatile double* w_lj = &words->lj;
-    volatile double* w_s1 = &words->s1;
+    lds_vint_t* w_req = lds_vint(&words->req);
+    lds_vint_t* w_moves = lds_vint(&words->moves);
+    lds_vint_t* w_resp = lds_vint(&words->resp);
+    lds_vint_t* w_dec = lds_vint(&words->dec);
+    lds_vint_t* w_cnt = lds_vint(&words->cnt);
+    lds_vint_t* w_have0 = lds_vint(&words->have0);
+    lds_vdouble_t* w_q = lds_vdouble(&words->q);
+    lds_vdouble_t* w_lj = lds_vdouble(&words->lj);
+    lds_vdouble_t* w_s1 = lds_vdouble(&words->s1);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     // ---- the tables, by all four waves (the only workgroup barriers of the kernel: before any wave polls a hand-over word)

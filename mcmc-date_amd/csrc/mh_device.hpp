@@ -10,6 +10,18 @@
 
 namespace mcd {
 
+// Hand-over words between two waves of a workgroup live in LDS and are polled: typed as LDS (address space 3), because a `volatile int*`
+// made from a pointer into dynamic LDS compiles to FLAT loads with system scope, each followed by a wait for every outstanding global
+// load of the wave (the next step's table row, say) as well.
+typedef __attribute__((address_space(3))) volatile int lds_vint_t;
+typedef __attribute__((address_space(3))) volatile double lds_vdouble_t;
+__device__ __forceinline__ lds_vint_t* lds_vint(int* p) { return (lds_vint_t*)p; }
+__device__ __forceinline__ lds_vdouble_t* lds_vdouble(double* p) { return (lds_vdouble_t*)p; }
+// LDS keeps a wave's accesses in order and serves one CU: publishing needs this wave's earlier LDS writes issued (they are: program
+// order) and the compiler kept from moving them -- not the full workgroup-scope fence, which also waits for every global load in flight
+__device__ __forceinline__ void lds_publish_fence() { __builtin_amdgcn_s_waitcnt(0xc07f); __asm__ volatile("" ::: "memory"); }
+__device__ __forceinline__ void lds_acquire_fence() { __asm__ volatile("" ::: "memory"); }
+
 // Random stream of one (chain, step): Philox4x32-10, counter = (draw, chain, step_lo, step_hi), key = seed.
 struct Rng {
     uint32_t k0, k1, chain, s0, s1;
