@@ -111,7 +111,7 @@ __device__ __forceinline__ void mhb_stream_pass_body(const double* __restrict__ 
 template <int R, int LW>
 __device__ __noinline__ void mhb_stream_pass_call(const double* __restrict__ Ft, d2* ring, int lw, int lane, int ncols)
 {
-    mhb_stream_pass_body<R, LW>(Ft, ring, lw, lane, ncols);
+    mhb_stream_pass_body<R, LW>((const double*)(const __attribute__((address_space(1))) double*)Ft, ring, lw, lane, ncols);   // (global memory: global loads)
 }
 // (R <= 4 keeps the body inline: no call frame, no scratch at all in those instantiations)
 template <int R, int LW>
@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         int kind = M.kind[p], node = M.node[p];
         const bool inc = V.Wc != nullptr;
         int sp = inc ? M.sparse[p] : 0;
+        // (the factor is in global memory: said so, the stream's loads are global loads -- as generic pointer they compiled to flat loads,
+        // which count against the LDS counter as well and so tie the ring's writes to the whole stream)
+        const double* Ft_g = (const double*)(const __attribute__((address_space(1))) double*)V.Ft;
         // (HLP) this wave's chain: its proposed state, and the tables the chain waves put in LDS before their first barrier
         const int32_t* tb_first_ = reinterpret_cast<const int32_t*>(dyn) + 2 * nn;
         const int32_t* tb_nch_ = tb_first_ + nn;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             // z of the current state (start of the launch, then every 256 steps), then the step's own sweep if its proposal is dense
             // (one call site: the stream is a long unrolled body)
             const int passes = ((inc && (gs & (kMhbRefresh - 1)) == 0) ? 1 : 0) + ((mhb_moves_likelihood(kind, node) && !sp) ? 1 : 0);
-            for (int r = 0; r < passes; ++r) mhb_stream_pass<R, LW>(V.Ft, ring, lw, lane, ncols);
+            for (int r = 0; r < passes; ++r) mhb_stream_pass<R, LW>(Ft_g, ring, lw, lane, ncols);
             if constexpr (HLP) {
                 if (inc && sp && mhb_moves_likelihood(kind, node)) {
                     // ---- the likelihood wave of a sparse step (k_mh_segment.hip has the same: the slots the written nodes feed, each once)
