@@ -246,8 +246,22 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
     s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
     cal = [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025), M.Calibration("n", 5, 0.2, 0.025, None, 0.0)]
     con = [M.Constraint("k", 7, 3, 0.025)]
-    ps, _ = M.proposals(topo, [], calibrations_available=True)
-    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :260]
+    braces = []
+    if B == 33:                                              # braced nodes (Brace.hs): a pair of internal nodes, one from each side of the root
+        par = np.asarray(topo.parent)
+        size = np.ones(topo.n_nodes, int)
+        for v in range(topo.n_nodes - 1, 0, -1):
+            size[par[v]] += size[v]
+        rr = 1 + size[1]
+        braces = [M.Brace("b0", [[v for v in range(2, rr) if size[v] > 1][0], [v for v in range(rr + 1, topo.n_nodes) if size[v] > 1][0]], 0.01)]
+    ps, _ = M.proposals(topo, braces, calibrations_available=True)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))
+    if braces:                                               # (the brace proposals of the cycle among the 260 steps)
+        kinds = M.table_arrays(ps)["kind"][sched[0]]
+        pick = np.sort(np.unique(np.concatenate([np.flatnonzero(np.isin(kinds, [14, 15]))[:20], np.arange(240)])))
+        sched = sched[:, pick[:260]]
+    else:
+        sched = sched[:, :260]
     for model in ("UncorrelatedGamma", "AutocorrelatedLogNormal"):
         runs = []
         for phased in (False, True):
@@ -257,7 +271,7 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
                 monkeypatch.delenv("MCD_MH_PER_PHASE", raising=False)
             lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
             lik.mvn.set_form("sweep")                        # (the two-launch path would take the row split at 240 < N <= 256, <= 128 chains)
-            smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, [], topo), ps, B, seed=13)
+            smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, braces, topo), ps, B, seed=13)
             smp.set_state(s0)
             tol = 1e-8 + 1e-12 * np.abs(smp.posterior()[:, :2]).max()
             a, k = smp.run_schedule(sched[:, :200], accumulate=True, trace=True)
@@ -303,14 +317,30 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
     s0 = S.random_states(topo, B, seed=62)
     s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
     cal = [M.Calibration("root", 0, 0.9, 0.025, 1.1, 0.025), M.Calibration("n", 5, 0.2, 0.025, None, 0.0)]
-    ps, _ = M.proposals(topo, [], calibrations_available=True)
-    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :1500]
+    braces = []
+    if B == 33:                                              # braced nodes (Brace.hs): two pairs of internal nodes, one from each side of the root
+        par = np.asarray(topo.parent)
+        size = np.ones(topo.n_nodes, int)
+        for v in range(topo.n_nodes - 1, 0, -1):
+            size[par[v]] += size[v]
+        rr = 1 + size[1]
+        left = [v for v in range(2, rr) if size[v] > 1][:2]
+        right = [v for v in range(rr + 1, topo.n_nodes) if size[v] > 1][:2]
+        braces = [M.Brace("b0", [left[0], right[0]], 0.01), M.Brace("b1", [left[1], right[1]], 0.02)]
+    ps, _ = M.proposals(topo, braces, calibrations_available=True)
+    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))
+    if braces:                                               # (every brace proposal of the cycle among the 1 500 steps)
+        kinds = M.table_arrays(ps)["kind"][sched[0]]
+        first = np.concatenate([np.flatnonzero(np.isin(kinds, [14, 15]))[:40], np.arange(1460)])
+        sched = sched[:, np.sort(np.unique(first))[:1500]]
+    else:
+        sched = sched[:, :1500]
     runs = []
     for inc, seg in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("MCD_MH_INCREMENTAL", inc)
         monkeypatch.setenv("MCD_MH_SEGMENTS", seg)
         lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
-        smp = M.Sampler(lik, M.PriorFunction(1.0, "UncorrelatedGamma", cal, [], [], topo), ps, B, seed=13)
+        smp = M.Sampler(lik, M.PriorFunction(1.0, "UncorrelatedGamma", cal, [], braces, topo), ps, B, seed=13)
         smp.set_state(s0)
         if B == 33:                                          # heated chains (MC3): posterior^beta in every path's acceptance ratio
             smp.set_temperatures(np.linspace(1.0, 0.55, B))
