@@ -400,7 +400,7 @@ def test_streaming_chain_kernel_over_many_steps_against_the_twin(gpu):
 
 
 @pytest.mark.parametrize("n_leaves,B,n_steps", [(70, 6, 400), (128, 64, 150), (70, 2100, 24), (140, 33, 150), (150, 512, 60), (160, 64, 100),
-                                                (513, 512, 24)])
+                                                (513, 512, 24), (513, 32, 600), (300, 16, 600), (513, 8, 3000)])
 def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
     """Synthetic trees beyond 64 nodes (70 leaves: 139 nodes, N = 137, three row blocks; 128 leaves: 255 nodes, N = 253,
     the size of BASELINE.json's config 3, with 64 chains): lanes stride over the nodes and the likelihood runs through
@@ -408,7 +408,8 @@ def test_large_tree_uses_the_per_phase_path(gpu, n_leaves, B, n_steps):
     likelihood launch takes the multiply form on the matrix cores (k_wide.hip).  140 / 150 / 160 leaves = 279 / 299 / 319 nodes:
     the window between the streaming chain kernel (N <= 256, i.e. <= 258 nodes) and the workgroup-per-chain step kernel (more
     than 320 nodes) -- one-wave k_mh_step with the prior inside + the row-split likelihood (round-2 review: no test reached it).
-    513 leaves x 512 chains = config 5's share of one GPU (1025 nodes), step by step against the twin."""
+    513 leaves x 512 chains = config 5's share of one GPU (1025 nodes), step by step against the twin; 600 lock steps at 1025 and at 599
+    nodes: several segments (k_mh_segment.hip), dense proposals between them, two recomputations of z."""
     from mcmc_date_amd import synthetic as S
 
     topo = S.random_topology(n_leaves, seed=3)
