@@ -186,6 +186,7 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_perio
     if swap_info:
         out["mc3"] = swap_info
     if comm is not None:
+        out["rccl_comm_ranks"] = comm.count()
         comm.close()
     return out
 
@@ -272,6 +273,82 @@ def sparse_measure(dev_index, n, B, steps, warm, band=3, extra=4):
                                   "traffic": None}}
 
 
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves -- fresh interpreter
+    processes created BEFORE this process has made any GPU call (it never makes one: it only waits), one per device, rendezvous
+    through the environment exactly as torch.distributed.run sets it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Rank 0's stdout is ours, so the ONE JSON line comes out where the driver reads it.  On a box with fewer devices than ranks the
+    children run as a REHEARSAL (MCD_BENCH_REHEARSAL=1: every rank on cuda:0, control collectives and the swap all-gather through
+    gloo, because RCCL refuses two ranks on one device) and the line says so (`"rehearsal": true`, `"devices": 1`).
+    The device count is taken in a child process as well, so that this one stays clear of the GPU whatever the runtime does."""
+    import socket
+    import subprocess
+
+    ndev = 0
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        ndev = int(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else 0
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        ndev = 0
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    rehearsal = ndev < n_ranks or os.environ.get("MCD_BENCH_REHEARSAL") == "1"
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   MCD_BENCH_SELF_LAUNCHED="1", MCD_BENCH_DEVICES=str(ndev))
+        if rehearsal:
+            env["MCD_BENCH_REHEARSAL"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("MCD_BENCH_LAUNCH_TIMEOUT", "3000"))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            c = p.poll()
+            if c is not None:
+                alive.remove(p)
+                if c != 0:
+                    rc = rc or c
+        if rc != 0 or time.time() > deadline:                   # one rank failed (or the run hangs): end exactly the processes started here
+            for p in alive:
+                p.terminate()
+            for p in alive:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def rank_report(dist, world, rank, elapsed, K, ctl_dev, rehearsal, comm_ranks=None):
+    """What the line says about the ranks of a multi-rank run: every rank's own ms_per_step (all-gathered), the rank count the
+    process group reports (and, with --kind mh and a swap phase, the one the C ABI's RCCL communicator reports: ncclCommCount),
+    how many devices the box has and whether the run was a one-device rehearsal."""
+    import torch
+
+    per = [1e3 * elapsed / K]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
+        g = torch.empty(world, dtype=torch.float64, device=ctl_dev)
+        dist.all_gather_into_tensor(g, t)
+        per = [1e3 * float(x) / K for x in g.cpu().tolist()]
+    ndev = int(os.environ.get("MCD_BENCH_DEVICES", "0")) or torch.cuda.device_count()
+    return {"world_size": int(dist.get_world_size()) if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+            "rccl_comm_ranks": comm_ranks, "ms_per_step_per_rank": per, "devices": ndev, "rehearsal": bool(rehearsal),
+            "launched_by": ("bench.py (self-launched child processes)" if os.environ.get("MCD_BENCH_SELF_LAUNCHED") == "1"
+                            else "torch.distributed.run" if world > 1 else "single process")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +369,10 @@ def main():
     ap.add_argument("--no-mh", action="store_true", help="skip the secondary Metropolis-Hastings measurement of the default run")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): this process becomes the launcher and never touches the GPU
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -302,8 +383,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # Rehearsal on a one-GPU box: MCD_BENCH_REHEARSAL=1 maps every rank to cuda:0 and uses gloo for the control
@@ -330,6 +410,7 @@ def main():
         r = mh_measure(dev_index, n, B, K, W, seed=3, rank=rank, world=world, swap_period=args.swap_period, swap_steps=args.swap_steps,
                        rehearsal=rehearsal)
         elapsed = K * r["us_per_lockstep"] * 1e-6
+        ranks = rank_report(dist, world, rank, elapsed, K, ctl_dev, rehearsal, r.get("rccl_comm_ranks"))
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -363,7 +444,7 @@ def main():
                              "note": "achieved: SURVEY.md 8(d)'s bytes of ONE FULL likelihood evaluation of the batch per lock step; most proposals are "
                                      "evaluated incrementally (columns of L^-1 on a kept z) and move less -- traffic: memory-side bytes per lock step of "
                                      "the whole run, every kernel (PMC, profiles/)"},
-                "mh": r}))
+                "ranks": ranks, "mh": r}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -549,6 +630,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)
+    ranks = rank_report(dist, world, rank, elapsed, K, ctl_dev, rehearsal)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -574,7 +656,7 @@ def main():
         flops = algorithmic_flops_per_eval(n) * (2.0 if has_grad else 1.0) * B / per_launch_s / 1e12
         traffic, traffic_source = (measured_traffic({("logpdf", 256): "n256", ("logpdf", 1024): "n1024", ("tree", 255): "tree255",
                                                      ("tree", 1023): "tree1023"}.get((args.kind, n)))
-                                   if B == 512 and args.form == "auto" else (None, None))
+                                   if B == 512 and args.form == "auto" and world == 1 else (None, None))
         out = {
             "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes",   # BASELINE.json:metric, verbatim
             "value": evals / elapsed,
@@ -601,6 +683,8 @@ def main():
                          "fp64_tflops": flops, "fp64_frac": flops / FP64_PEAK_TFLOPS},
         }
         out["config"]["form"] = form
+        if world > 1:
+            out["ranks"] = ranks
         if form == "multiply":
             # k_wide.hip: a triangular matrix product on the fp64 matrix cores -- priced against the dense fp64 MFMA peak
             # (v_mfma_f64_16x16x4_f64: 64 cycles per 16x16x4 tile product and SIMD = the vector fp64 rate, 78.6 TFLOP/s)

@@ -122,6 +122,9 @@ foreign import ccall safe "mcd_shard_comm_create"
 foreign import ccall unsafe "mcd_shard_comm_destroy"
   c_shard_comm_destroy :: Ptr () -> IO ()
 
+foreign import ccall unsafe "mcd_shard_comm_count"
+  c_shard_comm_count :: Ptr () -> Ptr CInt -> IO CInt
+
 foreign import ccall unsafe "mcd_shard_allgather"
   c_shard_allgather :: Ptr () -> Ptr CDouble -> Ptr CDouble -> Int64 -> Ptr () -> IO CInt
 

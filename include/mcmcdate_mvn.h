@@ -442,6 +442,7 @@ int mcd_sparse_tree_loglik_batch(const mcd_sparse_tree_t* t, const double* heigh
 int mcd_shard_unique_id(char id[MCD_SHARD_ID_BYTES]);
 int mcd_shard_comm_create(void** comm, int world_size, int rank, const char id[MCD_SHARD_ID_BYTES], int device_id);
 void mcd_shard_comm_destroy(void* comm);
+int mcd_shard_comm_count(void* comm, int* n_ranks);   /* the rank count the RCCL communicator itself reports (ncclCommCount) */
 int mcd_shard_allgather(void* comm, const double* send, double* recv, int64_t count, void* stream);
 int mcd_mh_posterior_device(const mcd_mh_t* m, const double** post, void** stream);
 

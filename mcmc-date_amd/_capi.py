@@ -75,6 +75,7 @@ SYMBOLS = {
     "mcd_shard_unique_id": (C.c_int, [C.c_char_p]),
     "mcd_shard_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "mcd_shard_comm_destroy": (None, [_vp]),
+    "mcd_shard_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mcd_shard_allgather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "mcd_mh_posterior_device": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "mcd_hmc_nuts": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_uint64, C.c_int64, C.c_uint64, _dp, _ip]),

@@ -190,3 +190,12 @@ extern "C" int mcd_debug_stamps(unsigned long long* out)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcd::g_dbg), 64 * sizeof(unsigned long long));
 }
 #endif
+#if defined(MCD_STAMP) && defined(MCD_STAMP_LIGHT) && MCD_RGROUP == 0
+// the ring of the last 64 launches: hist [64][8][8], span [64][64][2], *n = launches completed
+extern "C" int mcd_debug_hist(unsigned long long* hist, unsigned long long* span, unsigned int* n)
+{
+    if (hipMemcpyFromSymbol(hist, HIP_SYMBOL(mcd::g_hist), 64 * 8 * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(span, HIP_SYMBOL(mcd::g_span), 64 * 64 * 2 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(n, HIP_SYMBOL(mcd::g_launch), sizeof(unsigned int));
+}
+#endif

@@ -86,7 +86,32 @@ __device__ __forceinline__ void lds_barrier()
 #define MCD_SB __builtin_amdgcn_sched_barrier(0)
 
 // Diagnostic builds only (-DMCD_STAMP): wave-level timestamps of workgroup 0 at a few milestones.
-#ifdef MCD_STAMP
+// -DMCD_STAMP_LIGHT (with MCD_STAMP; k_logpdf.hip, `make stamp_headline`): the milestones only, kept per launch in a ring of the
+// last 64 launches together with entry / exit of every workgroup on workgroup 0's XCD -- the budget of a graph-replayed launch
+// (tools/microbench/headline_phases.py); no accumulators inside the sweep, so the loop under test is the shipped one.
+#if defined(MCD_STAMP) && defined(MCD_STAMP_LIGHT)
+__device__ unsigned long long g_dbg[64];
+__device__ unsigned long long g_hist[64][8][8];            // [launch % 64][wave][milestone] of workgroup 0
+__device__ unsigned long long g_span[64][64][2];           // [launch % 64][i][entry, exit] of compute wave 0 of workgroup 8 i
+__device__ unsigned int g_launch;                          // launches completed (bumped by workgroup 0 at its exit)
+#define MCD_T(idx)                                                                               \
+    do {                                                                                         \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+        if ((threadIdx.x & 63) == 0) {                                                           \
+            const unsigned ln_ = __atomic_load_n(&g_launch, __ATOMIC_RELAXED) & 63u;             \
+            if (blockIdx.x == 0) g_hist[ln_][threadIdx.x >> 6][(idx)] = t_;                       \
+            if ((blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && threadIdx.x == 0 && ((idx) == 0 || (idx) == 4)) \
+                g_span[ln_][blockIdx.x >> 3][(idx) == 0 ? 0 : 1] = t_;                           \
+            if (blockIdx.x == 0 && threadIdx.x == 0 && (idx) == 4) __atomic_fetch_add(&g_launch, 1u, __ATOMIC_RELAXED); \
+        }                                                                                        \
+    } while (0)
+#define MCD_ACC_DECL
+#define MCD_ACC(idx) do { } while (0)
+#define MCD_ACC_PARAMS
+#define MCD_ACC_ARGS
+#define MCD_ACC_FLUSH(base) do { } while (0)
+#elif defined(MCD_STAMP)
 __device__ unsigned long long g_dbg[64];
 #define MCD_T(idx)                                                                               \
     do {                                                                                         \

@@ -29,6 +29,7 @@ typedef int (*GetUniqueIdFn)(NcclUniqueId*);
 typedef int (*CommInitRankFn)(NcclComm*, int, NcclUniqueId, int);
 typedef int (*CommDestroyFn)(NcclComm);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, NcclComm, hipStream_t);
+typedef int (*CommCountFn)(NcclComm, int*);
 typedef const char* (*GetErrorStringFn)(int);
 constexpr int kNcclDouble = 8;
 
@@ -38,6 +39,7 @@ struct Rccl {
     CommInitRankFn comm_init_rank = nullptr;
     CommDestroyFn comm_destroy = nullptr;
     AllGatherFn all_gather = nullptr;
+    CommCountFn comm_count = nullptr;
     GetErrorStringFn error_string = nullptr;
     bool ok = false;
 };
@@ -57,6 +59,7 @@ Rccl& rccl()
         r.comm_init_rank = (CommInitRankFn)dlsym(r.lib, "ncclCommInitRank");
         r.comm_destroy = (CommDestroyFn)dlsym(r.lib, "ncclCommDestroy");
         r.all_gather = (AllGatherFn)dlsym(r.lib, "ncclAllGather");
+        r.comm_count = (CommCountFn)dlsym(r.lib, "ncclCommCount");
         r.error_string = (GetErrorStringFn)dlsym(r.lib, "ncclGetErrorString");
         r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather;
     });
@@ -106,6 +109,14 @@ int mcd_shard_comm_create(void** comm, int world_size, int rank, const char id[M
 void mcd_shard_comm_destroy(void* comm)
 {
     if (comm && rccl().ok) (void)rccl().comm_destroy((NcclComm)comm);
+}
+
+int mcd_shard_comm_count(void* comm, int* n_ranks)
+{
+    if (!comm || !n_ranks) return fail(MCD_ERR_INVALID_ARG, "mcd_shard_comm_count: NULL argument");
+    if (!rccl().ok || !rccl().comm_count) return fail(MCD_ERR_UNSUPPORTED, "mcd_shard_comm_count: librccl.so could not be loaded");
+    if (int rc = rccl().comm_count((NcclComm)comm, n_ranks)) return fail(MCD_ERR_HIP, "ncclCommCount", rc);
+    return MCD_OK;
 }
 
 int mcd_shard_allgather(void* comm, const double* send, double* recv, int64_t count, void* stream)

@@ -118,8 +118,16 @@ def gather_posterior_device(sampler, comm: "ShardComm"):
     lib = _capi.lib()
     dptr, st = C.c_void_p(), C.c_void_p()
     _capi.check(lib.mcd_mh_posterior_device(sampler._h, C.byref(dptr), C.byref(st)))
-    dev = torch.device("cuda", torch.cuda.current_device())
-    out = torch.empty((comm.shard.world, 3, sampler.batch), dtype=torch.float64, device=dev)
+    # The receive buffer belongs to the communicator and lives as long as it does: it is written by the all-gather and read by
+    # the swap kernel on the SAMPLER'S stream only, which torch's caching allocator knows nothing about -- a fresh torch.empty per
+    # phase could be handed out again (or still carry pending work of torch's stream) while that stream uses it.
+    key = (int(sampler.batch),)
+    out = comm._gathered.get(key)
+    if out is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        out = torch.empty((comm.shard.world, 3, sampler.batch), dtype=torch.float64, device=dev)
+        torch.cuda.current_stream(dev).synchronize()          # nothing of torch's stream is pending on the block when the other stream gets it
+        comm._gathered[key] = out
     _capi.check(lib.mcd_shard_allgather(comm._comm, dptr, C.c_void_p(out.data_ptr()), 3 * sampler.batch, st))
     return out
 
@@ -148,21 +156,38 @@ class ShardComm:
 
         self.shard = shard
         self._lib = _capi.lib()
+        self._gathered = {}
         buf = C.create_string_buffer(128)
         if shard.rank == 0:
             _capi.check(self._lib.mcd_shard_unique_id(buf))
         ident = buf.raw
         if shard.world > 1:
             if exchange is None:
+                # a 128-byte tensor broadcast: on the device for the nccl (= RCCL) backend, on the host for gloo -- no pickled
+                # objects, nothing that depends on how the backend moves Python objects
+                import torch
                 import torch.distributed as dist
 
-                box = [ident]
-                dist.broadcast_object_list(box, src=0)
-                ident = box[0]
+                on_dev = dist.get_backend() == "nccl"
+                t = torch.frombuffer(bytearray(ident), dtype=torch.uint8).clone()
+                if on_dev:
+                    t = t.to(torch.device("cuda", int(device)))
+                dist.broadcast(t, src=0)
+                ident = bytes(t.cpu().numpy().tobytes())
             else:
                 ident = exchange(ident)
         self._comm = C.c_void_p()
         _capi.check(self._lib.mcd_shard_comm_create(C.byref(self._comm), shard.world, shard.rank, ident, int(device)))
+
+    def count(self) -> int:
+        """The rank count the RCCL communicator itself reports (ncclCommCount)."""
+        import ctypes as C
+
+        from . import _capi
+
+        n = C.c_int(0)
+        _capi.check(self._lib.mcd_shard_comm_count(self._comm, C.byref(n)))
+        return int(n.value)
 
     def allgather(self, send, stream=None):
         """send: 1-D float64 CUDA tensor, the same length on every rank; returns [world * len] in rank order."""
