@@ -88,6 +88,7 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
         O.logpdf_full_batch(mu, P, logdet, sample, native=True, all_cores=True)
         evals_mt += len(sample)
     out["all_cores"] = {"value": evals_mt / (time.perf_counter() - t0), "unit": "evals/s", "cores": threads}
+    out["haskell_toolchain"] = haskell_toolchain()          # `kind` could only be "haskell" with one (and the reference's sources)
     return out
 
 
@@ -273,6 +274,114 @@ def sparse_measure(dev_index, n, B, steps, warm, band=3, extra=4):
                                   "traffic": None}}
 
 
+def haskell_toolchain():
+    """is a Haskell toolchain on this box?  (`cpu_baseline.kind` says "haskell" only if the reference binary
+    could be built and timed; the reference's sources are not on the GPU box either, so a toolchain alone changes nothing -- reported.)"""
+    import shutil
+
+    return {t: shutil.which(t) for t in ("ghc", "cabal", "stack")}
+
+
+def e2e_measure(dev_index, chains=128, iterations=8000, period=2, seed=21, cpu_budget_s=15.0):
+    """The reference's ONLY published timing, end to end: the posterior analysis of the 7-taxon mtCDNApri data --
+    `./run -s -f analysis.conf -c ul s r`: sparse multivariate normal likelihood (graphical lasso 0.1), uncorrelated log-normal clock,
+    calibrations from the MCMCtree-style tree, the burn-in schedule with auto tuning (app/Definitions.hs:420-424) + 8000 iterations
+    (:440-441), monitors with period 2 (bench/comparison_with_mcmctree/README.md:615-632) -- 154 s per chain on an i7-1165G7 (README.md:720;
+    other hardware: a stated baseline, not a ratio to claim).  Here: `prepare` on the host (timed apart), then `chains` chains in lock
+    step on the device through the NATIVE sparse handle (mcd_mh_create_sparse: every proposal inside a segment launch), the chains'
+    states fetched every 2 iterations as the monitors would; the node ages against the reference's committed samples
+    (tests/golden/mtCDNApri_post_samples.json; must stay within 1 %).  Beside it the CPU twin (oracle/mh_oracle.c, a restatement) timed on
+    a bounded sample on this box's host cores."""
+    import tempfile
+
+    import mcmc_date_amd as M
+    from mcmc_date_amd import monitor as MO
+    from mcmc_date_amd.prepare import prepare
+
+    gold = os.path.join(ROOT, "tests", "golden")
+    fx = json.load(open(os.path.join(gold, "mtCDNApri_prior_samples.json")))
+    post = json.load(open(os.path.join(gold, "mtCDNApri_post_samples.json")))
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory() as d:
+        paths = {}
+        for k in ("rooted_tree", "calibration_tree", "tree_list"):
+            paths[k] = os.path.join(d, k)
+            open(paths[k], "w").write(fx["inputs"][k])
+        prep = prepare(paths["tree_list"], paths["rooted_tree"], "SparseMultivariateNormal 0.1")
+        topo = prep.topology
+        cal = M.load_calibrations_from_tree(topo, paths["calibration_tree"])
+    prepare_s = time.perf_counter() - t0
+    ht = M.get_mean_root_height(cal)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    S_iter = int(sum(p.weight for p in ps))
+    burn = list(M.sampler.BURN_IN_FAST) + list(M.sampler.BURN_IN_SLOW)
+
+    def run_device():
+        lik = M.SparseLikelihood(prep.lhd, device=dev_index).bind_tree(topo)
+        pf = M.PriorFunction(ht, "UncorrelatedLogNormal", cal, [], [], topo, device=dev_index)
+        smp = M.Sampler(lik, pf, ps, chains, seed=seed)
+        x0 = M.init_with(topo, prep.mean_lengths)
+        x0.time_height = ht
+        smp.set_initial_state(x0)
+        t0 = time.perf_counter()
+        for p in burn:                                      # burn-in with the monitors running (the reference's monitor files hold it)
+            MO.collect(smp, p, period=period)
+            smp.autotune()
+        tb = time.perf_counter()
+        tr = MO.collect(smp, iterations, period=period)
+        t1 = time.perf_counter()
+        return smp, tr, tb - t0, t1 - tb
+
+    run_device()                                            # (untimed: code objects, allocations)
+    smp, tr, burn_s, run_s = run_device()
+    ages = tr.ages()[:, :, post["nodes"]].reshape(-1, len(post["nodes"]))
+    ref = {k: np.array(v) for k, v in post["pooled"].items()}
+    dev = np.abs(ages.mean(axis=0) - ref["mean"]) / ref["mean"]
+    assert np.all(dev <= 0.01), f"node ages off the reference's committed samples: {dev}"
+    wall = burn_s + run_s
+    n_it = sum(burn) + iterations
+    out = {"analysis": "mtCDNApri posterior, SparseMultivariateNormal 0.1, uncorrelated log-normal clock (bench/comparison_with_mcmctree/README.md:615-632)",
+           "chains": int(chains), "iterations": int(iterations), "burn_in_iterations": int(sum(burn)), "proposals_per_iteration": S_iter,
+           "monitor_period": int(period), "wall_s": wall, "burn_in_s": burn_s, "run_s": run_s, "prepare_s_host": prepare_s,
+           "s_per_chain": wall / chains, "proposal_steps_per_s": chains * n_it * S_iter / wall,
+           "node_age_max_rel_dev_vs_reference_samples": float(dev.max()), "node_age_rel_dev": [float(x) for x in dev],
+           "likelihood": "native sparse handle (mcd_sparse_create / mcd_mh_create_sparse)", "path": smp.last_path(),
+           "published_reference": {"value": 154.0, "unit": "s per chain (one chain per process)", "hardware": "Intel i7-1165G7 (Lenovo X1 Carbon Gen 9)",
+                                   "source": "bench/comparison_with_mcmctree/README.md:720; scripts/Benchmarking_comptime.R:39-45",
+                                   "note": "other hardware, the Haskell binary: a stated baseline beside this figure, not a measured ratio"},
+           "haskell_toolchain": haskell_toolchain()}
+    # the CPU twin on this box: a bounded sample of the same analysis (one chain per host thread), extrapolated to the whole analysis
+    try:
+        import oracle as O
+
+        O.build(native=True, force=True)
+        nthr = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        n = topo.n_nodes - 2
+        P = np.zeros((n, n))
+        for (i, j), v in prep.lhd.sigma_inv_assoc:
+            P[i, j] = v
+        spec = O.PriorSpec(topo.parent, ht, "UncorrelatedLogNormal", [(c.node, c.lower, c.lower_p, c.upper, c.upper_p) for c in cal], [], [])
+        model = O.MhModel(topo.parent, np.asarray(prep.mu, float), P, float(prep.lhd.logdet_sigma), spec, M.table_arrays(ps))
+        x0 = M.init_with(topo, prep.mean_lengths)
+        x0.time_height = ht
+        s0 = M.StateBatch.from_states([x0] * nthr)
+        tw = O.MhChains(model, s0.time_birth_rate, s0.time_death_rate, s0.time_height, s0.heights, s0.rate_mean, s0.rate_variance, s0.rates, seed=seed)
+        rng = np.random.default_rng(5)
+        tw.run(M.cycle_schedule(ps, 2, rng))
+        t0 = time.perf_counter()
+        its = 0
+        while time.perf_counter() - t0 < cpu_budget_s:
+            tw.run(M.cycle_schedule(ps, 20, rng))
+            its += 20
+        dt = time.perf_counter() - t0
+        out["cpu_twin"] = {"kind": "port", "cores": nthr, "chains": nthr, "sample": f"{its} iterations of {nthr} chains (one per host thread) in {dt:.1f} s",
+                           "s_per_chain_full_analysis_extrapolated": dt / its * n_it, "proposal_steps_per_s": nthr * its * S_iter / dt,
+                           "what": "oracle/mh_oracle.c: sequential restatement of the same proposal cycle, prior and dense-matrix likelihood (not the Haskell binary)"}
+    except Exception as e:                                   # (a secondary field must not take the line down)
+        out["cpu_twin"] = {"error": repr(e)}
+    return out
+
+
 def self_launch(n_ranks, argv):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves -- fresh interpreter
     processes created BEFORE this process has made any GPU call (it never makes one: it only waits), one per device, rendezvous
@@ -365,7 +474,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--form", default="auto", choices=["auto", "sweep", "multiply"],
                     help="log-density kernel form (mcd_set_logpdf_form); auto = multiply for N >= 96 and >= 2048 chains, N >= 32 and >= 8192")
-    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior", "mh", "sparse"])
+    ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior", "mh", "sparse", "e2e"])
     ap.add_argument("--no-mh", action="store_true", help="skip the secondary Metropolis-Hastings measurement of the default run")
     args = ap.parse_args()
 
@@ -447,6 +556,22 @@ def main():
                 "ranks": ranks, "mh": r}))
         if world > 1:
             dist.destroy_process_group()
+        return
+    if args.kind == "e2e":
+        if world > 1:
+            raise SystemExit("bench.py --kind e2e runs on one GPU (the analysis is one batch of chains)")
+        chains = args.chains if args.chains != 512 else 128
+        r = e2e_measure(dev_index, chains=chains)
+        n_it = r["iterations"] + r["burn_in_iterations"]
+        print(json.dumps({
+            "metric": "MVN log-likelihood evals/sec (= MCMC steps/sec \u00d7 chains) at N=256 nodes", "value": r["proposal_steps_per_s"],
+            "unit": "MH proposal steps/s (lock steps x chains), whole analysis incl. burn-in, tuning and period-2 state fetches",
+            "n_gpus": 1, "steps": n_it * r["proposals_per_iteration"], "warmup": 0, "ms_per_step": 1e3 * r["wall_s"] / (n_it * r["proposals_per_iteration"]),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "the reference's committed mtCDNApri inputs (tests/golden)",
+            "config": {"workload": f"end to end: mtCDNApri posterior analysis (7 taxa, N = 11, sparse likelihood), {chains} chains, burn-in + 8000 iterations, "
+                                   "monitors every 2 iterations", "n": 11, "chains_per_gpu": chains, "kernel": "e2e"},
+            "roofline": None, "e2e": r, "cpu_baseline": {**({k: v for k, v in r["cpu_twin"].items()} if "error" not in r["cpu_twin"] else {}),
+                                                           "value": r["cpu_twin"].get("proposal_steps_per_s"), "unit": "MH proposal steps/s"}}))
         return
     if args.kind == "sparse":
         K, W = args.steps, args.warmup

@@ -69,7 +69,7 @@ const char* mcd_last_error(void);
  *   MCD_FORM_MULTIPLY always the multiply form z = L^-1 (x - mu) on the fp64 matrix cores (the throughput form).
  * mcd_mvn_set_form chooses per handle (two samplers with a handle each can pin different forms); a handle whose choice is
  * MCD_FORM_AUTO follows the process default, which mcd_set_logpdf_form sets (a test and tuning knob; the environment
- * variable MCD_WIDE=0|1 sets its initial value to SWEEP | MULTIPLY).  Both return the previous value.
+ * variable MCD_WIDE=0|1, read when the library is loaded, sets its initial value to SWEEP | MULTIPLY).  Both return the previous value.
  * The gradient entry points follow the same choice; above N = 256 the multiply form uses the gradient rows (`G`, `g_heights`)
  * as scratch while it runs: a call whose gradient array IS an input array (in place) takes the sweeps instead; partially
  * overlapping arrays are not supported by either form.
@@ -81,6 +81,18 @@ const char* mcd_last_error(void);
  * mcd_mvn_release_stream(h, stream) before destroying one: it waits for the stream and returns its set to the handle's pool
  * (sets of captures stay with the capture: its graph may still be replayed).  hipStreamPerThread is keyed per calling thread.
  */
+/*
+ * Test and tuning knobs -- ONE explicit, thread-safe table instead of environment variables read on the hot path (rounds 1-3 called
+ * getenv() per launch: a stray variable silently changed the launch structure and the rounding of a run, and getenv() races with setenv()
+ * in a threaded host such as the reference's, mcmc-date.cabal:42-43).  name = "MCD_MH_SEGMENTS", "MCD_MH_INCREMENTAL", "MCD_MH_PER_PHASE",
+ * "MCD_MH_PRIOR", "MCD_MH_PRIOR_CACHE", "MCD_MH_STEP_WG", "MCD_MH_CHAIN_LW", "MCD_MH_INC_SLOTS", "MCD_MH_SPARSE_SLOTS", "MCD_SPLIT", "MCD_SPLIT_G",
+ * "MCD_SPLIT_SCATTER", "MCD_SPLIT_NOROT", "MCD_SPLIT_PROBE", "MCD_GEOM", "MCD_WIDE_CT", "MCD_SPARSE_QUAD"; value = a decimal integer, NULL or ""
+ * = back to the default.  What each knob does is said where it acts (mcd_mh_run, the forms above).  The environment variables of the same
+ * names are read ONCE, when the library is loaded, as initial values -- never afterwards.  No knob changes a result beyond rounding.
+ */
+int mcd_set_option(const char* name, const char* value);
+int mcd_get_option(const char* name, int* is_set, int* value);
+
 #define MCD_FORM_AUTO 0
 #define MCD_FORM_SWEEP 1
 #define MCD_FORM_MULTIPLY 2
@@ -312,11 +324,17 @@ typedef struct mcd_mh mcd_mh_t;
 int mcd_mh_create(mcd_mh_t** out, const mcd_tree_t* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
                   const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
                   const double* p0, const double* p1, int64_t batch, uint64_t seed);
-/* The same driver over a likelihood whose precision matrix stays sparse on the device (mcd_sparse_tree_create): the reference's
- * configuration for trees with thousands of branches -- `mhg` with likelihoodFunction (Sparse ...) (app/Main.hs:474, 333-347;
- * app/Probability.hs:178-184, 279).  Trees of 321 .. 2048 nodes (smaller ones take the dense handle); two launches per lock step: the
- * step kernel leaves the proposed states' distances, the sparse product runs on them.  Everything else (mcd_mh_set_state, _run,
- * _tune, _mc3_*, ...) as for mcd_mh_create.  The mcd_sparse_tree_t type is declared with the sparse form below. */
+/* The same driver over a likelihood whose precision matrix stays sparse on the device (mcd_sparse_tree_create): the reference's PRODUCTION
+ * configuration -- `mhg` with likelihoodFunction (Sparse ...) (app/Main.hs:474, 257-277, 333-347; app/Probability.hs:178-184, 279); every
+ * published timing of the reference uses it.  Trees of 3 .. 2048 nodes (a Sparse record never has to be densified).  mcd_mh_run takes the
+ * segment structure (MCD_MH_PATH_SEGMENTS_SPARSE): every run of steps between two proposals that move more than 254 distances in ONE launch,
+ * the chains' states in LDS, the quadratic form q = dx^T P dx kept per chain and updated through the ROWS of the moved distances,
+ *     q' = q + sum_{j moved} delta_j sum_k Ps[j][k] (2 dx_k + delta_k),   Ps = (P + P^T) / 2;
+ * such a dense proposal by two launches (the step kernel proposes, the one-launch full form evaluates), q recomputed by a full form every
+ * 256 steps.  On a tree whose distances all fit the list (at most 256 nodes) every proposal runs inside a segment.  MCD_MH_SEGMENTS=0 or
+ * MCD_MH_INCREMENTAL=0 (mcd_set_option): the step kernel + a full product at every step (round 3's structure; the chains: same decisions and
+ * states).  Everything else (mcd_mh_set_state, _run, _tune, _mc3_*, ...) as for mcd_mh_create.  The mcd_sparse_tree_t type is declared with
+ * the sparse form below. */
 struct mcd_sparse_tree;
 int mcd_mh_create_sparse(mcd_mh_t** out, const struct mcd_sparse_tree* tree, const mcd_prior_t* prior, int n_prop, const int32_t* kind,
                          const int32_t* node, const int32_t* n1, const int32_t* n2, const int32_t* jac_root, const int32_t* dim,
@@ -341,9 +359,9 @@ int mcd_mh_get_posterior(const mcd_mh_t* m, double* post);
  * proposal by two launches.  Trees of up to 258 nodes with more than 1024 chains, and trees over a sparse likelihood: two launches per step -- accept the pending
  * proposal and propose the next one; then ln likelihood of the proposed states, which up to 256 dimensions also carries their ln
  * prior as workgroups of a second role (both depend on the proposal only); from 321 nodes the likelihood launch only for proposals that
- * move more than 32 distances (the others: columns of L^-1 on a kept z).  Environment, read per call, for tests and timing:
+ * move more than 32 distances (the others: columns of L^-1 on a kept z).  Knobs (mcd_set_option), for tests and timing:
  * MCD_MH_SEGMENTS=0 / MCD_MH_INCREMENTAL=0 switch the segments / every incremental evaluation off (the chains: same decisions and states),
- * MCD_MH_INC_SLOTS (read by mcd_mh_create) sets the number of moved distances up to which a proposal counts as sparse (at most 256),
+ * MCD_MH_INC_SLOTS (consulted by mcd_mh_create) sets the number of moved distances up to which a proposal counts as sparse (at most 256),
  * MCD_MH_SPARSE_SLOTS the same for the whole-schedule kernel of 65 .. 258 nodes (at most 64), MCD_MH_CHAIN_LW=0 runs the small-tree kernel with
  * one wave per chain (the likelihood then after the prior instead of beside it: the same bits),
  * MCD_MH_PRIOR=0 evaluates the prior inside the first launch everywhere (the chains are the same bits either way),
@@ -362,6 +380,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t ste
 #define MCD_MH_PATH_STEP_WG_INCREMENTAL 6     /* the same, the likelihood launch only for proposals that move many distances (k_mh_inc.hip) */
 #define MCD_MH_PATH_STEP_WG_SPARSE 7          /* workgroup-per-chain step leaving distances + the sparse product on them (mcd_mh_create_sparse) */
 #define MCD_MH_PATH_SEGMENTS 8                /* 259 .. 1026 nodes: every run of steps between two dense proposals in one launch (state in LDS), a dense proposal by path 6's launches */
+#define MCD_MH_PATH_SEGMENTS_SPARSE 9         /* sparse likelihood, 3 .. 2048 nodes: the same with the quadratic form updated through the rows of the moved distances (k_mh_segment_sparse.hip); a dense proposal by the step kernel + the one-launch full form */
 int mcd_mh_last_path(const mcd_mh_t* m);
 /* Auto tuning at the end of a tuning period [mcmc]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3). */
 int mcd_mh_tune(mcd_mh_t* m);
@@ -402,11 +421,16 @@ int mcd_mh_reset_age_sums(mcd_mh_t* m);
  * sigmaInvSparse logDetSigma) (:279) over the operands of getData's SparseS branch (app/Main.hs:95-97: the association list
  * [((i, j), v)] of `prepare`'s graphical-lasso estimate, :142-155, 257-277) -- the reference's route for trees with thousands
  * of branches (tutorial/main/tutorial.org:487-496), beyond MCD_MAX_DIM of the dense kernels.
- *   ll = -N ln sqrt(2 pi) - 1/2 (logdet_sigma + dx^T P dx),  dx = x - mu;   mcd_sparse_grad_batch also returns G = -P dx.
+ *   ll = -N ln sqrt(2 pi) - 1/2 (logdet_sigma + dx^T P dx),  dx = x - mu;   mcd_sparse_grad_batch also returns its gradient
+ *   G = -1/2 (P + P^T) dx  (= -P dx for the symmetric matrices `prepare` writes).
  * row / col / val: the nnz entries in any order, entries of one position are added up; P is used as given (no symmetrisation,
  * no positive-definiteness check: the reference evaluates the form with whatever the .data file holds).  Batches are chain-major
- * like everywhere; trees as in mcd_tree_create.  (mcd_mvn_create with a densified matrix remains the route to the gradient of
- * tree states and to the Metropolis-Hastings / NUTS drivers, N <= MCD_MAX_DIM.)
+ * like everywhere; trees as in mcd_tree_create.  Up to 4096 chains the log-density is ONE launch (a workgroup stages the dx of one or two
+ * chains in LDS and walks the flat stream of the matrix's entries; for an exactly symmetric matrix the upper triangle only), beyond that
+ * three launches with lanes = chains; the two agree to rounding.  (mcd_mvn_create with a densified matrix remains the route to the gradient
+ * of tree states and to the NUTS driver, N <= MCD_MAX_DIM; the Metropolis-Hastings driver takes the sparse handle: mcd_mh_create_sparse.)
+ * mcd_sparse_release_stream: a host that makes short-lived streams calls it before destroying one (the gradient's and the large batches'
+ * scratch buffer of that stream is freed; like mcd_mvn_release_stream).
  */
 #define MCD_MAX_SPARSE_DIM 8192
 typedef struct mcd_sparse mcd_sparse_t;
@@ -416,6 +440,7 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
 void mcd_sparse_destroy(mcd_sparse_t* h);
 int mcd_sparse_dim(const mcd_sparse_t* h);
 int64_t mcd_sparse_nnz(const mcd_sparse_t* h);   /* stored entries after adding up duplicates */
+int mcd_sparse_release_stream(const mcd_sparse_t* h, void* stream /* hipStream_t */);
 int mcd_sparse_logpdf_batch(const mcd_sparse_t* h, const double* X, int64_t ld, int64_t batch, int on_device, void* stream, double* ll);
 int mcd_sparse_grad_batch(const mcd_sparse_t* h, const double* X, int64_t ld, int64_t batch, int on_device, void* stream, double* ll,
                           double* G, int64_t ldg);

@@ -5,7 +5,7 @@ One hot path, hand-written for gfx950, behind the reference's likelihood plugin 
 (app/Probability.hs:277-281).  See DESIGN.md and include/mcmcdate_mvn.h.
 """
 from . import _capi, monitor
-from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating
+from ._capi import McdError, NoDevice, NotPositiveDefinite, RootNotBifurcating, get_option, set_option
 from .likelihood import (Full, LikelihoodData, MvnLikelihood, set_logpdf_form, NoData, Sparse, SparseLikelihood, SparseTreeLikelihood, TreeLikelihood, Univariate,
                          jacobian_root_branch, likelihood_function, read_data_file, write_data_file)
 from .hmc import DualAveraging, Leapfrog, hmc_transition, nuts_transition, nuts_warmup, run_cycle_with_nuts
@@ -26,5 +26,5 @@ __all__ = [
     "load_braces", "get_mean_root_height",
     "MC3", "Proposal", "Sampler", "cycle_schedule", "init_with", "proposals", "table_arrays", "weight_n_branches",
     "Leapfrog", "hmc_transition", "nuts_transition", "nuts_warmup", "run_cycle_with_nuts", "DualAveraging", "get_mask", "to_vector", "from_vector_with", "grad_to_vector", "target_grad",
-    "McdError", "NotPositiveDefinite", "RootNotBifurcating", "NoDevice",
+    "McdError", "NotPositiveDefinite", "RootNotBifurcating", "NoDevice", "set_option", "get_option",
 ]

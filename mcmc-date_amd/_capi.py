@@ -31,6 +31,8 @@ SYMBOLS = {
     "mcd_device_count": (C.c_int, []),
     "mcd_version": (C.c_char_p, []),
     "mcd_last_error": (C.c_char_p, []),
+    "mcd_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "mcd_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mcd_set_logpdf_form": (C.c_int, [C.c_int]),
     "mcd_mvn_set_form": (C.c_int, [_vp, C.c_int]),
     "mcd_mvn_release_stream": (C.c_int, [_vp, _vp]),
@@ -59,6 +61,7 @@ SYMBOLS = {
     "mcd_sparse_destroy": (None, [_vp]),
     "mcd_sparse_dim": (C.c_int, [_vp]),
     "mcd_sparse_nnz": (C.c_int64, [_vp]),
+    "mcd_sparse_release_stream": (C.c_int, [_vp, _vp]),
     "mcd_sparse_logpdf_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp]),
     "mcd_sparse_grad_batch": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_int64]),
     "mcd_sparse_tree_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, _ip]),
@@ -142,6 +145,20 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def set_option(name: str, value=None):
+    """A test / tuning knob of the library (include/mcmcdate_mvn.h: mcd_set_option): value = an integer (or its string), None = back to the
+    default.  The names are the environment variables of rounds 1-3 ("MCD_MH_SEGMENTS", "MCD_SPLIT", ...); the environment itself is read
+    once, when the library is loaded."""
+    check(lib().mcd_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name: str):
+    """The knob's value, or None when it is at its default."""
+    s, v = C.c_int(0), C.c_int(0)
+    check(lib().mcd_get_option(name.encode(), C.byref(s), C.byref(v)))
+    return int(v.value) if s.value else None
 
 
 def check(rc: int):

@@ -90,7 +90,7 @@ int sweep_chunk_columns(int R)
 
 int wide_chain_tiles(int64_t batch)
 {
-    static const int force = getenv("MCD_WIDE_CT") ? atoi(getenv("MCD_WIDE_CT")) : 0;
+    const int force = opt_or(OPT_WIDE_CT, 0);
     if (force == 1 || force == 2 || force == 4) return force;
     // 16 chains per workgroup while that leaves every CU at most one workgroup; 32 above (two workgroups then share a CU:
     // one stages while the other multiplies).  64 (MCD_WIDE_CT=4) measured slower at every size: its LDS chunk fills the CU.
@@ -126,8 +126,7 @@ bool use_split(const MvnDev& M, int64_t batch)
     // 7.4-7.5 us); from 256 chains the sweep's single launch-to-result path is shorter (7.7 against 7.9 us at 512 chains: the split
     // pays about two memory round trips for handing the partial sums over); at N = 200 and 224 (13 / 14 row blocks over 8 groups:
     // uneven) and below the sweep wins everywhere; from 2048 chains k_wide takes over
-    const char* env = getenv("MCD_SPLIT");                 // tests and tuning: 1 = wherever possible, 0 = never (read per launch)
-    const int force = env ? atoi(env) : -1;
+    const int force = opt_or(OPT_SPLIT, -1);               // tests and tuning (mcd_set_option "MCD_SPLIT"): 1 = wherever possible, 0 = never
     if (effective_form(M) != 0 || M.split == nullptr || batch < 1 || batch > kSplitMaxBatch || force == 0) return false;
     if (force == 1) return true;
     if (M.n > 256) return true;
@@ -138,8 +137,7 @@ bool use_split_grad(const MvnDev& M, int64_t batch)
 {
     // the gradient on the row-split schedule: two (tree states: three) launches over 8 row groups x batch / 16 workgroups, where
     // the sweep walks a chain of N / 64 dependent blocks twice and k_wide_grad_mc fills batch / 16 CUs.  MCD_SPLIT as above.
-    const char* env = getenv("MCD_SPLIT");
-    const int force = env ? atoi(env) : -1;
+    const int force = opt_or(OPT_SPLIT, -1);
     if (effective_form(M) != 0 || M.split == nullptr || batch < 1 || batch > kSplitMaxBatch || force == 0) return false;
     if (force == 1) return true;
     return M.n > 256 || (M.n > 240 && batch <= 512);      // (measured: tools/gpu/grad_prof.sh; at N = 224 the sweeps are level or ahead)

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "mh_inc_device.hpp"
+#include "options.h"
 
 #include <atomic>
 #include <type_traits>
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
     int* spar = snode + n;
     const bool dist = X1 != nullptr;
     const bool incr = dist && I.X0 != nullptr;
+    const bool inc_cols = incr && I.prop_mode == 1;        // this launch evaluates its sparse proposal itself (columns of L^-1; dense likelihood, at most 1024 slots)
     const bool cached = prior_inline && M.psum != nullptr;
     const bool cache_init = summands_init != 0;           // the first launch of a run: no summands kept yet
 #ifdef MCD_MHSTEP_STAMP
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
                 tb[w] = bv[k];
                 tc[w] = cv[k];
             }
-            if (incr && w < n_dim) incsh.dl[w] = xv[k];    // (the current distances, until the proposal's are known)
+            if (inc_cols && w < n_dim) incsh.dl[w] = xv[k];   // (the current distances, until the proposal's are known)
         }
         if (ok) {
 #pragma unroll
@@ -508,7 +510,6 @@ __global__ __launch_bounds__(64 * MHW, 2) void k_mh_step_wg(MhDev M, PriorDev P,
     }
     // The incremental evaluation of a sparse proposal (k_mh_inc.hip): which distances moved, in row order -- every wave lists its
     // quarter of the rows, the four lists read one after the other are the row order
-    const bool inc_cols = incr && I.prop_mode == 1;
     if (dist) {
         // The distances of the proposed state, so that the likelihood launch takes them as a plain vector: the proposal is in LDS
         // here, while the row-split kernel's tree staging gathers it from global memory a chain at a time (25.7 against 19.3 us at
@@ -727,8 +728,8 @@ static size_t mh_step_wg_lds(int n_nodes)
 }
 bool mh_step_wg_active(const MhDev& M, int prior_inline, int min_nodes)
 {
-    const char* env = getenv("MCD_MH_STEP_WG");
-    const bool wg = env ? atoi(env) != 0 : (prior_inline && M.n_nodes > min_nodes);
+    const int force = opt_get(OPT_MH_STEP_WG);            // (mcd_set_option "MCD_MH_STEP_WG": 1 / 0 = for every tree / never)
+    const bool wg = force != MCD_OPT_UNSET ? force != 0 : (prior_inline && M.n_nodes > min_nodes);
     return wg && M.n_nodes <= 2048 && mh_step_wg_lds(M.n_nodes) + sizeof(IncShared) <= 144 * 1024;   // (above 64 KiB: allowed at launch)
 }
 

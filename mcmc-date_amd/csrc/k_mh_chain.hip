@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "mh_device.hpp"
+#include "options.h"
 #include "prior_device.hpp"
 
 namespace mcd {
@@ -306,8 +307,7 @@ hipError_t launch_mh_chain(const MhDev& M, const MvnDev& V, const TreeDev& T, co
     } else {
         constexpr int WPB = 1;
         const size_t sh = mh_chain_lds_bytes(V.n, M.n_prop, WPB) + sizeof(double) * prior_node_tables_doubles(P.n_cal, P.n_con);
-        const char* env = getenv("MCD_MH_CHAIN_LW");      // 0: one wave per chain (tests, timing; read per call)
-        if (env && env[0] == '0')
+        if (opt_is(OPT_MH_CHAIN_LW, 0))                   // (mcd_set_option "MCD_MH_CHAIN_LW" = 0: one wave per chain; tests, timing)
             hipLaunchKernelGGL((k_mh_chain<WPB, false>), dim3((unsigned)M.batch), dim3(64), sh, st, M, V, T, P, Fp, sched, n_steps, S, accumulate,
                                step0, seed, trace_alpha, trace_accept);
         else

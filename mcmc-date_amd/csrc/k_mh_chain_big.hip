@@ -33,6 +33,7 @@
 // Reference: the loop this replaces is `mhg`'s iteration of `mcmc` [external] driven from app/Main.hs:460-479 with the cycle of
 // app/Definitions.hs:256-278; likelihood app/Probability.hs:166-173, 195-207; jacobianRootBranch :393-410.
 #include "mvn_device.hpp"
+#include "options.h"
 #include "mh_device.hpp"
 #include "prior_device.hpp"
 
@@ -930,8 +931,7 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
 {
     if (n_steps <= 0) return hipSuccess;
     if (!mh_chain_big_available(M, V)) return hipErrorInvalidValue;
-    const char* env = getenv("MCD_MH_INCREMENTAL");          // 0: every proposal through the full sweep (tests, timing; read per call)
-    if (env && env[0] == '0') {
+    if (opt_is(OPT_MH_INCREMENTAL, 0)) {                     // (mcd_set_option "MCD_MH_INCREMENTAL" = 0: every proposal through the full sweep; tests, timing)
         MvnDev V0 = V;
         V0.Wc = nullptr;
         switch (V.R) {

@@ -24,7 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "mvn_kernels.h"
+#include "options.h"
 
 namespace mcd {
 
@@ -201,20 +204,171 @@ static hipError_t launch_any(const SparseDev& S, const SparseTreeDev& T, const d
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same log-density in ONE launch with no scratch (round 4): a workgroup owns C chains (1 or 2), stages their dx in LDS -- plain
+// vectors coalesced, tree states with the distances formed on the way -- and its 256 threads walk the FLAT stream of the matrix's
+// entries, (row | column << 16, value): 12 coalesced bytes per entry, no row pointers to chase, every load independent of every other;
+// an entry costs two LDS gathers per chain:   q = sum_e v_e dx[row_e] dx[col_e].
+// For an exactly symmetric matrix (what `prepare`'s graphical lasso writes) the stream holds the upper triangle only, off-diagonal
+// values doubled: half the bytes and half the gathers.  Thread t takes the entries t, t + 256, ... in that order, the partial sums
+// are added lane by lane and wave by wave in a fixed order: bit-reproducible.  Three launches and 2 x 8 N B bytes of transposed
+// scratch (above) become one launch: N = 2011 x 512 chains 34.9 -> see DESIGN.md; N = 256 x 512 chains 16.4 -> below the dense sweep.
+// The value agrees with the row form above to rounding (another order of summation), not bit for bit.
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sp_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int C, bool TREE>
+__global__ __launch_bounds__(256) void k_sparse_quad(SparseDev S, SparseTreeDev T, const double* __restrict__ X, const double* __restrict__ Rt, int64_t ld,
+                                                    const double* __restrict__ tH, const double* __restrict__ rMu, int64_t batch,
+                                                    double* __restrict__ ll, double* __restrict__ logjac, double* __restrict__ qout)
+{
+    extern __shared__ double qsh[];                          // [C][n] dx, then [C][4] the waves' partial sums
+    const int n = S.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * C;
+    double* red = qsh + (size_t)C * n;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int64_t b = (b0 + c < batch) ? b0 + c : batch - 1;      // (a chain beyond the batch: the last one again, nothing stored)
+        double* dx = qsh + (size_t)c * n;
+        if constexpr (TREE) {
+            const double* H = X + b * ld;
+            const double* R = Rt + b * ld;
+            const double s = tH[b] * rMu[b];
+            const int rr = T.root_right;
+            for (int j = tid; j < n; j += 256) {
+                const int a = T.slot_node[j], pa = T.slot_parent[j];
+                double d = (H[pa] - H[a]) * R[a];            // heightTreeToLengthTree, times * rates   (app/Probability.hs:201-207)
+                if (j == 0) d = d + (H[0] - H[rr]) * R[rr];  // sumFirstTwo
+                d = d * s;
+                if (j == 0 && logjac && b0 + c < batch) logjac[b] = log(1.0 / d);          // jacobianRootBranch, :393-410
+                dx[j] = d - S.mu[j];
+            }
+        } else {
+            const double* x = X + b * ld;
+            for (int j = tid; j < n; j += 256) dx[j] = x[j] - S.mu[j];
+        }
+    }
+    __syncthreads();
+    double acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0;
+    const int64_t nq = S.q_nnz;
+    constexpr int U = 8;                                     // entries in flight per thread
+    int64_t e = tid;
+    for (; e + (int64_t)(U - 1) * 256 < nq; e += (int64_t)U * 256) {
+        uint32_t rc[U];
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rc[u] = S.q_rc[e + (int64_t)u * 256];
+            v[u] = S.q_val[e + (int64_t)u * 256];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = (int)(rc[u] & 0xFFFFu), k = (int)(rc[u] >> 16);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = fma(v[u] * qsh[(size_t)c * n + r], qsh[(size_t)c * n + k], acc[c]);
+        }
+    }
+    for (; e < nq; e += 256) {
+        const uint32_t rc = S.q_rc[e];
+        const double v = S.q_val[e];
+        const int r = (int)(rc & 0xFFFFu), k = (int)(rc >> 16);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = fma(v * qsh[(size_t)c * n + r], qsh[(size_t)c * n + k], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double w = sp_wave_sum(acc[c]);
+        if (lane == 0) red[c * 4 + wave] = w;
+    }
+    __syncthreads();
+    if (tid < C && b0 + tid < batch) {
+        const double q = ((red[tid * 4 + 0] + red[tid * 4 + 1]) + red[tid * 4 + 2]) + red[tid * 4 + 3];
+        if (qout) qout[b0 + tid] = q;
+        if (ll) ll[b0 + tid] = S.c + (-0.5) * (S.logdet + q);       // :180 (c - 1/2 (logdet + q))
+    }
+}
+
+static size_t sparse_quad_lds(int n, int C) { return sizeof(double) * ((size_t)C * n + 4 * (size_t)C); }
+bool sparse_quad_available(const SparseDev& S, int64_t batch) { return S.q_rc != nullptr && S.n <= 65535 && sparse_quad_lds(S.n, 1) <= 160 * 1024 && batch >= 1; }
+
+template <int C, bool TREE>
+static hipError_t launch_quad_C(const SparseDev& S, const SparseTreeDev& T, const double* X, const double* Rt, int64_t ld, const double* tH, const double* rMu,
+                                int64_t batch, double* ll, double* logjac, double* qout, hipStream_t st)
+{
+    const size_t lds = sparse_quad_lds(S.n, C);
+    if (lds > 64 * 1024) {                                   // more than 64 KiB of LDS has to be allowed once per device
+        static std::atomic<unsigned long long> allowed{0};
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev)) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!((allowed.load(std::memory_order_acquire) >> dev) & 1ull)) {
+            if (hipError_t e = hipFuncSetAttribute((const void*)k_sparse_quad<C, TREE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
+            allowed.fetch_or(1ull << dev, std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL((k_sparse_quad<C, TREE>), dim3((unsigned)((batch + C - 1) / C)), dim3(256), lds, st, S, T, X, Rt, ld, tH, rMu, batch, ll, logjac, qout);
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_quad(const SparseDev& S, const SparseTreeDev* T, const double* X, const double* Rt, int64_t ld, const double* tH,
+                              const double* rMu, int64_t batch, double* ll, double* logjac, double* qout, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    if (!sparse_quad_available(S, batch)) return hipErrorInvalidValue;
+    // two chains per workgroup share a pass over the entry stream once every CU has a workgroup anyway (and while both fit in LDS)
+    const bool two = batch >= 512 && sparse_quad_lds(S.n, 2) <= 160 * 1024;
+    if (T) {
+        if (two) return launch_quad_C<2, true>(S, *T, X, Rt, ld, tH, rMu, batch, ll, logjac, qout, st);
+        return launch_quad_C<1, true>(S, *T, X, Rt, ld, tH, rMu, batch, ll, logjac, qout, st);
+    }
+    if (two) return launch_quad_C<2, false>(S, SparseTreeDev{}, X, nullptr, ld, nullptr, nullptr, batch, ll, nullptr, qout, st);
+    return launch_quad_C<1, false>(S, SparseTreeDev{}, X, nullptr, ld, nullptr, nullptr, batch, ll, nullptr, qout, st);
+}
+
+// which form a log-density launch takes: the one-launch quadratic form up to kSparseQuadMaxBatch chains (a workgroup per one or two chains:
+// the matrix streams through every workgroup), the row form with lanes = chains beyond (the matrix once per 64 chains); mcd_set_option
+// "MCD_SPARSE_QUAD" = 1 / 0 forces / forbids the former (tests, timing)
+constexpr int64_t kSparseQuadMaxBatch = 4096;
+static bool use_quad(const SparseDev& S, int64_t batch)
+{
+    const int force = opt_get(OPT_SPARSE_QUAD);
+    if (!sparse_quad_available(S, batch) || force == 0) return false;
+    return force == 1 || batch <= kSparseQuadMaxBatch;
+}
+
 hipError_t launch_sparse_logpdf(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* scratch, hipStream_t st)
 {
+    if (use_quad(S, batch)) return launch_sparse_quad(S, nullptr, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, nullptr, st);
     return launch_any<false, false>(S, SparseTreeDev{}, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, nullptr, 0, scratch, st);
 }
 
 hipError_t launch_sparse_grad(const SparseDev& S, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg, double* scratch,
                               hipStream_t st)
 {
-    return launch_any<false, true>(S, SparseTreeDev{}, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, G, ldg, scratch, st);
+    // d ll / d x = -1/2 (P + P^T) dx: the product runs over the symmetric part (the matrix itself when it is symmetric -- what `prepare`
+    // writes; for another matrix -P dx would not be the gradient of the value)
+    SparseDev Sy = S;
+    Sy.nnz = S.s_nnz;
+    Sy.rowptr = S.s_rowptr;
+    Sy.trow = S.s_trow;
+    Sy.col = S.s_col;
+    Sy.val = S.s_val;
+    return launch_any<false, true>(Sy, SparseTreeDev{}, X, nullptr, ldx, nullptr, nullptr, batch, ll, nullptr, G, ldg, scratch, st);
 }
 
 hipError_t launch_sparse_tree_logpdf(const SparseDev& S, const SparseTreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                      const double* rMu, int64_t batch, double* ll, double* logjac, double* scratch, hipStream_t st)
 {
+    if (use_quad(S, batch)) return launch_sparse_quad(S, &T, H, Rt, lds, tH, rMu, batch, ll, logjac, nullptr, st);
     return launch_any<true, false>(S, T, H, Rt, lds, tH, rMu, batch, ll, logjac, nullptr, 0, scratch, st);
 }
 

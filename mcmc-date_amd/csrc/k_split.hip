@@ -36,6 +36,7 @@
 #include "wide_device.hpp"
 #include "host_factor.h"
 #include "split_sched.hpp"
+#include "options.h"
 
 #include <stdlib.h>
 #include <atomic>
@@ -905,8 +906,7 @@ hipError_t split_release_stream(SplitHost* s, hipStream_t st)
 
 static int pick_variant(const SplitHost* s, int64_t batch)
 {
-    const char* env = getenv("MCD_SPLIT_G");               // tuning / tests: force G (read per launch)
-    const int force = env ? atoi(env) : 0;
+    const int force = opt_or(OPT_SPLIT_G, 0);              // tuning / tests (mcd_set_option "MCD_SPLIT_G"): force G
     const int64_t tiles = (batch + 15) / 16;
     int best = 0;
     for (int v = 0; v < 3; ++v) {
@@ -930,12 +930,9 @@ static hipError_t launch_split(const MvnDev& M, const WideSrc& A, int64_t batch,
     if (S.G == 0) return hipErrorInvalidValue;
     SplitHost::Set set;
     if (hipError_t e = scratch_for(s, st, MODE == 1, set)) return e;
-    const char* env = getenv("MCD_SPLIT_SCATTER");         // tests: a tile's row groups on different XCDs (read per launch)
-    int scatter = env ? (atoi(env) & 1) : 0;
-    env = getenv("MCD_SPLIT_NOROT");
-    if (env && atoi(env)) scatter |= 2;
-    env = getenv("MCD_SPLIT_PROBE");                       // timing probes (results are then garbage): 4 launch only, 8 + staging, 16 all but the hand-over
-    if (env) scatter |= atoi(env) & 28;
+    int scatter = opt_or(OPT_SPLIT_SCATTER, 0) & 1;        // tests (mcd_set_option "MCD_SPLIT_SCATTER"): a tile's row groups on different XCDs
+    if (opt_or(OPT_SPLIT_NOROT, 0)) scatter |= 2;
+    scatter |= opt_or(OPT_SPLIT_PROBE, 0) & 28;            // timing probes (results are then garbage): 4 launch only, 8 + staging, 16 all but the hand-over
     const bool probe = (scatter & 28) != 0;
 
     const int64_t tiles = (batch + 15) / 16;

@@ -14,6 +14,7 @@
 
 #include "../../include/mcmcdate_mvn.h"
 #include "mvn_kernels.h"
+#include "options.h"
 
 extern "C" int mcd_set_last_error_(int code, const char* msg);   // mvn_capi.cpp
 struct mcd_sparse;
@@ -74,6 +75,7 @@ struct mcd_mh {
     int8_t* d_trace_accept = nullptr;
     size_t trace_cap = 0;
     int last_path = MCD_MH_PATH_NONE;   // which launch structure the last mcd_mh_run took
+    bool list_all = false;              // sparse likelihood on a tree whose distance slots all fit the segment kernel's list
     // Metropolis-coupled MCMC (mcd_mh_mc3_*): temperature ranks of all GLOBAL chains, ladder, counters; phase = swap phases done
     mcd::Mc3Dev mc3{};
     uint64_t mc3_seed = 0, mc3_phase = 0;
@@ -223,20 +225,26 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
     // (sparse_inc: the same for the two-launch path's incremental evaluation, k_mh_inc.hip, whose list of moved distances is not bounded
     // by registers: up to kMhIncSlots columns of L^-1 still cost less than a likelihood launch.)
     std::vector<int32_t> sparse((size_t)n_prop, 0), sparse_inc((size_t)n_prop, 0);
-    const char* env_slots = getenv("MCD_MH_INC_SLOTS");
+    const int opt_slots = mcd::opt_get(mcd::OPT_MH_INC_SLOTS);      // (mcd_set_option "MCD_MH_INC_SLOTS", read here)
     // (where the segment kernel runs the sparse proposals, k_mh_segment.hip, many more: a likelihood launch there also costs the whole
     // state's way through memory twice; measured at 1025 nodes x 512 chains: 16 -> 22.5, 64 -> 14.2, 128 -> 12.7, 192 -> 12.5 us per lock step)
     mcd::MhDev probe{};
     probe.n_nodes = n;
     probe.batch = batch;
     const bool seg_capable = m->mvn != nullptr && mcd::mh_segment_available(probe, *m->mvn);
-    const int inc_slots = env_slots ? std::max(1, std::min(mcd::kMhSegList, atoi(env_slots))) : seg_capable ? mcd::kMhSegSlots : mcd::kMhIncSlots;
+    // (over a sparse precision matrix, k_mh_segment_sparse.hip: a listed distance costs a row of the matrix, some 15 entries, where the
+    // two launches of a dense proposal cost a full product -- whatever the list holds)
+    const bool sseg_capable = m->sp != nullptr && mcd::mh_segment_sparse_available(probe, *m->sp);
+    const int list_cap = sseg_capable ? mcd::mh_segment_sparse_list() : mcd::kMhSegList;
+    const int inc_slots = opt_slots != mcd::MCD_OPT_UNSET ? std::max(1, std::min(list_cap, opt_slots)) : sseg_capable ? list_cap : seg_capable ? mcd::kMhSegSlots : mcd::kMhIncSlots;
+    // a tree whose distance slots ALL fit the sparse segment kernel's list: every proposal of the cycle can run inside a segment
+    m->list_all = sseg_capable && m->sp->n <= list_cap;
     for (int pass = 0; pass < 2; ++pass) {
-        const char* env_ss = getenv("MCD_MH_SPARSE_SLOTS");      // (the streaming chain kernel's threshold; tuning)
+        const int opt_ss = mcd::opt_get(mcd::OPT_MH_SPARSE_SLOTS);      // (the streaming chain kernel's threshold; tuning: mcd_set_option "MCD_MH_SPARSE_SLOTS")
         // (up to 258 nodes the chain's likelihood wave takes the columns four at a time beside the prior: 48; above, where the chain wave
         // itself fetches them two at a time -- the sweep-only builds of the larger trees, which otherwise run in segments --: 16)
         const int big_default = (m->mvn != nullptr && m->mvn->R <= 4) ? mcd::kMhSparseSlots : 16;
-        const int limit = pass ? inc_slots : env_ss ? std::max(1, std::min(64, atoi(env_ss))) : big_default;      // (64: the kernel's list, kMhbList)
+        const int limit = pass ? inc_slots : opt_ss != mcd::MCD_OPT_UNSET ? std::max(1, std::min(64, opt_ss)) : big_default;      // (64: the kernel's list, kMhbList)
         std::vector<std::vector<int>> kids((size_t)n);
         for (int v = 1; v < n; ++v) kids[(size_t)parent[v]].push_back(v);
         auto slots_of = [&](const std::vector<int>& nodes) {
@@ -274,7 +282,7 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
                     break;
                 default: known = false; break;                         // scalars, whole-tree scalings, pulley, root slide
             }
-            (pass ? sparse_inc : sparse)[(size_t)i] = (known && slots_of(touched) <= limit) ? 1 : 0;
+            (pass ? sparse_inc : sparse)[(size_t)i] = ((known && slots_of(touched) <= limit) || (pass && m->list_all)) ? 1 : 0;
         }
     }
     m->sparse_rows = sparse_inc;
@@ -312,9 +320,8 @@ int mh_create_impl(mcd_mh_t** out, std::unique_ptr<mcd_mh>& m, const mcd_prior_t
         return rc;
     // trees of at most 64 nodes: the whole schedule runs in one launch with the factor staged in LDS (k_mh_chain.hip).
     // MCD_MH_PER_PHASE=1 (diagnostic) keeps the two-launches-per-step path that larger trees use.
-    const char* per_phase = getenv("MCD_MH_PER_PHASE");
     const int nd = m->mvn ? m->mvn->n : m->sp->n;
-    if (m->mvn && n <= 64 && !(per_phase && per_phase[0] == '1') && mcd::mh_chain_lds_bytes(nd, n_prop, 4) + sizeof(double) * mcd::prior_node_tables_doubles(m->prior->n_cal, m->prior->n_con) <= 64 * 1024) {
+    if (m->mvn && n <= 64 && !mcd::opt_is(mcd::OPT_MH_PER_PHASE, 1) && mcd::mh_chain_lds_bytes(nd, n_prop, 4) + sizeof(double) * mcd::prior_node_tables_doubles(m->prior->n_cal, m->prior->n_con) <= 64 * 1024) {
         std::vector<double> Fp((size_t)nd * 64, 0.0);
         for (int i = 0; i < nd; ++i) {
             const double inv = 1.0 / host_L[(size_t)i * nd + i];
@@ -373,9 +380,8 @@ int mcd_mh_create_sparse(mcd_mh_t** out, const mcd_sparse_tree_t* tree, const mc
     const int32_t* parent = nullptr;
     if (mcd_sparse_tree_internal_(tree, &m->sp_handle, &m->sp, &m->sp_tree, &dev_t, &parent) || mcd_prior_internal_(prior, &m->prior, &dev_p))
         return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_create_sparse: invalid handle");
-    if (m->sp_tree->n_nodes <= 320 || m->sp_tree->n_nodes > 2048)
-        return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_create_sparse: %d nodes (the sparse driver serves trees of 321 .. 2048 nodes; smaller ones take the dense handle)",
-                     m->sp_tree->n_nodes);
+    if (m->sp_tree->n_nodes < 3 || m->sp_tree->n_nodes > 2048)
+        return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_create_sparse: %d nodes (the sparse driver serves trees of 3 .. 2048 nodes)", m->sp_tree->n_nodes);
     m->tree_shim = mcd::TreeDev{m->sp_tree->n_nodes, (m->sp_tree->n_nodes + 63) / 64 * 64, m->sp_tree->root_right, m->prior->parent, m->sp_tree->slot_node,
                                 m->sp_tree->slot_parent, nullptr, nullptr};
     m->tree = &m->tree_shim;
@@ -563,15 +569,14 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
     }
     // larger trees at a sampler's batch: the whole schedule in one launch as well, the factor streamed once per step
     // (k_mh_chain_big.hip).  MCD_MH_PER_PHASE=1 keeps the two-launch path (tests, timing; read per call).
-    const char* per_phase_env = getenv("MCD_MH_PER_PHASE");
+    const bool per_phase = mcd::opt_is(mcd::OPT_MH_PER_PHASE, 1);
+    const bool seg_off = mcd::opt_is(mcd::OPT_MH_SEGMENTS, 0), inc_off = mcd::opt_is(mcd::OPT_MH_INCREMENTAL, 0);
     // From 259 nodes (R >= 6) the segment path below is ahead of it (271 nodes x 512 chains 11.3 -> 9.6 us per lock step, 513 nodes
     // 16.0 -> 9.6): the factor streamed for every dense proposal costs more there than two launches for the few proposals that
     // move more than 192 distances.  MCD_MH_SEGMENTS=0 / MCD_MH_INCREMENTAL=0 keep the streaming kernel.
-    const char* env_seg0 = getenv("MCD_MH_SEGMENTS");
-    const char* env_inc0 = getenv("MCD_MH_INCREMENTAL");
-    const bool prefer_segments = m->mvn && !m->chain_kernel && !(env_seg0 && env_seg0[0] == '0') && !(env_inc0 && env_inc0[0] == '0') &&
+    const bool prefer_segments = m->mvn && !m->chain_kernel && !seg_off && !inc_off &&
                                  mcd::mh_segment_available(D, *m->mvn) && mcd::use_split(*m->mvn, std::min<int64_t>(D.batch, mcd::kSplitMaxBatch));
-    const bool streaming = m->mvn && !m->chain_kernel && !(per_phase_env && per_phase_env[0] == '1') && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
+    const bool streaming = m->mvn && !m->chain_kernel && !per_phase && mcd::effective_form(*m->mvn) != MCD_FORM_MULTIPLY &&
                            mcd::mh_chain_big_available(D, *m->mvn) && !prefer_segments;
     if (streaming) {
         m->last_path = MCD_MH_PATH_CHAIN_STREAMED;
@@ -607,15 +612,15 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // likelihood launch, that launch carries the prior as workgroups of a second role (k_tree_logpdf.hip, mh_prior_role.hpp)
         // and k_mh_step leaves it out; elsewhere (row-split / multiply form) k_mh_step evaluates it as before.  Same functions
         // on the same numbers either way: the same chains.  MCD_MH_PRIOR=0 keeps it inside the step everywhere (tests, timing).
-        const char* env_prior = getenv("MCD_MH_PRIOR");
+        const bool prior_in_step = mcd::opt_is(mcd::OPT_MH_PRIOR, 0);
         // (A launch of its own for the prior with four waves per chain was measured for the larger trees: 58.9 -> 56.4 us per
         // lock step at 1025 nodes, 33.3 -> 35.4 at 513 -- the step kernel's other strided loops weigh more there; not kept.)
-        const bool beside = m->mvn && !prefer_segments && !(env_prior && atoi(env_prior) == 0) && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
+        const bool beside = m->mvn && !prefer_segments && !prior_in_step && mcd::tree_logpdf_can_carry_prior(*m->mvn, D.batch, D.n_nodes);
         const int prior_inline = beside ? 0 : 1;
         // large trees: the step kernel (a workgroup per chain) leaves the proposed states' DISTANCES, the likelihood launch takes
         // them as plain vectors (the row-split kernel's tree staging costs 6 us more at 1023 slots); same arithmetic, same bits
         const int n_dim = m->mvn ? m->mvn->n : m->sp->n;
-        const int wg_from = prefer_segments ? 258 : 320;   // (the workgroup-per-chain step kernel: the only one that leaves distances)
+        const int wg_from = m->sp ? 0 : prefer_segments ? 258 : 320;   // (the workgroup-per-chain step kernel: the only one that leaves distances)
         const bool use_x = mcd::mh_step_wg_active(D, prior_inline, wg_from) && !beside && D.n_nodes > wg_from;
         if (m->sp && !use_x) return mfail(MCD_ERR_UNSUPPORTED, "mcd_mh_run: the sparse driver needs the workgroup-per-chain step kernel (MCD_MH_STEP_WG must not be 0)");
         if (use_x && m->d_X1 == nullptr) {
@@ -625,8 +630,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // the workgroup-per-chain step kernel keeps the per-node summands of the ln prior between launches (k_mh.hip: psum);
         // MCD_MH_PRIOR_CACHE=0: every summand at every step
         {
-            const char* env_cache = getenv("MCD_MH_PRIOR_CACHE");
-            const bool keep = prior_inline && mcd::mh_step_wg_active(D, prior_inline, wg_from) && !(env_cache && env_cache[0] == '0');
+            const bool keep = prior_inline && mcd::mh_step_wg_active(D, prior_inline, wg_from) && !mcd::opt_is(mcd::OPT_MH_PRIOR_CACHE, 0);
             if (keep && m->d_psum == nullptr) {
                 const size_t NS = (size_t)((D.n_nodes - 1 + 63) / 64) * 64;
                 MHIP_TRY(hipMalloc((void**)&m->d_psum, sizeof(double) * (size_t)D.batch * 4 * NS));
@@ -642,14 +646,28 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         double* X1 = use_x ? m->d_X1 : nullptr;
         // Large trees at a sampler's batch: the likelihood launch only for the proposals that move many distances (k_mh_inc.hip);
         // the others are evaluated from columns of L^-1 on the kept z.  MCD_MH_INCREMENTAL=0: the full evaluation at every step.
-        const char* env_inc = getenv("MCD_MH_INCREMENTAL");
         // (batches beyond the row-split kernel's 1024 chains: its z products chunk by chunk, z' of a dense proposal copied to zprop)
-        const bool inc = m->mvn && use_x && !(env_inc && env_inc[0] == '0') && m->mvn->Wc != nullptr && 64 * m->mvn->R <= 1024 &&
-                         mcd::use_split(*m->mvn, std::min<int64_t>(D.batch, mcd::kSplitMaxBatch));
-        const bool chunked = D.batch > mcd::kSplitMaxBatch;
-        const int dense_mode = chunked ? 1 : 2;              // where the z' of a dense proposal is afterwards: zprop or the z tiles
+        const bool inc_dense = m->mvn && use_x && !inc_off && m->mvn->Wc != nullptr && 64 * m->mvn->R <= 1024 &&
+                               mcd::use_split(*m->mvn, std::min<int64_t>(D.batch, mcd::kSplitMaxBatch));
+        // Over a sparse precision matrix (k_mh_segment_sparse.hip) the incremental form keeps the quadratic form q itself: MhInc with
+        // NPz = 1 -- zcur / zprop = q of the current states / of the pending dense proposal -- so that k_mh_step_wg's accept half moves
+        // X1 -> X0 and q' -> q like it moves z' -> z.  It exists only together with the segments.
+        const bool inc_sparse = m->sp && use_x && !inc_off && !seg_off && mcd::mh_segment_sparse_available(D, *m->sp) && mcd::sparse_quad_available(*m->sp, D.batch);
+        const bool inc = inc_dense || inc_sparse;
+        const bool chunked = inc_dense && D.batch > mcd::kSplitMaxBatch;
+        const int dense_mode = (chunked || inc_sparse) ? 1 : 2;   // where the z' (q') of a dense proposal is afterwards: zprop or the z tiles
+        static const mcd::MvnDev no_mvn{};                   // (k_mh_step_wg takes the incremental bookkeeping only with an MvnDev beside it)
+        const mcd::MvnDev* Vinc = m->mvn ? m->mvn : &no_mvn;
         mcd::MhInc& I = m->inc;
-        if (inc && I.X0 == nullptr) {
+        if (inc_sparse && I.X0 == nullptr) {
+            I.NPz = 1;
+            MHIP_TRY(hipMalloc((void**)&I.X0, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
+            m->allocs.push_back(I.X0);
+            MHIP_TRY(hipMalloc((void**)&I.zcur, sizeof(double) * 2 * (size_t)D.batch));
+            m->allocs.push_back(I.zcur);
+            I.zprop = I.zcur + D.batch;
+        }
+        if (inc_dense && I.X0 == nullptr) {
             I.NPz = 64 * m->mvn->R;
             MHIP_TRY(hipMalloc((void**)&I.X0, sizeof(double) * (size_t)D.batch * (size_t)n_dim));
             m->allocs.push_back(I.X0);
@@ -663,6 +681,10 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // ll and z = L^-1 (X - mu) of every chain by full products (the row-split kernel, at most 1024 chains per launch); z to dst
         // (chain-major) -- or, for a batch of one launch and dst = null, left in that launch's z tiles
         auto z_product = [&](const double* X, double* ll, double* dst) -> int {
+            if (inc_sparse) {                                // the full form in one launch (k_sparse.hip: k_sparse_quad): ll and q (dst)
+                MHIP_TRY(mcd::launch_sparse_quad(*m->sp, nullptr, X, nullptr, n_dim, nullptr, nullptr, D.batch, ll, nullptr, dst, m->stream));
+                return MCD_OK;
+            }
             for (int64_t c0 = 0; c0 < D.batch; c0 += mcd::kSplitMaxBatch) {
                 const int64_t cnt = std::min<int64_t>(mcd::kSplitMaxBatch, D.batch - c0);
                 MHIP_TRY(mcd::launch_logpdf_split_z(*m->mvn, X + c0 * n_dim, n_dim, cnt, ll + c0, &I.zt, &I.nr, m->stream));
@@ -670,7 +692,9 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
             }
             return MCD_OK;
         };
-        auto refresh_z = [&]() -> int { return z_product(I.X0, m->d_inc_ll, I.zcur); };      // (the ll of that product is not used)
+        // (dense: the ll of that product is not used -- q is |z'|^2 afresh at every step; sparse: q itself is what is kept, and the chains' ln
+        // likelihood is set to the recomputed value with it, so that the two stay the same number)
+        auto refresh_z = [&]() -> int { return z_product(I.X0, inc_sparse ? D.post + D.batch : m->d_inc_ll, I.zcur); };
         if (inc) {
             I.mode = 0;
             MHIP_TRY(mcd::launch_mh_inc_init(D, *m->tree, I, n_dim, n_dim, m->stream));
@@ -681,8 +705,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         // Trees of 259 .. 1026 nodes: the runs of steps between two dense proposals as ONE launch each, every chain's state in LDS from
         // the run's first step to its last (k_mh_chain_big.hip, SEG); a dense proposal as before: proposed by the step kernel, its
         // likelihood by the row-split launch, accepted by the step kernel.  MCD_MH_SEGMENTS=0: every step by the two launches.
-        const char* env_seg = getenv("MCD_MH_SEGMENTS");
-        const bool segments = inc && !(env_seg && env_seg[0] == '0') && mcd::mh_segment_available(D, *m->mvn) && I.NPz == 64 * m->mvn->R;
+        const bool segments = inc_sparse || (inc_dense && !seg_off && mcd::mh_segment_available(D, *m->mvn) && I.NPz == 64 * m->mvn->R);
         if (segments) {
             bool summands_kept = false;                      // MhDev::psum holds the current states' summands
             int64_t draws_block = 0;                         // (draws_for(0) above)
@@ -702,9 +725,15 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 if (inc_mode(schedule[gs]) != 2) {
                     int64_t e = gs + 1;                      // ... up to the next recomputation of z (every 256 steps)
                     while (e < total && inc_mode(schedule[e]) != 2 && (e & 255) != 0) ++e;
-                    MHIP_TRY(mcd::launch_mh_segment(D, *m->mvn, *m->tree, *m->prior, I, m->d_sched + gs, e - gs, S, accumulate ? 1 : 0, step_base + (uint64_t)gs,
-                                                    m->seed, trace ? m->d_trace_alpha + gs * B : nullptr, trace ? m->d_trace_accept + gs * B : nullptr, gs,
-                                                    summands_kept ? 1 : 0, have_pending ? &pending : nullptr, m->stream));
+                    if (inc_sparse)
+                        MHIP_TRY(mcd::launch_mh_segment_sparse(D, *m->sp, *m->tree, *m->prior, I, m->d_sched + gs, e - gs, S, accumulate ? 1 : 0,
+                                                               step_base + (uint64_t)gs, m->seed, trace ? m->d_trace_alpha + gs * B : nullptr,
+                                                               trace ? m->d_trace_accept + gs * B : nullptr, gs, summands_kept ? 1 : 0,
+                                                               have_pending ? &pending : nullptr, m->list_all ? 1 : 0, m->stream));
+                    else
+                        MHIP_TRY(mcd::launch_mh_segment(D, *m->mvn, *m->tree, *m->prior, I, m->d_sched + gs, e - gs, S, accumulate ? 1 : 0, step_base + (uint64_t)gs,
+                                                        m->seed, trace ? m->d_trace_alpha + gs * B : nullptr, trace ? m->d_trace_accept + gs * B : nullptr, gs,
+                                                        summands_kept ? 1 : 0, have_pending ? &pending : nullptr, m->stream));
                     have_pending = false;
                     if (D.psum != nullptr) summands_kept = true;
                     if (accumulate) m->n_samples += (e / S) - (gs / S);          // iterations closed by steps gs .. e - 1
@@ -719,11 +748,11 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                 I.mode = 0;
                 I.prop_mode = 2;
                 MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[gs], m->rows[schedule[gs]], (int)(gs & 63), m->step, m->seed, 0, nullptr,
-                                             nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, m->mvn, summands_kept ? 0 : 1));
+                                             nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, Vinc, summands_kept ? 0 : 1));
                 if (D.psum != nullptr) summands_kept = true;
                 while (true) {
                     const int pa = schedule[gs];
-                    if (int rc = z_product(X1, D.post1 + D.batch, chunked ? I.zprop : nullptr)) return rc;
+                    if (int rc = z_product(X1, D.post1 + D.batch, (chunked || inc_sparse) ? I.zprop : nullptr)) return rc;
                     I.mode = dense_mode;
                     const bool closes = ((gs + 1) % S) == 0;
                     const bool refresh_now = ((gs + 1) & 255) == 0;
@@ -748,7 +777,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                     I.prop_mode = 2;
                     MHIP_TRY(mcd::launch_mh_step(D, *m->prior, pa, m->rows[pa].jac_root, pn, pn >= 0 ? m->rows[pn] : none, (int)((gs + 1) & 63), m->step,
                                                  m->seed, (accumulate && closes) ? 1 : 0, trace ? m->d_trace_alpha + gs * B : nullptr,
-                                                 trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, m->mvn, 0));
+                                                 trace ? m->d_trace_accept + gs * B : nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, Vinc, 0));
                     if (refresh_now && gs + 1 < total)
                         if (int rc = refresh_z()) return rc;
                     m->step += 1;
@@ -757,7 +786,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                     if (pn < 0) break;
                 }
             }
-            m->last_path = MCD_MH_PATH_SEGMENTS;
+            m->last_path = inc_sparse ? MCD_MH_PATH_SEGMENTS_SPARSE : MCD_MH_PATH_SEGMENTS;
         } else {
         I.prop_mode = inc ? inc_mode(schedule[0]) : 0;
         MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[0], m->rows[schedule[0]], 0, m->step - 1, m->seed, 0, nullptr, nullptr,

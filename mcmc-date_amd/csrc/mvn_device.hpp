@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "mvn_kernels.h"
+#include "options.h"
 
 namespace mcd {
 
@@ -194,6 +195,9 @@ __device__ __forceinline__ void stage_load(Stage<R, LW>& st, const double* __res
         st.v[SET][i] = reinterpret_cast<const d2*>(F)[((size_t)p * R + k) * 64 + lane];
     }
 }
+// (Measured and dropped in round 4: the lanes of a DIAGONAL row block's unit that hold stored zeros -- rows up to the unit's first column,
+// about a fifth of the whole stream at R = 4 -- not loading but staging the zero themselves.  Fewer bytes, but the exec-masked loads and the
+// selects in the loaders' issue stream cost far more than the bytes saved: 7.6 -> 13.5 us per launch at N = 256 x 512 chains, same bits.)
 
 template <int R, int LW, int KLO, int KHI, int SET>
 __device__ __forceinline__ void stage_store(const Stage<R, LW>& st, d2* slot, int lw, int lane)
@@ -683,9 +687,9 @@ static inline Geometry pick_geometry(int64_t batch)
     // Up to 4096 chains: 4 compute waves per workgroup keep the grid within one wave of workgroups
     // per CU for longer (measured at N = 256, B = 1024: 9.5 us against 14.4 us).
     // More: 4 compute waves x 2 chains share each pass over the factor.
-    const char* env = getenv("MCD_GEOM");                // tuning: "21" | "41" | "42" = compute waves, chains per wave (read per launch)
-    if (env && env[0] == '2') return {2, 2, 1};
-    if (env && env[0] == '4') return {4, 2, env[1] == '2' ? 2 : 1};
+    const int force = opt_get(OPT_GEOM);                 // tuning (mcd_set_option "MCD_GEOM"): 21 | 41 | 42 = compute waves, chains per wave
+    if (force == 21) return {2, 2, 1};
+    if (force == 41 || force == 42) return {4, 2, force == 42 ? 2 : 1};
     if (batch <= 512) return {2, 2, 1};
     if (batch <= 4096) return {4, 2, 1};
     return {4, 2, 2};

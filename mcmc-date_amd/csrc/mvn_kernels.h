@@ -124,6 +124,18 @@ struct SparseDev {
     const double* val;       // [nnz]
     const double* mu;        // [n]
     double c, logdet;        // -N ln sqrt(2 pi), log det Sigma
+    // the one-launch quadratic form (k_sparse_quad): the entries as a flat stream, (row | column << 16, value); when the matrix is
+    // exactly symmetric only its upper triangle, off-diagonal values doubled
+    int64_t q_nnz;
+    const uint32_t* q_rc;    // [q_nnz]
+    const double* q_val;     // [q_nnz]
+    // the symmetric part (P + P^T) / 2 in CSR -- the matrix itself when it is symmetric: the gradient -1/2 (P + P^T) dx and the
+    // incremental form of the Metropolis-Hastings driver (k_mh_segment_sparse.hip: the rows of the moved distances)
+    int64_t s_nnz;
+    const int32_t* s_rowptr;   // [n + 1]
+    const int32_t* s_trow;     // [s_nnz]
+    const int32_t* s_col;      // [s_nnz]
+    const double* s_val;       // [s_nnz]
 };
 struct SparseTreeDev {
     int n_nodes, root_right;
@@ -138,6 +150,12 @@ hipError_t launch_sparse_grad(const SparseDev& S, const double* X, int64_t ldx, 
                               hipStream_t st);
 hipError_t launch_sparse_tree_logpdf(const SparseDev& S, const SparseTreeDev& T, const double* H, const double* Rt, int64_t lds, const double* tH,
                                      const double* rMu, int64_t batch, double* ll, double* logjac, double* scratch, hipStream_t st);
+// ONE launch, no scratch: a workgroup stages the dx of one or two chains in LDS and walks the flat entry stream (k_sparse.hip: k_sparse_quad);
+// T != null: tree states (X = heights, Rt = rates, ld = their row stride; logjac may be null), else X = plain vectors; ll and qout
+// (the quadratic form dx^T P dx itself; what the Metropolis-Hastings driver keeps per chain) may each be null
+bool sparse_quad_available(const SparseDev& S, int64_t batch);
+hipError_t launch_sparse_quad(const SparseDev& S, const SparseTreeDev* T, const double* X, const double* Rt, int64_t ld, const double* tH,
+                              const double* rMu, int64_t batch, double* ll, double* logjac, double* qout, hipStream_t st);
 
 // Metropolis-coupled MCMC (k_mc3.hip): the temperature rank of every GLOBAL chain, the ladder of reciprocal temperatures and the
 // swap counters per rung; all pointers are device memory.
@@ -172,6 +190,13 @@ struct MhSegPending {          // a dense proposal that is still to be decided w
     int z_in_zprop;            // its z' is in MhInc::zprop (batches beyond 1024 chains: taken there chunk by chunk), not in the z tiles
 };
 bool mh_segment_available(const MhDev& M, const MvnDev& V);
+// the same over a sparse precision matrix (k_mh_segment_sparse.hip); I: X0 = current distances [batch][n], zcur / zprop = the quadratic
+// forms q [batch] of the current states / of the pending dense proposal (NPz = 1)
+bool mh_segment_sparse_available(const MhDev& M, const SparseDev& Sp);
+int mh_segment_sparse_list();      // moved distances of one proposal at most
+hipError_t launch_mh_segment_sparse(const MhDev& M, const SparseDev& Sp, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
+                                    int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
+                                    int64_t gs_base, int summands_kept, const MhSegPending* pending, int list_all, hipStream_t st);
 hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
                              int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha, int8_t* trace_accept,
                              int64_t gs_base, int summands_kept, const MhSegPending* pending, hipStream_t st);

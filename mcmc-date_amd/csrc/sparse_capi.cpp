@@ -75,6 +75,10 @@ int scratch_for(const mcd_sparse* h, hipStream_t st, size_t doubles, double** ou
     std::lock_guard<std::mutex> lock(h->mu);
     auto& e = h->scratch[st];
     if (e.second < doubles) {
+        // growing frees the old buffer: a graph captured on this stream earlier has its address baked in -- refuse while a capture is open
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone && e.first != nullptr)
+            return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse: the stream's scratch would have to grow during a stream capture (make the largest call once before capturing)");
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;      // (legal while the calling thread captures a stream)
         (void)hipThreadExchangeStreamCaptureMode(&mode);
         if (e.first) (void)hipFree(e.first);                          // waits for the device: earlier launches are done with it
@@ -185,6 +189,70 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
         return rc;
     h->dev.n = n;
     h->dev.nnz = (int64_t)vv.size();
+    {
+        // Is the matrix exactly symmetric (pattern and values)?  `prepare`'s graphical-lasso estimate is (app/Main.hs:257-277); a hand-made
+        // .data file need not be.  The symmetric part Ps = (P + P^T) / 2 in CSR serves the gradient -Ps dx and the Metropolis-Hastings
+        // driver's incremental form (rows of the moved distances); for a symmetric matrix it IS the matrix (no second copy).
+        const size_t nz = vv.size();
+        bool symmetric = true;
+        auto find = [&](int r, int c) -> int64_t {
+            const int32_t* lo = cc.data() + rowptr[(size_t)r];
+            const int32_t* hi = cc.data() + rowptr[(size_t)r + 1];
+            const int32_t* it = std::lower_bound(lo, hi, (int32_t)c);
+            return (it != hi && *it == c) ? (int64_t)(it - cc.data()) : -1;
+        };
+        for (size_t e = 0; e < nz && symmetric; ++e) {
+            const int64_t t = find(cc[e], rr[e]);
+            symmetric = t >= 0 && vv[(size_t)t] == vv[e];
+        }
+        if (symmetric) {
+            h->dev.s_nnz = (int64_t)nz;
+            h->dev.s_rowptr = h->dev.rowptr;
+            h->dev.s_trow = h->dev.trow;
+            h->dev.s_col = h->dev.col;
+            h->dev.s_val = h->dev.val;
+        } else {
+            // merge row i of P with column i of P (= row i of P^T): entries (i, k) -> (P[i][k] + P[k][i]) / 2
+            std::vector<std::vector<std::pair<int32_t, double>>> rows((size_t)n);
+            for (size_t e = 0; e < nz; ++e) {
+                rows[(size_t)rr[e]].push_back({cc[e], 0.5 * vv[e]});
+                rows[(size_t)cc[e]].push_back({rr[e], 0.5 * vv[e]});
+            }
+            std::vector<int32_t> sp((size_t)n + 1, 0), sc, sr;
+            std::vector<double> sv;
+            for (int i = 0; i < n; ++i) {
+                auto& r = rows[(size_t)i];
+                std::stable_sort(r.begin(), r.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
+                for (size_t q = 0; q < r.size(); ++q) {
+                    if (q > 0 && r[q - 1].first == r[q].first) {
+                        sv.back() += r[q].second;
+                        continue;
+                    }
+                    sc.push_back(r[q].first);
+                    sr.push_back(i);
+                    sv.push_back(r[q].second);
+                }
+                sp[(size_t)i + 1] = (int32_t)sc.size();
+            }
+            h->dev.s_nnz = (int64_t)sv.size();
+            if ((rc = upload(h.get(), &h->dev.s_rowptr, sp.data(), sp.size())) || (rc = upload(h.get(), &h->dev.s_col, sc.data(), sc.size())) ||
+                (rc = upload(h.get(), &h->dev.s_trow, sr.data(), sr.size())) || (rc = upload(h.get(), &h->dev.s_val, sv.data(), sv.size())))
+                return rc;
+        }
+        // the flat entry stream of the one-launch form: (row | column << 16, value); a symmetric matrix as its upper triangle with the
+        // off-diagonal values doubled
+        if (n <= 65535) {
+            std::vector<uint32_t> qrc;
+            std::vector<double> qv;
+            for (size_t e = 0; e < nz; ++e) {
+                if (symmetric && cc[e] < rr[e]) continue;
+                qrc.push_back((uint32_t)rr[e] | ((uint32_t)cc[e] << 16));
+                qv.push_back((symmetric && cc[e] != rr[e]) ? 2.0 * vv[e] : vv[e]);
+            }
+            h->dev.q_nnz = (int64_t)qv.size();
+            if ((rc = upload(h.get(), &h->dev.q_rc, qrc.data(), qrc.size())) || (rc = upload(h.get(), &h->dev.q_val, qv.data(), qv.size()))) return rc;
+        }
+    }
     h->dev.c = -(0.9189385332046727417803297364056176 * (double)n);   // m_ln_sqrt_2_pi * k, Probability.hs:181-183
     h->dev.logdet = logdet_sigma;
     *out = h.release();
@@ -192,6 +260,19 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
 }
 
 void mcd_sparse_destroy(mcd_sparse_t* h) { delete h; }
+
+int mcd_sparse_release_stream(const mcd_sparse_t* h, void* stream)
+{
+    if (!h) return sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_release_stream: NULL handle");
+    SHIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lock(h->mu);
+    auto it = h->scratch.find((hipStream_t)stream);
+    if (it == h->scratch.end()) return MCD_OK;
+    SHIP_TRY(hipStreamSynchronize((hipStream_t)stream));    // the launches that use the buffer have run
+    if (it->second.first) (void)hipFree(it->second.first);
+    h->scratch.erase(it);
+    return MCD_OK;
+}
 int mcd_sparse_dim(const mcd_sparse_t* h) { return h ? h->n : sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_dim: NULL handle"); }
 int64_t mcd_sparse_nnz(const mcd_sparse_t* h) { return h ? h->dev.nnz : (int64_t)sfail(MCD_ERR_INVALID_ARG, "mcd_sparse_nnz: NULL handle"); }
 

@@ -32,3 +32,36 @@ def gpu():
 
     mcmc_date_amd._capi.lib()
     return torch.device("cuda:0")
+
+
+class _Knobs:
+    """The library's test / tuning knobs (mcd_set_option) with monkeypatch's setenv / delenv spelling: the names are the environment
+    variables of rounds 1-3, which the library no longer reads after it has been loaded.  Every knob touched goes back to its default at
+    the end of the test."""
+
+    def __init__(self):
+        self.touched = set()
+
+    def setenv(self, name, value):
+        import mcmc_date_amd as M
+
+        M.set_option(name, value)
+        self.touched.add(name)
+
+    def delenv(self, name, raising=True):
+        import mcmc_date_amd as M
+
+        M.set_option(name, None)
+
+    def restore(self):
+        import mcmc_date_amd as M
+
+        for name in self.touched:
+            M.set_option(name, None)
+
+
+@pytest.fixture
+def knobs():
+    k = _Knobs()
+    yield k
+    k.restore()

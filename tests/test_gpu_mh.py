@@ -102,7 +102,7 @@ def test_lockstep_parity_other_clock_models(gpu, golden, model):
     compare_states(smp, twin)
 
 
-def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
+def test_chain_kernel_equals_per_phase_kernels(gpu, golden, knobs):
     """Trees of at most 64 nodes run the whole schedule in one launch (k_mh_chain.hip); larger trees use two
     launches per step (k_mh.hip + k_tree_logpdf.hip).  Same arithmetic in the same order: bit-identical chains."""
     fx = golden["25-leaves-bastien"]
@@ -110,11 +110,11 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
     sched = M.cycle_schedule(ps, 3, np.random.default_rng(8))
     a1, k1 = fused.run_schedule(sched, accumulate=True, trace=True)
     assert fused.last_path().startswith("whole schedule in one launch, factor resident in LDS")
-    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")             # (read when the handle is made and at every run)
+    knobs.setenv("MCD_MH_PER_PHASE", "1")             # (read when the handle is made and at every run)
     _, _, phased, _ = setup(fx, B=12, seed=5)
     a2, k2 = phased.run_schedule(sched, accumulate=True, trace=True)
     assert phased.last_path().startswith("two launches per lock step")
-    monkeypatch.delenv("MCD_MH_PER_PHASE")
+    knobs.delenv("MCD_MH_PER_PHASE")
     assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2)
     s1, s2 = fused.state(), phased.state()
     for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
@@ -125,14 +125,14 @@ def test_chain_kernel_equals_per_phase_kernels(gpu, golden, monkeypatch):
 
 
 @pytest.mark.parametrize("dataset", ["12-leaves-variable-rate", "25-leaves-bastien"])
-def test_chain_kernel_with_a_likelihood_wave(gpu, golden, dataset, monkeypatch):
+def test_chain_kernel_with_a_likelihood_wave(gpu, golden, dataset, knobs):
     """Trees of at most 64 nodes, fewer than 1024 chains: a second wave per chain evaluates the ln likelihood of the proposed state while
     the chain's wave evaluates the ln prior (k_mh_chain.hip, LW).  The same instructions on the same numbers as the one-wave kernel
     (MCD_MH_CHAIN_LW=0): bit-identical traces, states, posteriors, counters and age sums -- with calibrations, constraints, braces."""
     fx = golden[dataset]
     runs = []
     for lw in ("1", "0"):
-        monkeypatch.setenv("MCD_MH_CHAIN_LW", lw)
+        knobs.setenv("MCD_MH_CHAIN_LW", lw)
         topo, ps, smp, _ = setup(fx, B=37, seed=5)
         sched = M.cycle_schedule(ps, 3, np.random.default_rng(8))
         a, k = smp.run_schedule(sched, accumulate=True, trace=True)
@@ -146,7 +146,7 @@ def test_chain_kernel_with_a_likelihood_wave(gpu, golden, dataset, monkeypatch):
 
 
 @pytest.mark.parametrize("n_leaves,B", [(12, 10), (70, 6), (129, 512), (129, 700), (200, 40), (513, 96)])
-def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, monkeypatch):
+def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, knobs):
     """Two-launch path: by default the likelihood launch carries the ln prior of the proposed states as workgroups of a second
     role (k_tree_logpdf.hip PRIOR variant, mh_prior_role.hpp); MCD_MH_PRIOR=0 evaluates it inside k_mh_step as before.  The same
     wave-level functions on the same numbers: bit-identical acceptance ratios, decisions, states, posteriors, age sums -- with
@@ -155,7 +155,7 @@ def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, mon
     stays inside the step: both settings are then the same launches."""
     from mcmc_date_amd import synthetic as S
 
-    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")              # (the 23-node tree would otherwise run the whole-schedule kernel)
+    knobs.setenv("MCD_MH_PER_PHASE", "1")              # (the 23-node tree would otherwise run the whole-schedule kernel)
     topo = S.random_topology(n_leaves, seed=21)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=21)
@@ -169,15 +169,15 @@ def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, mon
         runs = []
         for inside in (False, True):
             if inside:
-                monkeypatch.setenv("MCD_MH_PRIOR", "0")
+                knobs.setenv("MCD_MH_PRIOR", "0")
             else:
-                monkeypatch.delenv("MCD_MH_PRIOR", raising=False)
+                knobs.delenv("MCD_MH_PRIOR", raising=False)
             lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
             smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, [], topo), ps, B, seed=13)
             smp.set_state(s0)
             a, k = smp.run_schedule(sched, accumulate=True, trace=True)
             runs.append((a, k, smp.state(), smp.posterior(), smp.age_sums()[:2]))
-        monkeypatch.delenv("MCD_MH_PRIOR", raising=False)
+        knobs.delenv("MCD_MH_PRIOR", raising=False)
         (a1, k1, s1, p1, g1), (a2, k2, s2, p2, g2) = runs
         assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
         for f in ("heights", "rates", "time_height", "rate_mean", "rate_variance", "time_birth_rate", "time_death_rate"):
@@ -186,14 +186,14 @@ def test_prior_beside_the_likelihood_gives_the_same_chains(gpu, n_leaves, B, mon
 
 
 @pytest.mark.parametrize("n_leaves,B", [(12, 10), (129, 64), (200, 40), (513, 96)])
-def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkeypatch):
+def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, knobs):
     """Trees of more than 320 nodes take the step kernel with a workgroup of four waves per chain (k_mh_step_wg: threads = nodes
     for the copies, worker waves for the per-node summands of the ln prior, added up in the one-wave order); MCD_MH_STEP_WG=1 / 0
     force it / the one-wave kernel for any tree.  Bit-identical chains: traces, states, posteriors, age sums."""
     from mcmc_date_amd import synthetic as S
 
-    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
-    monkeypatch.setenv("MCD_MH_INCREMENTAL", "0")            # (the incremental likelihood of the large-tree path has its own test below)
+    knobs.setenv("MCD_MH_PER_PHASE", "1")
+    knobs.setenv("MCD_MH_INCREMENTAL", "0")            # (the incremental likelihood of the large-tree path has its own test below)
     topo = S.random_topology(n_leaves, seed=41)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=41)
@@ -205,12 +205,12 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
     sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :300]
     for model, inside in (("UncorrelatedGamma", True), ("UncorrelatedWhiteNoise", True), ("UncorrelatedGamma", False)):
         if inside:
-            monkeypatch.setenv("MCD_MH_PRIOR", "0")          # the prior inside the step: the part the two kernels do differently
+            knobs.setenv("MCD_MH_PRIOR", "0")          # the prior inside the step: the part the two kernels do differently
         else:
-            monkeypatch.delenv("MCD_MH_PRIOR", raising=False)   # beside the likelihood (N <= 256): the kernels only leave the flags
+            knobs.delenv("MCD_MH_PRIOR", raising=False)   # beside the likelihood (N <= 256): the kernels only leave the flags
         runs = []
         for wg in ("1", "0"):
-            monkeypatch.setenv("MCD_MH_STEP_WG", wg)
+            knobs.setenv("MCD_MH_STEP_WG", wg)
             lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
             smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, [], topo), ps, B, seed=13)
             smp.set_state(s0)
@@ -225,7 +225,7 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, monkey
 
 @pytest.mark.parametrize("n_leaves,B", [(33, 9), (40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777), (150, 64), (193, 33), (257, 512)])
 @pytest.mark.parametrize("incremental", ["1", "0"])
-def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, incremental, monkeypatch):
+def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, incremental, knobs):
     """Trees of 65 .. 514 nodes at up to 1024 chains (777: two rounds of workgroups) run the whole schedule in one launch, two
     chains per workgroup, the factor streamed through the sweep's LDS ring (k_mh_chain_big.hip; 150 / 193 / 257 leaves = 299 / 385 /
     513 nodes: six and eight 64-row blocks per lane).  The same proposal, prior and sweep
@@ -237,7 +237,7 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
     tolerance, and the accept / reject decisions, states, ln priors, ln Jacobians, counters are still the same bits."""
     from mcmc_date_amd import synthetic as S
 
-    monkeypatch.setenv("MCD_MH_INCREMENTAL", incremental)
+    knobs.setenv("MCD_MH_INCREMENTAL", incremental)
     exact = incremental == "0"
     topo = S.random_topology(n_leaves, seed=51)
     n = topo.n_nodes - 2
@@ -266,9 +266,9 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
         runs = []
         for phased in (False, True):
             if phased:
-                monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
+                knobs.setenv("MCD_MH_PER_PHASE", "1")
             else:
-                monkeypatch.delenv("MCD_MH_PER_PHASE", raising=False)
+                knobs.delenv("MCD_MH_PER_PHASE", raising=False)
             lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
             lik.mvn.set_form("sweep")                        # (the two-launch path would take the row split at 240 < N <= 256, <= 128 chains)
             smp = M.Sampler(lik, M.PriorFunction(1.0, model, cal, con, braces, topo), ps, B, seed=13)
@@ -279,12 +279,12 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
                 assert smp.last_path().startswith("whole schedule in one launch, two chains per workgroup")
             # the last 60 steps by the OTHER path: what one path leaves behind, the other continues from
             if phased:
-                monkeypatch.delenv("MCD_MH_PER_PHASE", raising=False)
+                knobs.delenv("MCD_MH_PER_PHASE", raising=False)
             else:
-                monkeypatch.setenv("MCD_MH_PER_PHASE", "1")
+                knobs.setenv("MCD_MH_PER_PHASE", "1")
             a2, k2 = smp.run_schedule(sched[:, 200:], accumulate=True, trace=True)
             runs.append((np.concatenate([a, a2]), np.concatenate([k, k2]), smp.state(), smp.posterior(), smp.tuning(), smp.age_sums()[:2]))
-        monkeypatch.delenv("MCD_MH_PER_PHASE", raising=False)
+        knobs.delenv("MCD_MH_PER_PHASE", raising=False)
         (a1, k1, s1, p1, t1, g1), (a2, k2, s2, p2, t2, g2) = runs
         assert np.array_equal(k1, k2) and 0.02 < k1.mean() < 0.98
         fin = np.isfinite(a2)
@@ -301,7 +301,7 @@ def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, increme
 
 
 @pytest.mark.parametrize("n_leaves,B", [(200, 40), (513, 64), (513, 5), (300, 33), (300, 1100), (200, 2100)])
-def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
+def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, knobs):
     """Trees of more than 320 nodes at a sampler's batch (399, 599 and 1025 nodes here; an odd batch leaves a workgroup of the segment
     kernel with one chain; 1100 chains: beyond one launch of the row-split kernel, its z products are taken chunk by chunk): the workgroup-per-chain step kernel with the likelihood launch only for the proposals that move many
     distances (k_mh_inc.hip; the others: columns of L^-1 on a z kept in global memory, refreshed by a full product every 256 steps)
@@ -310,7 +310,7 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
     and ln Jacobians bit for bit, ln acceptance ratios and ln likelihoods within the twin's tolerance."""
     from mcmc_date_amd import synthetic as S
 
-    monkeypatch.setenv("MCD_MH_PER_PHASE", "1")              # (399 nodes would otherwise take the streaming chain kernel)
+    knobs.setenv("MCD_MH_PER_PHASE", "1")              # (399 nodes would otherwise take the streaming chain kernel)
     topo = S.random_topology(n_leaves, seed=61)
     n = topo.n_nodes - 2
     mu, sigma = S.random_spd_problem(n, seed=61)
@@ -337,8 +337,8 @@ def test_incremental_likelihood_on_large_trees(gpu, n_leaves, B, monkeypatch):
         sched = sched[:, :1500]
     runs = []
     for inc, seg in (("1", "1"), ("1", "0"), ("0", "0")):
-        monkeypatch.setenv("MCD_MH_INCREMENTAL", inc)
-        monkeypatch.setenv("MCD_MH_SEGMENTS", seg)
+        knobs.setenv("MCD_MH_INCREMENTAL", inc)
+        knobs.setenv("MCD_MH_SEGMENTS", seg)
         lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
         smp = M.Sampler(lik, M.PriorFunction(1.0, "UncorrelatedGamma", cal, [], braces, topo), ps, B, seed=13)
         smp.set_state(s0)

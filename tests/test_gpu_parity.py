@@ -172,7 +172,7 @@ def test_synthetic_logpdf_and_grad(gpu, n, batch):
 
 
 @pytest.mark.parametrize("n,batch", [(193, 64), (200, 65), (224, 130), (255, 1000), (256, 512), (256, 1024), (241, 77), (256, 1), (230, 5), (199, 17), (129, 1), (160, 100), (192, 128)])
-def test_row_split_form(gpu, n, batch, monkeypatch):
+def test_row_split_form(gpu, n, batch, knobs):
     """128 < N <= 256 through the row-split form (k_split.hip; forced here with MCD_SPLIT=1 -- the automatic choice takes it at
     these sizes only up to 32 chains, see tests/test_gpu_split.py for N > 256): W's row blocks split over 8 workgroups per chain
     tile, partial sums added by the row group that started last.  Oracle bound of the sweeps, ragged tiles, padded rows,
@@ -180,7 +180,7 @@ def test_row_split_form(gpu, n, batch, monkeypatch):
     import threading
     import torch
 
-    monkeypatch.setenv("MCD_SPLIT", "1")
+    knobs.setenv("MCD_SPLIT", "1")
 
     mu, sigma = S.random_spd_problem(n, seed=n)
     X = S.sample_chains(mu, sigma, batch, seed=n + 7)

@@ -39,7 +39,7 @@ def test_reference_sparse_operands_mtcdnapri(gpu):
     dense = M.MvnLikelihood(lhd)
     assert np.max(np.abs(ll - dense.logpdf(X)) / np.maximum(1.0, np.abs(ref))) <= 1e-10
     ll_g, G = sp.grad(X)
-    assert np.array_equal(ll_g, ll)
+    assert np.allclose(ll_g, ll, rtol=1e-13, atol=0)        # (the gradient call takes the row form, the value call the one-launch form: rounding)
     assert np.allclose(G, -(an.sigma_inv @ (X - lhd.mu).T).T, rtol=1e-12, atol=1e-12 * np.abs(G).max())
     # states
     topo = an.topo
@@ -80,7 +80,7 @@ def test_thousand_taxa(gpu):
     for b in (0, 17, 36):
         assert abs(ll[b] - O.logpdf_sparse(mu, coo.row, coo.col, coo.data, logdet, X[b])) <= 1e-12 * abs(ref[b])
     ll2, G = sp.grad(Xd)
-    assert np.array_equal(ll2.cpu().numpy(), ll)
+    assert np.allclose(ll2.cpu().numpy(), ll, rtol=1e-13, atol=0)     # (row form beside the one-launch form: another order of summation)
     Gref = -(P @ dx.T).T
     assert np.max(np.abs(G.cpu().numpy() - Gref)) <= 1e-12 * np.abs(Gref).max()
     assert np.array_equal(sp.logpdf(X), ll)                  # host pointers: the same bits
@@ -138,19 +138,12 @@ def test_structural_faults_and_duplicates(gpu):
         sp.bind_tree(M.Topology(np.array([-1, 0, 1, 1, 0, 4, 4], dtype=np.int32)))     # 7 nodes: dimension 5, not 3
 
 
-@pytest.mark.parametrize("n_leaves,B,n_steps", [(200, 16, 200), (1007, 8, 60)])
-def test_metropolis_hastings_over_a_sparse_likelihood(gpu, n_leaves, B, n_steps):
-    """The lock-step driver over a likelihood whose precision matrix stays sparse on the device (mcd_mh_create_sparse): the
-    reference's configuration for large trees -- `mhg` with likelihoodFunction (Sparse ...) -- at 399 nodes and at the size of its
-    1007-taxon example (2013 nodes, N = 2011: beyond the dense kernels).  Step by step against the CPU twin, which evaluates the
-    same precision matrix densely: identical accept / reject decisions, ln acceptance ratios within the twin's tolerance, final
-    states within 1e-9."""
+def _sparse_problem(n_leaves, B):
     from mcmc_date_amd import synthetic as S
 
     topo = S.random_topology(n_leaves, seed=9)
     n = topo.n_nodes - 2
     P, assoc = banded_random_precision(n, seed=n)
-    rng = np.random.default_rng(10)
     s0 = S.random_states(topo, B, seed=11)
     s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
     # the mean vector near the states' distances, so that ln likelihoods are of the size a sampler sees
@@ -158,6 +151,19 @@ def test_metropolis_hastings_over_a_sparse_likelihood(gpu, n_leaves, B, n_steps)
     mu = D.mean(axis=0)
     Pd = P.toarray()
     logdet = -float(np.linalg.slogdet(Pd)[1])
+    return topo, P, Pd, assoc, mu, logdet, s0
+
+
+@pytest.mark.parametrize("n_leaves,B,n_steps", [(7, 8, 700), (40, 16, 600), (200, 16, 200), (513, 64, 300), (1007, 8, 60), (1007, 512, 600)])
+def test_metropolis_hastings_over_a_sparse_likelihood(gpu, n_leaves, B, n_steps):
+    """The lock-step driver over a likelihood whose precision matrix stays sparse on the device (mcd_mh_create_sparse): the
+    reference's production configuration -- `mhg` with likelihoodFunction (Sparse ...), app/Main.hs:474, 257-277; app/Probability.hs:
+    178-184 -- from a 13-node tree (every proposal inside a segment: all distances fit the list) over 399 and 1025 nodes (two chains per
+    workgroup) to the size of its 1007-taxon example (2013 nodes, N = 2011, one chain per workgroup; 512 chains x 600 lock steps, two
+    recomputations of q).  Segments (k_mh_segment_sparse.hip): the quadratic form updated through the rows of the moved distances.
+    Step by step against the CPU twin, which evaluates the same precision matrix densely at every step: identical accept / reject
+    decisions, ln acceptance ratios within the twin's tolerance, final states within 1e-9."""
+    topo, P, Pd, assoc, mu, logdet, s0 = _sparse_problem(n_leaves, B)
     sp = M.SparseLikelihood(M.Sparse(mu, assoc, logdet))
     tl = sp.bind_tree(topo)
     pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
@@ -169,10 +175,11 @@ def test_metropolis_hastings_over_a_sparse_likelihood(gpu, n_leaves, B, n_steps)
                       s0.time_height, s0.heights, s0.rate_mean, s0.rate_variance, s0.rates, seed=13)
     post0 = smp.posterior()
     assert np.allclose(post0[:, 1], twin_ll(topo, s0, mu, P, logdet), rtol=1e-11)
-    sched = M.cycle_schedule(ps, 1, np.random.default_rng(0))[:, :n_steps]
+    cyc = M.cycle_schedule(ps, 1, np.random.default_rng(0))
+    sched = np.tile(cyc, (1, n_steps // cyc.shape[1] + 1))[:, :n_steps]
     tol = 1e-8 + 1e-12 * np.abs(post0[:, :2]).max()
     ta, tk = smp.run_schedule(sched, trace=True)
-    assert "sparse product" in smp.last_path()
+    assert "segments over a sparse precision matrix" in smp.last_path()
     ra, rk = twin.run(sched, trace=True)
     fin = np.isfinite(ra)
     assert np.array_equal(np.isfinite(ta), fin) and np.all(np.abs(ta[fin] - ra[fin]) <= tol + 1e-10 * np.abs(ra[fin]))
@@ -181,12 +188,85 @@ def test_metropolis_hastings_over_a_sparse_likelihood(gpu, n_leaves, B, n_steps)
     for a, b in ((s.time_height, twin.tH), (s.heights, twin.H), (s.rate_mean, twin.rMu), (s.rates, twin.R)):
         assert np.allclose(a, b, rtol=1e-9, atol=0)
     assert np.allclose(smp.posterior(), twin.post, rtol=1e-11, atol=tol)
-    with pytest.raises(M.McdError):                          # small trees take the dense handle
-        small = S.random_topology(20, seed=1)
-        Ps, assoc_s = banded_random_precision(small.n_nodes - 2, seed=1)
-        tls = M.SparseLikelihood(M.Sparse(np.full(small.n_nodes - 2, 0.1), assoc_s, 0.0)).bind_tree(small)
-        pss, _ = M.proposals(small, [], calibrations_available=True)
-        M.Sampler(tls, M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], small), pss, 4, seed=1)
+
+
+@pytest.mark.parametrize("n_leaves,B,n_steps", [(7, 5, 600), (200, 33, 700), (1007, 6, 300)])
+def test_sparse_segments_against_a_full_product_at_every_step(gpu, n_leaves, B, n_steps, knobs):
+    """The same chains with the segments (incremental quadratic form, q recomputed every 256 steps) and with round 3's structure -- the
+    step kernel and a full product at every step (knob MCD_MH_SEGMENTS = 0): identical decisions, states, ln priors and ln Jacobians;
+    ln likelihoods to rounding.  An odd batch (a workgroup with one chain missing); runs continued by the other structure."""
+    topo, P, Pd, assoc, mu, logdet, s0 = _sparse_problem(n_leaves, B)
+    tl = M.SparseLikelihood(M.Sparse(mu, assoc, logdet)).bind_tree(topo)
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    cyc = M.cycle_schedule(ps, 1, np.random.default_rng(1))
+    sched = np.tile(cyc, (1, n_steps // cyc.shape[1] + 1))[:, :n_steps]
+    out = {}
+    for seg in ("1", "0"):
+        knobs.setenv("MCD_MH_SEGMENTS", seg)
+        smp = M.Sampler(tl, pf, ps, B, seed=21)
+        smp.set_state(s0)
+        ta, tk = smp.run_schedule(sched, trace=True)
+        assert ("segments over a sparse" in smp.last_path()) == (seg == "1") and ("sparse product" in smp.last_path()) == (seg == "0")
+        knobs.setenv("MCD_MH_SEGMENTS", "0" if seg == "1" else "1")      # ... and continued by the other structure
+        tb, tkb = smp.run_schedule(sched[:, :97], trace=True)
+        out[seg] = (ta, tk, tb, tkb, smp.state(), smp.posterior())
+    a, b = out["1"], out["0"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    for x, y in ((a[0], b[0]), (a[2], b[2])):
+        fin = np.isfinite(y)
+        assert np.array_equal(np.isfinite(x), fin) and np.all(np.abs(x[fin] - y[fin]) <= 1e-9 + 1e-11 * np.abs(y[fin]))
+    for f in ("time_birth_rate", "time_death_rate", "time_height", "heights", "rate_mean", "rate_variance", "rates"):
+        assert np.array_equal(getattr(a[4], f), getattr(b[4], f)), f
+    assert np.array_equal(a[5][:, 0], b[5][:, 0]) and np.array_equal(a[5][:, 2], b[5][:, 2])
+    assert np.allclose(a[5][:, 1], b[5][:, 1], rtol=1e-11, atol=1e-9)
+
+
+def test_one_launch_form_against_the_row_form(gpu, knobs):
+    """The one-launch quadratic form (k_sparse_quad: a workgroup per one or two chains, the flat entry stream; upper triangle for a
+    symmetric matrix) against the three-launch row form (lanes = chains) and scipy.sparse: symmetric and non-symmetric matrices, batches
+    that take one and two chains per workgroup, tree states; the gradient of a non-symmetric matrix is -1/2 (P + P^T) dx."""
+    import torch
+
+    from mcmc_date_amd import synthetic as S
+
+    rng = np.random.default_rng(3)
+    for n, B, symmetric in ((11, 5, True), (255, 700, True), (2011, 513, True), (300, 64, False), (8001, 3, True)):
+        P, assoc = banded_random_precision(n, seed=n)
+        if not symmetric:
+            assoc = [((i, j), v * (1.3 if i < j else 1.0)) for (i, j), v in assoc]
+            P = sps.coo_matrix(([v for _, v in assoc], ([ij[0] for ij, _ in assoc], [ij[1] for ij, _ in assoc])), shape=(n, n)).tocsr()
+        mu = rng.uniform(0.01, 0.2, n)
+        sp = M.SparseLikelihood(M.Sparse(mu, assoc, 0.3))
+        X = mu + 0.01 * rng.standard_normal((B, n))
+        dx = X - mu
+        ref = -n * 0.9189385332046727 - 0.5 * (0.3 + np.einsum("bi,bi->b", dx, (P @ dx.T).T))
+        got = {}
+        for form in ("1", "0"):
+            knobs.setenv("MCD_SPARSE_QUAD", form)
+            got[form] = sp.logpdf(X)
+            assert np.max(np.abs(got[form] - ref) / np.abs(ref)) <= 1e-12, (n, B, form)
+            Xd = torch.as_tensor(X, device="cuda")
+            assert np.array_equal(sp.logpdf(Xd).cpu().numpy(), got[form])      # device-resident = host-pointer, bit for bit
+        knobs.delenv("MCD_SPARSE_QUAD")
+        ll_g, G = sp.grad(X)
+        Ps = 0.5 * (P + P.T)
+        assert np.allclose(G, -(Ps @ dx.T).T, rtol=1e-12, atol=1e-13 * np.abs(G).max())
+        assert np.max(np.abs(ll_g - ref) / np.abs(ref)) <= 1e-12
+    # tree states through the one-launch form
+    topo = S.random_topology(129, seed=4)
+    n = topo.n_nodes - 2
+    P, assoc = banded_random_precision(n, seed=n)
+    mu = rng.uniform(0.01, 0.2, n)
+    st = S.random_states(topo, 70, seed=5)
+    tl = M.SparseLikelihood(M.Sparse(mu, assoc, 0.0)).bind_tree(topo)
+    res = {}
+    for form in ("1", "0"):
+        knobs.setenv("MCD_SPARSE_QUAD", form)
+        res[form] = tl.loglik(st)
+    assert np.allclose(res["1"][0], res["0"][0], rtol=1e-12) and np.array_equal(res["1"][1], res["0"][1])
+    reft, refj = O.tree_loglik_full_batch(topo.parent, st.heights, st.rates, st.time_height, st.rate_mean, mu, P.toarray(), 0.0)
+    assert np.max(np.abs(res["1"][0] - reft) / np.maximum(1.0, np.abs(reft))) <= 1e-11 and np.allclose(res["1"][1], refj, rtol=1e-13, atol=0)
 
 
 def twin_ll(topo, st, mu, P, logdet):

@@ -25,27 +25,30 @@ LN_SQRT_2PI = 0.9189385332046727
 
 
 class env:
-    """Set environment variables the launcher reads per launch (MCD_SPLIT_G, MCD_SPLIT_SCATTER) for a block."""
+    """Set knobs of the launcher (mcd_set_option: MCD_SPLIT, MCD_SPLIT_G, MCD_SPLIT_SCATTER) for a block -- until round 3 these were
+    environment variables read per launch."""
 
     def __init__(self, **kv):
         self.kv = {k: str(v) for k, v in kv.items()}
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
+        import mcmc_date_amd as M
+
+        self.old = {k: M.get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            M.set_option(k, v)
 
     def __exit__(self, *a):
+        import mcmc_date_amd as M
+
         for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+            M.set_option(k, v)
 
 
 @pytest.fixture(autouse=True)
 def split_wherever_possible():
     """The automatic choice takes the row split above N = 256 (240 < N <= 256: up to 128 chains); these tests exercise it over
-    its whole range (N > 128, up to 1024 chains): MCD_SPLIT=1, read per launch."""
+    its whole range (N > 128, up to 1024 chains): the knob MCD_SPLIT = 1."""
     with env(MCD_SPLIT=1):
         yield
 

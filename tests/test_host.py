@@ -33,6 +33,67 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.mcd_version()
 
 
+def _haskell_imports(path):
+    """(symbol, number of arguments) of every `foreign import ccall` of a Haskell source file (function pointers `&sym` skipped)."""
+    src = open(path).read()
+    src = re.sub(r"--.*", "", src)
+    out = []
+    for m in re.finditer(r'foreign import ccall\s+(?:safe|unsafe)?\s*"(&?)(mcd_[a-z_0-9]+)"\s*\n?\s*\w+\s*::(.*?)(?=\n\s*\n|\nforeign|\ncheck|\Z)', src, flags=re.S):
+        if m.group(1) == "&":
+            continue
+        sig = m.group(3)
+        depth, parts, cur = 0, [], ""
+        i = 0
+        while i < len(sig):                                  # split on top-level "->"
+            c = sig[i]
+            if c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+            if depth == 0 and sig[i:i + 2] == "->":
+                parts.append(cur)
+                cur = ""
+                i += 2
+                continue
+            cur += c
+            i += 1
+        parts.append(cur)
+        out.append((m.group(2), len(parts) - 1))
+    return out
+
+
+def test_haskell_bindings_name_real_symbols_with_the_headers_arity():
+    """haskell/McmcDate/Gpu.hs (the literal drop-in + raw bindings) and GpuSampler.hs (the replacement of runMetropolisHastingsGreen,
+    app/Main.hs:460-479) cannot be compiled here (no GHC); what CAN be checked: every `foreign import ccall` names a symbol the library
+    exports, with as many arguments as the header declares -- and the sampler module imports every mcd_mh_* entry point its loop needs."""
+    need = {"mcd_mh_create", "mcd_mh_create_sparse", "mcd_mh_destroy", "mcd_mh_set_state", "mcd_mh_get_state", "mcd_mh_run", "mcd_mh_tune",
+            "mcd_mh_get_age_sums", "mcd_mh_reset_age_sums", "mcd_mh_mc3_init", "mcd_mh_mc3_swap", "mcd_mh_mc3_get", "mcd_mh_last_path"}
+    for name in ("Gpu.hs", "GpuSampler.hs"):
+        imps = _haskell_imports(os.path.join(ROOT, "haskell", "McmcDate", name))
+        assert len(imps) >= 15, name
+        for sym, n_args in imps:
+            assert sym in _capi.SYMBOLS, f"{name}: {sym} is not in the C ABI"
+            assert n_args == len(_capi.SYMBOLS[sym][1]), f"{name}: {sym} takes {len(_capi.SYMBOLS[sym][1])} arguments, the import has {n_args}"
+        if name == "GpuSampler.hs":
+            assert need <= {s for s, _ in imps}, need - {s for s, _ in imps}
+
+
+def test_options_table():
+    """mcd_set_option / mcd_get_option: one explicit table instead of getenv on the hot path; unknown names are refused."""
+    M.set_option("MCD_MH_SEGMENTS", 0)
+    assert M.get_option("MCD_MH_SEGMENTS") == 0
+    M.set_option("MCD_MH_SEGMENTS", None)
+    assert M.get_option("MCD_MH_SEGMENTS") is None
+    with pytest.raises(M.McdError):
+        M.set_option("MCD_NO_SUCH_KNOB", 1)
+    src = ""
+    for f in os.listdir(os.path.join(ROOT, "mcmc-date_amd", "csrc")):
+        if f.endswith((".hip", ".hpp", ".cpp", ".h")) and f not in ("options.cpp", "options.h"):
+            src += open(os.path.join(ROOT, "mcmc-date_amd", "csrc", f)).read()
+    # the only getenv left outside options.cpp: the load-time seed of the process default form (MCD_WIDE)
+    assert len(re.findall(r"\bgetenv\(", src)) == 2 and src.count('getenv("MCD_WIDE")') == 2
+
+
 def test_no_device_is_a_loud_error_not_a_fallback():
     lib = _capi.lib()
     if lib.mcd_device_count() > 0:
