@@ -35,13 +35,15 @@
 // app/Definitions.hs:256-278; likelihood app/Probability.hs:166-173, 195-207; jacobianRootBranch :393-410.
 #include "mvn_device.hpp"
 #include "mh_segment_device.hpp"
+#include "options.h"
 
 #include <atomic>
 
 namespace mcd {
 
-template <int R>
-__global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDev T, PriorDev P, MhInc I, const int32_t* __restrict__ sched,
+// HELP: two more waves per chain evaluate the birth-death and the clock block of the ln prior beside the chain wave (mh_segment_device.hpp)
+template <int R, bool HELP>
+__global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDev T, PriorDev P, MhInc I, const int32_t* __restrict__ sched,
                                                     int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed,
                                                     double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int64_t gs_base,
                                                     int summands_kept, MhSegPending Q)
@@ -50,6 +52,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cs = wave & 1;                                 // which of the workgroup's two chains
+    const int role = wave >> 1;                              // 0 the chain wave, 1 the likelihood wave, 2 / 3 the prior waves (HELP)
+    constexpr int NT = HELP ? 512 : 256;
     const int nn = M.n_nodes;
     const int NPad = 64 * R;
     const int64_t B = M.batch;
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     int32_t* l_j = reinterpret_cast<int32_t*>(l_delta + kSegList);
     int32_t* mark = l_j + kSegList;                          // [NPad] the step (+ 1) that last listed the slot
     SegWords* words = reinterpret_cast<SegWords*>(reinterpret_cast<double*>(mark + NPad));
-    PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(words) + 8);
+    SegHelpWords* help = reinterpret_cast<SegHelpWords*>(reinterpret_cast<double*>(words) + 8);
+    PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(help) + kSegHelpDoubles);
     lds_vint_t* w_req = lds_vint(&words->req);
     lds_vint_t* w_moves = lds_vint(&words->moves);
     lds_vint_t* w_resp = lds_vint(&words->resp);
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
 
     // ---- the tables, by all four waves (the only workgroup barriers of the kernel: before any wave polls a hand-over word)
     const int rr = T.root_right;
-    for (int v = threadIdx.x; v < nn; v += 256) {
+    for (int v = threadIdx.x; v < nn; v += NT) {
         tb_parent[v] = M.parent[v];
         tb_size[v] = M.size[v];
         tb_first[v] = P.first_child[v];
@@ -100,7 +105,11 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         tb_second[v] = P.second_child[v];
         ts_of[v] = -1;
     }
-    if (wave < 2 && lane == 0) {
+    if (role == 0 && lane == 0) {
+        help->resp_bd = 0;
+        help->resp_cl = 0;
+        help->done_bd = 0;
+        help->done_cl = 0;
         words->req = 0;
         words->moves = 0;
         words->resp = 0;
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
         words->have0 = 0;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < NPad; j += 256) {
+    for (int j = threadIdx.x; j < NPad; j += NT) {
         const int a = T.slot_node[j];                        // -1 for padded rows
         ts_node[j] = (int16_t)a;
         ts_parent[j] = (int16_t)T.slot_parent[j];
@@ -118,11 +127,39 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     if (threadIdx.x == 0) ts_of[rr] = 0;                     // the root's two daughters share slot 0 (sumFirstTwo); no slot feeds on rr itself
     PriorDev Pst = P;                                        // (the node priors' tables in LDS where they fit)
     if (seg_node_tables_bytes(nn, NPad, P.n_cal, P.n_con) > 0)
-        prior_stage_node_tables(Pst, P, dyn + seg_table_doubles(nn, NPad) + 2 * seg_chain_doubles(nn, NPad), (int)threadIdx.x, 256);
+        prior_stage_node_tables(Pst, P, dyn + seg_table_doubles(nn, NPad) + 2 * seg_chain_doubles(nn, NPad), (int)threadIdx.x, NT);
     __syncthreads();
 
+    SegChainCtx L;
+    L.help = help;
+    L.tb_parent = tb_parent;
+    L.tb_size = tb_size;
+    L.tb_first = tb_first;
+    L.tb_nch = tb_nch;
+    L.tb_second = tb_second;
+    L.Hc = Hc;
+    L.Rc = Rc;
+    L.Hp = Hp;
+    L.Rp = Rp;
+    L.tbd = tbd;
+    L.tcl = tcl;
+    L.words = words;
+    L.A_lds = A_lds;
+    L.c = V.c;
+    L.logdet = V.logdet;
+    // ================================================================ prior waves
+    if constexpr (HELP) {
+        if (role == 2) {
+            seg_prior_wave<0>(M, P, Pst, L, Q, n_steps, seed, b, lane);
+            return;
+        }
+        if (role == 3) {
+            seg_prior_wave<1>(M, P, Pst, L, Q, n_steps, seed, b, lane);
+            return;
+        }
+    }
     // ================================================================ likelihood waves
-    if (wave >= 2) {
+    if (role == 1) {
         double zc[R];                                        // z = L^-1 (d - mu) of the current state, rows 64 k + lane
         double la_pending;
         const bool took = Q.p_acc >= 0 && seg_accept_pending(M, Q, b, seed, la_pending);
@@ -267,23 +304,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_segment(MhDev M, MvnDev V, TreeDe
     }
 
     // ================================================================ chain waves (mh_segment_device.hpp: shared with the sparse kernel)
-    SegChainCtx L;
-    L.tb_parent = tb_parent;
-    L.tb_size = tb_size;
-    L.tb_first = tb_first;
-    L.tb_nch = tb_nch;
-    L.tb_second = tb_second;
-    L.Hc = Hc;
-    L.Rc = Rc;
-    L.Hp = Hp;
-    L.Rp = Rp;
-    L.tbd = tbd;
-    L.tcl = tcl;
-    L.words = words;
-    L.A_lds = A_lds;
-    L.c = V.c;
-    L.logdet = V.logdet;
-    seg_chain_wave(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
+    seg_chain_wave<HELP>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
 }
 
 // trees whose factor takes 6 .. 16 register blocks (259 .. 1026 nodes: below that the streaming chain kernel's in-kernel sweeps of
@@ -294,8 +315,8 @@ bool mh_segment_available(const MhDev& M, const MvnDev& V)
     return seg_lds_bytes(M.n_nodes, 64 * V.R) <= 160 * 1024;
 }
 
-template <int R>
-static hipError_t launch_segment_R(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
+template <int R, bool HELP>
+static hipError_t launch_segment_RH(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
                                    int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha,
                                    int8_t* trace_accept, int64_t gs_base, int summands_kept, const MhSegPending& Q, hipStream_t st)
 {
@@ -305,12 +326,23 @@ static hipError_t launch_segment_R(const MhDev& M, const MvnDev& V, const TreeDe
     if (hipError_t e = hipGetDevice(&dev)) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!((allowed.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_segment<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
+        if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_segment<R, HELP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k_mh_segment<R>, dim3((unsigned)((M.batch + 1) / 2)), dim3(256), dynb, st, M, V, T, P, I, sched, n_steps, S, accumulate, step0,
+    hipLaunchKernelGGL((k_mh_segment<R, HELP>), dim3((unsigned)((M.batch + 1) / 2)), dim3(HELP ? 512 : 256), dynb, st, M, V, T, P, I, sched, n_steps, S, accumulate, step0,
                        seed, trace_alpha, trace_accept, gs_base, summands_kept, Q);
     return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_segment_R(const MhDev& M, const MvnDev& V, const TreeDev& T, const PriorDev& P, const MhInc& I, const int32_t* sched,
+                                   int64_t n_steps, int32_t S, int accumulate, uint64_t step0, uint64_t seed, double* trace_alpha,
+                                   int8_t* trace_accept, int64_t gs_base, int summands_kept, const MhSegPending& Q, hipStream_t st)
+{
+    // (mcd_set_option "MCD_MH_PRIOR_WAVES" = 0: the chain wave evaluates the whole ln prior; tests, timing)
+    if (opt_is(OPT_MH_PRIOR_WAVES, 0))
+        return launch_segment_RH<R, false>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
+    return launch_segment_RH<R, true>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);
 }
 
 // steps [0, n_steps) of `sched` (device memory), none of which moves more than kSegList distances; step0 = the step number of

@@ -483,6 +483,62 @@ __device__ __forceinline__ double mh_propose_params(const MhDev& M, const PropRo
     return lnq + lnj;
 }
 
+// WHICH nodes the proposal `row` writes -- the integer fields of the PropApply mh_propose_params fills -- from the row and the topology
+// alone: they do not depend on the state or on the draws (two kinds can bail out on an invalid state and then write nothing: whoever
+// uses this ahead of the proposal compares it with the transform the proposal posts).  A wave that evaluates the likelihood beside the
+// chain wave can so list the moved distances, and fetch what it needs for them, WHILE the proposal is being drawn.
+__device__ __forceinline__ void mh_propose_ranges(const MhDev& M, int kind, int v, PropApply& A)
+{
+    const int n = M.n_nodes;
+    int hlo = 0, hhi = 0, hlo2 = 0, hhi2 = 0, rlo = 0, rhi = 0, pt1 = -1, pt2 = -1, rp1 = -1, rp2 = -1, rp3 = -1, brace_lo = 0, brace_hi = 0;
+    switch (kind) {
+        case MCD_PROP_SLIDE_NODE: pt1 = v; break;
+        case MCD_PROP_SCALE_SUBTREE_TIME: hlo = v + 1; hhi = v + M.size[v]; pt1 = v; break;
+        case MCD_PROP_PULLEY: {
+            const int l = 1, r = 1 + M.size[1];
+            hlo = l + 1; hhi = l + M.size[l]; pt1 = l;
+            hlo2 = r + 1; hhi2 = r + M.size[r]; pt2 = r;
+            break;
+        }
+        case MCD_PROP_SCALE_BRANCH_RATE: rlo = v; rhi = v + 1; break;
+        case MCD_PROP_SCALE_SUBTREE_RATE: rlo = v; rhi = v + M.size[v]; break;
+        case MCD_PROP_SCALE_NORM_TREE:
+        case MCD_PROP_SCALE_VAR_TREE:
+        case MCD_PROP_SCALE_VAR_TREE_AUTO: rlo = 1; rhi = n; break;
+        case MCD_PROP_SLIDE_NODE_CONTRA: {
+            pt1 = v;
+            const int end = v + M.size[v];
+            int k = 0;
+            for (int c = v + 1; c < end; c += M.size[c], ++k) {
+                if (k == 0) rp1 = c; else rp2 = c;
+            }
+            rp3 = v;
+            break;
+        }
+        case MCD_PROP_SCALE_SUBTREE_CONTRA: hlo = v + 1; hhi = v + M.size[v]; pt1 = v; rlo = v + 1; rhi = v + M.size[v]; rp3 = v; break;
+        case MCD_PROP_SLIDE_ROOT_CONTRA: hlo = 1; hhi = n; rp1 = 1; rp2 = 1 + M.size[1]; break;
+        case MCD_PROP_SCALE_RATES_TREE_CONTRA: hlo = 1; hhi = n; break;
+        case MCD_PROP_SLIDE_BRACE:
+        case MCD_PROP_SLIDE_BRACE_CONTRA: brace_lo = M.brace_ptr[v]; brace_hi = M.brace_ptr[v + 1]; break;
+        default: break;                                      // the scalars, scaleContrarily: no node is written
+    }
+    A.kind = kind;
+    A.hlo = hlo; A.hhi = hhi; A.hlo2 = hlo2; A.hhi2 = hhi2; A.rlo = rlo; A.rhi = rhi;
+    A.pt1 = pt1; A.pt2 = pt2; A.rp1 = rp1; A.rp2 = rp2; A.rp3 = rp3;
+    A.brace_lo = brace_lo; A.brace_hi = brace_hi;
+}
+__device__ __forceinline__ bool mh_same_ranges(const PropApply& a, const PropApply& b)
+{
+    return a.kind == b.kind && a.hlo == b.hlo && a.hhi == b.hhi && a.hlo2 == b.hlo2 && a.hhi2 == b.hhi2 && a.rlo == b.rlo && a.rhi == b.rhi && a.pt1 == b.pt1 &&
+           a.pt2 == b.pt2 && a.rp1 == b.rp1 && a.rp2 == b.rp2 && a.rp3 == b.rp3 && a.brace_lo == b.brace_lo && a.brace_hi == b.brace_hi;
+}
+// does the proposal move tH * rMu (and with it every branch distance)?
+__device__ __forceinline__ bool mh_moves_scale(int kind, int v)
+{
+    return (kind == MCD_PROP_SCALE_SCALAR && (v == 2 || v == 3)) || kind == MCD_PROP_SCALE_NORM_TREE || kind == MCD_PROP_SCALE_CONTRARILY ||
+           kind == MCD_PROP_SLIDE_ROOT_CONTRA || kind == MCD_PROP_SCALE_RATES_TREE_CONTRA;
+}
+
 // Apply the proposal `row` with tuning parameter t to the state (sc, H, R) of one chain; all 64 lanes active.
 // Writes the proposed heights / rates to H1 / R1 (global memory or LDS), updates sc in place and returns
 // ln (q-ratio * Jacobian) without the root-branch factor (NaN = invalid proposal => reject).

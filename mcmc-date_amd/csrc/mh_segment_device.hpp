@@ -30,7 +30,7 @@ __host__ __device__ inline size_t seg_table_doubles(int n_nodes, int np) { retur
 // int32); the slots' marks (int32 [np]); eight words of hand-over; the proposal's per-node transform.
 __host__ __device__ inline size_t seg_chain_doubles(int n_nodes, int np)
 {
-    return 6 * (size_t)n_nodes + (size_t)np + 2 * (size_t)kSegList + (size_t)kSegList / 2 + (size_t)np / 2 + 8 + (size_t)kSegApplyDoubles;
+    return 6 * (size_t)n_nodes + (size_t)np + 2 * (size_t)kSegList + (size_t)kSegList / 2 + (size_t)np / 2 + 8 + 16 /* SegHelpWords */ + (size_t)kSegApplyDoubles;
 }
 
 __host__ __device__ inline size_t seg_lds_bytes(int n_nodes, int np) { return sizeof(double) * (seg_table_doubles(n_nodes, np) + 2 * seg_chain_doubles(n_nodes, np)); }
@@ -87,8 +87,22 @@ __device__ __forceinline__ bool seg_accept_pending(const MhDev& M, const MhSegPe
     return (la >= 0) || (ua < exp(la));
 }
 
+// The hand-over between the chain wave and the two PRIOR waves of a chain (HELP = true): the chain wave posts the proposed scalars with
+// the transform (SegWords::req), each prior wave answers with its block of the ln prior and reports when it has committed or taken back
+// its summands after the decision (SegWords::dec).
+struct SegHelpWords {
+    int resp_bd, resp_cl;          // prior waves: step + 1 when c1p / c2p are there
+    int done_bd, done_cl;          // ... when the block's summands are those of the state the decision left
+    double c1p, c2p;               // the birth-death / the clock block of the ln prior of the proposal
+    double sc1[5];                 // chain wave: the proposal's scalars
+    double pad[7];
+};
+static_assert(sizeof(SegHelpWords) == 128, "sixteen doubles of LDS");
+constexpr int kSegHelpDoubles = 16;
+
 // LDS of one chain's CHAIN wave and the constants of its likelihood: set up by the kernel, read by seg_chain_wave
 struct SegChainCtx {
+    SegHelpWords* help;                                             // (HELP = true)
     int32_t *tb_parent, *tb_size, *tb_first, *tb_nch, *tb_second;   // the tree's tables (LDS; tb_size may be the global table)
     double *Hc, *Rc, *Hp, *Rp, *tbd, *tcl;                          // [n_nodes] each: current / proposed state, summands of the two blocks
     SegWords* words;
@@ -96,7 +110,157 @@ struct SegChainCtx {
     double c, logdet;                                               // ll = c - 1/2 (logdet + q)
 };
 
+// One of a chain's two PRIOR waves (HELP = true), for the whole segment: BLOCK 0 the birth-death block, BLOCK 1 the clock block of the ln
+// prior of every proposal -- the code the chain wave runs without them, on the same numbers: a proposal that writes a few nodes has the
+// summands of those nodes re-evaluated in place (the old values wait in this wave's registers for the decision) and the block is the sum over
+// kept and new summands in the order of the full evaluation; otherwise every summand.  Pl: the prior's tables with the tree in LDS.
+template <int BLOCK>
+__device__ __forceinline__ void seg_prior_wave(const MhDev& M, const PriorDev& P, const PriorDev& Pst, const SegChainCtx& L, const MhSegPending& Q,
+                                               int64_t n_steps, uint64_t seed, int64_t b, int lane)
+{
+    PriorDev Pl = Pst;                                       // (as the chain wave: the tree's tables from LDS)
+    Pl.parent = L.tb_parent;
+    Pl.first_child = L.tb_first;
+    Pl.n_children = L.tb_nch;
+    Pl.second_child = L.tb_second;
+    const int nn = M.n_nodes;
+    const int64_t B = M.batch;
+    int32_t* tb_first = L.tb_first;
+    int32_t* tb_nch = L.tb_nch;
+    int32_t* tb_second = L.tb_second;
+    double* Hp = L.Hp;
+    double* Rp = L.Rp;
+    double* tbd = L.tbd;
+    double* tcl = L.tcl;
+    lds_vint_t* w_req = lds_vint(&L.words->req);
+    lds_vint_t* w_dec = lds_vint(&L.words->dec);
+    lds_vint_t* w_resp = lds_vint(BLOCK == 0 ? &L.help->resp_bd : &L.help->resp_cl);
+    lds_vint_t* w_done = lds_vint(BLOCK == 0 ? &L.help->done_bd : &L.help->done_cl);
+    lds_vdouble_t* w_val = lds_vdouble(BLOCK == 0 ? &L.help->c1p : &L.help->c2p);
+    double la_pending;
+    const bool took = Q.p_acc >= 0 && seg_accept_pending(M, Q, b, seed, la_pending);
+    double sc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sc[i] = (took ? M.sc1 : M.sc)[i * B + b];
+    ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
+    if (BLOCK == 1) prior_clock_scalars(sc[4], cc);
+    for (int64_t gs = 0; gs < n_steps; ++gs) {
+        const int tag = (int)gs + 1;
+        (void)seg_poll(w_req, tag, 0);
+        const PropApply A = *L.A_lds;
+        double sc1[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sc1[i] = *lds_vdouble(&L.help->sc1[i]);
+        const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
+        const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
+        const int nbr = A.brace_hi - A.brace_lo;
+        bool need = false, few = false, mine = false;
+        int v = -1;
+        double old = 0.0;
+        ClockCache ccp = cc;
+        if (BLOCK == 0) {
+            const int len1 = A.hhi > A.hlo ? A.hhi - A.hlo : 0, len2 = A.hhi2 > A.hlo2 ? A.hhi2 - A.hlo2 : 0;
+            auto cand_bd = [&](int l) -> int {
+                if (l < len1) return A.hlo + l;
+                l -= len1;
+                if (l < len2) return A.hlo2 + l;
+                l -= len2;
+                const int g = l / 3, r = l - 3 * g;
+                int base = -1;
+                if (g == 0) base = A.pt1; else if (g == 1) base = A.pt2; else if (g - 2 < nbr) base = M.brace_nodes[A.brace_lo + g - 2];
+                if (base < 0) return -1;
+                if (r == 0) return base;
+                return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+            };
+            const int cnt_bd = len1 + len2 + 3 * (2 + nbr);
+            const bool bd_scalars = sc1[0] != sc[0] || sc1[1] != sc[1];
+            need = dH || bd_scalars;
+            few = need && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
+            v = few ? cand_bd(lane) : -1;
+            mine = few && lane < cnt_bd && v >= 1;
+            if (few) {
+                // in place (a node may come twice: every lane reads the old value before any lane writes -- LDS keeps a wave's order)
+                if (mine) old = tbd[v];
+                const double t = mine ? prior_bd_term(Pl, v, false, sc1[0], sc1[1], Hp) : 0.0;
+                if (mine) tbd[v] = t;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                double bd = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) bd += tbd[w];
+                const double c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+                if (lane == 0) *w_val = c1p;
+            } else if (need) {
+                const bool near = prior_bd_near(sc1[0], sc1[1]);
+                double bd = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) bd += prior_bd_term(Pl, w, near, sc1[0], sc1[1], Hp);
+                const double c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+                if (lane == 0) *w_val = c1p;
+            }
+        } else {
+            const int lenr = A.rhi > A.rlo ? A.rhi - A.rlo : 0;
+            const int nbr_r = (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA) ? nbr : 0;
+            auto cand_cl = [&](int l) -> int {
+                if (l < lenr) return A.rlo + l;
+                l -= lenr;
+                if (l < 3) return l == 0 ? A.rp1 : l == 1 ? A.rp2 : A.rp3;
+                l -= 3;
+                const int g = l / 3, r = l - 3 * g;
+                if (g >= nbr_r) return -1;
+                const int base = M.brace_nodes[A.brace_lo + g];
+                if (r == 0) return base;
+                return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+            };
+            const int cnt_cl = lenr + 3 + 3 * nbr_r;
+            const bool cl_heights = dH && P.clock_model >= 2;    // white noise / autocorrelated: the summands also hold branch durations
+            need = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
+            few = need && sc1[4] == sc[4] && P.clock_model < 2 && cnt_cl <= 64;
+            v = few ? cand_cl(lane) : -1;
+            mine = few && lane < cnt_cl && v >= 1;
+            if (few) {
+                if (mine) old = tcl[v];
+                const double t = mine ? prior_clock_term(Pl, v, sc1[4], cc.lg_k, cc.log_t, Hp, Rp) : 0.0;
+                if (mine) tcl[v] = t;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                double cl = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) cl += tcl[w];
+                const double c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
+                if (lane == 0) *w_val = c2p;
+            } else if (need) {
+                if (ccp.va != sc1[4]) prior_clock_scalars(sc1[4], ccp);
+                double cl = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) cl += prior_clock_term(Pl, w, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
+                const double c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
+                if (lane == 0) *w_val = c2p;
+            }
+        }
+        if (need) seg_post(w_resp, tag);
+        const int d = seg_poll(w_dec, tag, 1);
+        if (d & 1) {
+            // (few: already in place)  every summand: evaluated again, now to be kept -- the same function results as the sum's
+            if (!few && need) {
+                if (BLOCK == 0) {
+                    const bool near = prior_bd_near(sc1[0], sc1[1]);
+                    for (int w = 1 + lane; w < nn; w += 64) tbd[w] = prior_bd_term(Pl, w, near, sc1[0], sc1[1], Hp);
+                } else {
+                    for (int w = 1 + lane; w < nn; w += 64) tcl[w] = prior_clock_term(Pl, w, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
+            cc = ccp;
+        } else if (mine) {
+            if (BLOCK == 0) tbd[v] = old; else tcl[v] = old;     // the overwritten summand back
+        }
+        seg_post(w_done, tag);
+    }
+}
+
 // The chain wave of one chain for the whole segment (one wave; `lane` = its lane, b = the chain, valid = whether it exists).
+// HELP: two more waves of the workgroup evaluate the birth-death and the clock block of the proposal's ln prior (seg_prior_wave below: the
+// same functions on the same numbers in the same order, hence the same bits) while this wave evaluates the node priors -- the three
+// blocks depend on the proposal only, and one wave evaluated them one after the other: 37 - 44 % of a step (profiles/r04_*_phases*).
+template <bool HELP>
 __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P, const PriorDev& Pst, const SegChainCtx& L, const MhSegPending& Q,
                                                const int32_t* __restrict__ sched, int64_t n_steps, int32_t S, int accumulate, uint64_t step0,
                                                uint64_t seed, double* __restrict__ trace_alpha, int8_t* __restrict__ trace_accept, int64_t gs_base,
@@ -271,6 +435,13 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
         SEG_TICK(0)
         PropApply A;
         const double lnqj = mh_propose_params(Ml, row, t_cur, dr, lane, sc1, Hc, Rc, A);
+        if constexpr (HELP) {
+            // (the prior waves read Hp / Rp until they have committed or taken back the previous step's summands)
+            if (gs > 0) {
+                (void)seg_poll(lds_vint(&L.help->done_bd), tag - 1, 0);
+                (void)seg_poll(lds_vint(&L.help->done_cl), tag - 1, 0);
+            }
+        }
         for_write_set(A, [&](int w) {
             double h, r;
             mh_propose_node(Ml, A, w, Hc, Rc, h, r);
@@ -287,91 +458,114 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
             *A_lds = A;
             *w_s1 = sc1[2] * sc1[3];
             *w_moves = moves ? 1 : 0;
+            if constexpr (HELP) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) L.help->sc1[i] = sc1[i];
+            }
         }
         seg_post(w_req, tag);                                // (every lane stores the same word: the fence is the wave's)
         SEG_TICK(2)
+        bool bd_scalars = false, need_bd = false, few_bd = false, need_cl = false, few_cl = false, cl_heights = false, mine_bd = false, mine_cl = false;
+        int v_bd = -1, v_cl = -1;
+        double old_bd = 0.0, old_cl = 0.0;                   // the summands this lane overwrites, until the decision
+        double c1p = c1, c2p = c2;
+        ClockCache ccp = cc;
         // ---- ln prior: only the blocks whose inputs the proposal writes (a superset of "changed": a block re-evaluated on unchanged
         // inputs returns the same bits)
         const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
         const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
-        ClockCache ccp = cc;                                 // refreshed only if the proposal moved rVar
+        ccp = cc;                                            // refreshed only if the proposal moved rVar
         const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
-        const int nbr = A.brace_hi - A.brace_lo;
-        // candidate l of the birth-death block: the nodes whose height the proposal writes, with their daughters (a range is a sub
-        // tree without its root: closed under "daughter of"); -1 = none
-        const int len1 = A.hhi > A.hlo ? A.hhi - A.hlo : 0, len2 = A.hhi2 > A.hlo2 ? A.hhi2 - A.hlo2 : 0;
-        auto cand_bd = [&](int l) -> int {
-            if (l < len1) return A.hlo + l;
-            l -= len1;
-            if (l < len2) return A.hlo2 + l;
-            l -= len2;
-            const int g = l / 3, r = l - 3 * g;
-            int base = -1;
-            if (g == 0) base = A.pt1; else if (g == 1) base = A.pt2; else if (g - 2 < nbr) base = M.brace_nodes[A.brace_lo + g - 2];
-            if (base < 0) return -1;
-            if (r == 0) return base;
-            return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
-        };
-        const int cnt_bd = len1 + len2 + 3 * (2 + nbr);
-        // ... of the clock block (uncorrelated models: a summand depends on its node's rate only): the nodes whose rate is written
-        const int lenr = A.rhi > A.rlo ? A.rhi - A.rlo : 0;
-        const int nbr_r = (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA) ? nbr : 0;
-        auto cand_cl = [&](int l) -> int {
-            if (l < lenr) return A.rlo + l;
-            l -= lenr;
-            if (l < 3) return l == 0 ? A.rp1 : l == 1 ? A.rp2 : A.rp3;
-            l -= 3;
-            const int g = l / 3, r = l - 3 * g;
-            if (g >= nbr_r) return -1;
-            const int base = M.brace_nodes[A.brace_lo + g];
-            if (r == 0) return base;
-            return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
-        };
-        const int cnt_cl = lenr + 3 + 3 * nbr_r;
-        const bool bd_scalars = sc1[0] != sc[0] || sc1[1] != sc[1];
-        const bool need_bd = dH || bd_scalars;
-        const bool few_bd = need_bd && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
-        double c1p = c1;
-        double old_bd = 0.0, old_cl = 0.0;                   // the summands this lane overwrites, until the decision
-        const int v_bd = few_bd ? cand_bd(lane) : -1;
-        const bool mine_bd = few_bd && lane < cnt_bd && v_bd >= 1;
-        if (few_bd) {
-            // in place (a node may come twice: every lane reads the old value before any lane writes -- LDS keeps a wave's order)
-            if (mine_bd) old_bd = tbd[v_bd];
-            const double t = mine_bd ? prior_bd_term(Pl, v_bd, false, sc1[0], sc1[1], Hp) : 0.0;
-            if (mine_bd) tbd[v_bd] = t;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            double bd = 0.0;
-            for (int w = 1 + lane; w < nn; w += 64) bd += tbd[w];
-            c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
-        } else if (need_bd) {
-            // every summand (the rates moved, or many heights): the sum alone; the summands are evaluated again if the proposal is accepted
-            const bool near = prior_bd_near(sc1[0], sc1[1]);
-            double bd = 0.0;
-            for (int v = 1 + lane; v < nn; v += 64) bd += prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
-            c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
-        }
-        const bool cl_heights = dH && P.clock_model >= 2;    // white noise / autocorrelated: the summands also hold branch durations
-        const bool need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
-        const bool few_cl = need_cl && sc1[4] == sc[4] && P.clock_model < 2 && cnt_cl <= 64;
-        double c2p = c2;
-        const int v_cl = few_cl ? cand_cl(lane) : -1;
-        const bool mine_cl = few_cl && lane < cnt_cl && v_cl >= 1;
-        if (few_cl) {
-            if (mine_cl) old_cl = tcl[v_cl];
-            const double t = mine_cl ? prior_clock_term(Pl, v_cl, sc1[4], cc.lg_k, cc.log_t, Hp, Rp) : 0.0;
-            if (mine_cl) tcl[v_cl] = t;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            double cl = 0.0;
-            for (int w = 1 + lane; w < nn; w += 64) cl += tcl[w];
-            c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
-        } else if (need_cl) {
-            if (ccp.va != sc1[4]) prior_clock_scalars(sc1[4], ccp);
-            double cl = 0.0;
-            for (int v = 1 + lane; v < nn; v += 64) cl += prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
-            c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
+        if constexpr (!HELP) {
+            const int nbr = A.brace_hi - A.brace_lo;
+            // candidate l of the birth-death block: the nodes whose height the proposal writes, with their daughters (a range is a sub
+            // tree without its root: closed under "daughter of"); -1 = none
+            const int len1 = A.hhi > A.hlo ? A.hhi - A.hlo : 0, len2 = A.hhi2 > A.hlo2 ? A.hhi2 - A.hlo2 : 0;
+            auto cand_bd = [&](int l) -> int {
+                if (l < len1) return A.hlo + l;
+                l -= len1;
+                if (l < len2) return A.hlo2 + l;
+                l -= len2;
+                const int g = l / 3, r = l - 3 * g;
+                int base = -1;
+                if (g == 0) base = A.pt1; else if (g == 1) base = A.pt2; else if (g - 2 < nbr) base = M.brace_nodes[A.brace_lo + g - 2];
+                if (base < 0) return -1;
+                if (r == 0) return base;
+                return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+            };
+            const int cnt_bd = len1 + len2 + 3 * (2 + nbr);
+            // ... of the clock block (uncorrelated models: a summand depends on its node's rate only): the nodes whose rate is written
+            const int lenr = A.rhi > A.rlo ? A.rhi - A.rlo : 0;
+            const int nbr_r = (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA) ? nbr : 0;
+            auto cand_cl = [&](int l) -> int {
+                if (l < lenr) return A.rlo + l;
+                l -= lenr;
+                if (l < 3) return l == 0 ? A.rp1 : l == 1 ? A.rp2 : A.rp3;
+                l -= 3;
+                const int g = l / 3, r = l - 3 * g;
+                if (g >= nbr_r) return -1;
+                const int base = M.brace_nodes[A.brace_lo + g];
+                if (r == 0) return base;
+                return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+            };
+            const int cnt_cl = lenr + 3 + 3 * nbr_r;
+            bd_scalars = sc1[0] != sc[0] || sc1[1] != sc[1];
+            need_bd = dH || bd_scalars;
+            few_bd = need_bd && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
+            c1p = c1;
+            v_bd = few_bd ? cand_bd(lane) : -1;
+            mine_bd = few_bd && lane < cnt_bd && v_bd >= 1;
+            if (few_bd) {
+                // in place (a node may come twice: every lane reads the old value before any lane writes -- LDS keeps a wave's order)
+                if (mine_bd) old_bd = tbd[v_bd];
+                const double t = mine_bd ? prior_bd_term(Pl, v_bd, false, sc1[0], sc1[1], Hp) : 0.0;
+                if (mine_bd) tbd[v_bd] = t;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                double bd = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) bd += tbd[w];
+                c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+            } else if (need_bd) {
+                // every summand (the rates moved, or many heights): the sum alone; the summands are evaluated again if the proposal is accepted
+                const bool near = prior_bd_near(sc1[0], sc1[1]);
+                double bd = 0.0;
+                for (int v = 1 + lane; v < nn; v += 64) bd += prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
+                c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+            }
+            cl_heights = dH && P.clock_model >= 2;    // white noise / autocorrelated: the summands also hold branch durations
+            need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
+            few_cl = need_cl && sc1[4] == sc[4] && P.clock_model < 2 && cnt_cl <= 64;
+            c2p = c2;
+            v_cl = few_cl ? cand_cl(lane) : -1;
+            mine_cl = few_cl && lane < cnt_cl && v_cl >= 1;
+            if (few_cl) {
+                if (mine_cl) old_cl = tcl[v_cl];
+                const double t = mine_cl ? prior_clock_term(Pl, v_cl, sc1[4], cc.lg_k, cc.log_t, Hp, Rp) : 0.0;
+                if (mine_cl) tcl[v_cl] = t;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                double cl = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) cl += tcl[w];
+                c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
+            } else if (need_cl) {
+                if (ccp.va != sc1[4]) prior_clock_scalars(sc1[4], ccp);
+                double cl = 0.0;
+                for (int v = 1 + lane; v < nn; v += 64) cl += prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
+                c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
+            }
+        } else {
+            // the two prior waves evaluate their blocks (seg_prior_wave); whether a block has to be evaluated at all is decided here and
+            // there alike (the same expressions on the same numbers)
+            need_bd = dH || sc1[0] != sc[0] || sc1[1] != sc[1];
+            need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2);
+            if (need_bd) {
+                (void)seg_poll(lds_vint(&L.help->resp_bd), tag, 0);
+                c1p = *lds_vdouble(&L.help->c1p);
+            }
+            if (need_cl) {
+                (void)seg_poll(lds_vint(&L.help->resp_cl), tag, 0);
+                c2p = *lds_vdouble(&L.help->c2p);
+            }
         }
         const double lp1 = c0p + c1p + c2p;
         SEG_TICK(3)
@@ -400,12 +594,14 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
 #pragma unroll
             for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
             // (few: already in place)  every summand: evaluated again, now to be kept -- the same function results as the sum's
-            if (!few_bd && need_bd) {
-                const bool near = prior_bd_near(sc1[0], sc1[1]);
-                for (int v = 1 + lane; v < nn; v += 64) tbd[v] = prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
+            if constexpr (!HELP) {
+                if (!few_bd && need_bd) {
+                    const bool near = prior_bd_near(sc1[0], sc1[1]);
+                    for (int v = 1 + lane; v < nn; v += 64) tbd[v] = prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
+                }
+                if (!few_cl && need_cl)
+                    for (int v = 1 + lane; v < nn; v += 64) tcl[v] = prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
             }
-            if (!few_cl && need_cl)
-                for (int v = 1 + lane; v < nn; v += 64) tcl[v] = prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
             c0 = c0p;
             c1 = c1p;
             c2 = c2p;
@@ -418,8 +614,10 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
                 Hp[w] = Hc[w];
                 Rp[w] = Rc[w];
             });
-            if (mine_bd) tbd[v_bd] = old_bd;                 // the overwritten summands back
-            if (mine_cl) tcl[v_cl] = old_cl;
+            if constexpr (!HELP) {
+                if (mine_bd) tbd[v_bd] = old_bd;             // the overwritten summands back
+                if (mine_cl) tcl[v_cl] = old_cl;
+            }
         }
         if (lane == 0 && valid) {
             atomicAdd(&tried[p], 1);                         // (global memory, no value returned: nothing waits for it)
@@ -445,6 +643,12 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
     if (trace_alpha && lane == 0 && valid)
         for (int i = 0; i < 8; ++i) trace_alpha[(int64_t)i * B + b] = (double)tk[i];
 #endif
+    if constexpr (HELP) {
+        if (n_steps > 0) {
+            (void)seg_poll(lds_vint(&L.help->done_bd), (int)n_steps, 0);
+            (void)seg_poll(lds_vint(&L.help->done_cl), (int)n_steps, 0);
+        }
+    }
     if (!valid) return;
     // ---- back to where the two-launch path keeps a chain
     for (int w = lane; w < nn; w += 64) {

@@ -136,7 +136,15 @@ struct SparseDev {
     const int32_t* s_trow;     // [s_nnz]
     const int32_t* s_col;      // [s_nnz]
     const double* s_val;       // [s_nnz]
+    // ... and the same rows as fixed-size records (ELL, kSparseEllW entries per row, zero padded: no row pointer to chase -- a row's entries
+    // are ONE round trip after its index is known): column, value and mu[column] side by side; ell_more[j] = entries of row j beyond the
+    // record (they stay in the CSR arrays from s_rowptr[j] + kSparseEllW on).  The Metropolis-Hastings driver's incremental form.
+    const int32_t* ell_col;    // [n][kSparseEllW]
+    const double* ell_val;     // [n][kSparseEllW]
+    const double* ell_mu;      // [n][kSparseEllW]
+    const int32_t* ell_more;   // [n]
 };
+constexpr int kSparseEllW = 16;
 struct SparseTreeDev {
     int n_nodes, root_right;
     const int32_t* slot_node;     // [n] distance slot -> node (getBranches . sumFirstTwo order)

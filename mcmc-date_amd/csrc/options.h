@@ -25,6 +25,7 @@ enum Option {
     OPT_GEOM,               // 21 | 41 | 42: compute waves, chains per wave of the column sweep
     OPT_WIDE_CT,            // 1 | 2 | 4: chains per workgroup / 16 of the multiply form
     OPT_SPARSE_QUAD,        // 1 / 0: force / forbid the one-launch form of the sparse log-density
+    OPT_MH_PRIOR_WAVES,     // 0: the segment kernels without their prior waves (the chain wave evaluates the whole ln prior)
     OPT_COUNT
 };
 constexpr int MCD_OPT_UNSET = -2147483647 - 1;

@@ -195,6 +195,8 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
         // driver's incremental form (rows of the moved distances); for a symmetric matrix it IS the matrix (no second copy).
         const size_t nz = vv.size();
         bool symmetric = true;
+        std::vector<int32_t> sym_rowptr, sym_col;                    // the symmetric part, when it is not the matrix itself
+        std::vector<double> sym_val;
         auto find = [&](int r, int c) -> int64_t {
             const int32_t* lo = cc.data() + rowptr[(size_t)r];
             const int32_t* hi = cc.data() + rowptr[(size_t)r + 1];
@@ -218,8 +220,11 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
                 rows[(size_t)rr[e]].push_back({cc[e], 0.5 * vv[e]});
                 rows[(size_t)cc[e]].push_back({rr[e], 0.5 * vv[e]});
             }
-            std::vector<int32_t> sp((size_t)n + 1, 0), sc, sr;
-            std::vector<double> sv;
+            std::vector<int32_t>& sp = sym_rowptr;
+            std::vector<int32_t>& sc = sym_col;
+            std::vector<int32_t> sr;
+            std::vector<double>& sv = sym_val;
+            sp.assign((size_t)n + 1, 0);
             for (int i = 0; i < n; ++i) {
                 auto& r = rows[(size_t)i];
                 std::stable_sort(r.begin(), r.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
@@ -237,6 +242,28 @@ int mcd_sparse_create(mcd_sparse_t** out, int n, const double* mu, int64_t nnz, 
             h->dev.s_nnz = (int64_t)sv.size();
             if ((rc = upload(h.get(), &h->dev.s_rowptr, sp.data(), sp.size())) || (rc = upload(h.get(), &h->dev.s_col, sc.data(), sc.size())) ||
                 (rc = upload(h.get(), &h->dev.s_trow, sr.data(), sr.size())) || (rc = upload(h.get(), &h->dev.s_val, sv.data(), sv.size())))
+                return rc;
+        }
+        {   // the rows of the symmetric part as fixed-size records (SparseDev::ell_*)
+            const std::vector<int32_t>& rp = symmetric ? rowptr : sym_rowptr;
+            const std::vector<int32_t>& rcol = symmetric ? cc : sym_col;
+            const std::vector<double>& rv = symmetric ? vv : sym_val;
+            const int W = mcd::kSparseEllW;
+            std::vector<int32_t> ec((size_t)n * W), em((size_t)n, 0);
+            std::vector<double> ev((size_t)n * W, 0.0), eu((size_t)n * W, 0.0);
+            for (int i = 0; i < n; ++i) {
+                const int len = rp[(size_t)i + 1] - rp[(size_t)i];
+                for (int u = 0; u < W; ++u) {
+                    const bool in = u < len;
+                    const int32_t k = in ? rcol[(size_t)rp[(size_t)i] + u] : (int32_t)i;      // (padding: the row's own index, weight 0)
+                    ec[(size_t)i * W + u] = k;
+                    ev[(size_t)i * W + u] = in ? rv[(size_t)rp[(size_t)i] + u] : 0.0;
+                    eu[(size_t)i * W + u] = mu[k];
+                }
+                em[(size_t)i] = len > W ? len - W : 0;
+            }
+            if ((rc = upload(h.get(), &h->dev.ell_col, ec.data(), ec.size())) || (rc = upload(h.get(), &h->dev.ell_val, ev.data(), ev.size())) ||
+                (rc = upload(h.get(), &h->dev.ell_mu, eu.data(), eu.size())) || (rc = upload(h.get(), &h->dev.ell_more, em.data(), em.size())))
                 return rc;
         }
         // the flat entry stream of the one-launch form: (row | column << 16, value); a symmetric matrix as its upper triangle with the

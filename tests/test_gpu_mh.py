@@ -909,3 +909,44 @@ def test_shard_allgather_through_rccl(gpu, golden):
         assert torch.equal(shards.gather_loglik(send[64:128], shards.ChainShard(0, 1, 64)), send[64:128])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_leaves,B,sparse", [(200, 33, False), (513, 16, False), (7, 8, True), (300, 17, True), (1007, 5, True)])
+def test_prior_waves_of_the_segment_kernels_give_the_same_chains(gpu, n_leaves, B, sparse, knobs):
+    """The segment kernels (k_mh_segment.hip, k_mh_segment_sparse.hip) give every chain two PRIOR waves beside its chain wave and its
+    likelihood wave: the birth-death and the clock block of a proposal's ln prior are evaluated by them (mh_segment_device.hpp:
+    seg_prior_wave) while the chain wave evaluates the node priors.  The same functions on the same numbers in the same order: with the
+    knob MCD_MH_PRIOR_WAVES = 0 (the chain wave evaluates all three blocks, round 3's arrangement) every ln acceptance ratio, decision,
+    state and posterior term is the same bits.  Calibrations and a constraint, so that all three blocks are live; an odd batch."""
+    from mcmc_date_amd import synthetic as S
+
+    topo = S.random_topology(n_leaves, seed=31)
+    n = topo.n_nodes - 2
+    if sparse:
+        _, assoc = S.banded_precision(n, seed=n)
+        lik = M.SparseLikelihood(M.Sparse(np.random.default_rng(1).uniform(0.01, 0.2, n), assoc, 0.0)).bind_tree(topo)
+    else:
+        mu, sigma = S.random_spd_problem(n, seed=n)
+        lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+    inner = [v for v in range(1, topo.n_nodes) if (np.asarray(topo.parent) == v).any()]
+    cal = [M.Calibration("root", 0, 0.9, 0.025, 1.3, 0.025), M.Calibration("c", int(inner[len(inner) // 2]), 1e-3, 0.025, 5.0, 0.025)]
+    con = [M.Constraint("k", int(inner[-1]), int(topo.parent[inner[-1]]), 0.025)] if topo.parent[inner[-1]] > 0 else []
+    pf = M.PriorFunction(1.0, "UncorrelatedLogNormal", cal, con, [], topo)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    s0 = S.random_states(topo, B, seed=5)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    cyc = M.cycle_schedule(ps, 1, np.random.default_rng(2))
+    sched = np.tile(cyc, (1, 700 // cyc.shape[1] + 1))[:, :700]
+    out = {}
+    for waves in ("1", "0"):
+        knobs.setenv("MCD_MH_PRIOR_WAVES", waves)
+        smp = M.Sampler(lik, pf, ps, B, seed=77)
+        smp.set_state(s0)
+        ta, tk = smp.run_schedule(sched, trace=True)
+        assert "segments" in smp.last_path()
+        out[waves] = (ta, tk, smp.state(), smp.posterior())
+    a, b = out["1"], out["0"]
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1]) and 0.02 < a[1].mean() < 0.98
+    for f in ("time_birth_rate", "time_death_rate", "time_height", "heights", "rate_mean", "rate_variance", "rates"):
+        assert np.array_equal(getattr(a[2], f), getattr(b[2], f)), f
+    assert np.array_equal(a[3], b[3])

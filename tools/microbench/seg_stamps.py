@@ -11,10 +11,15 @@ from mcmc_date_amd import synthetic as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 kinds = [int(k) for k in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,5,10,11").split(",")]
+sparse = len(sys.argv) > 4 and sys.argv[4] == "sparse"      # the sparse driver's segment kernel (k_mh_segment_sparse.hip: the same chain wave)
 topo = S.random_topology((n + 3) // 2, seed=3)
 nd = topo.n_nodes - 2
-mu, sigma = S.random_spd_problem(nd, seed=3)
-tl = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+if sparse:
+    _, assoc = S.banded_precision(nd, seed=3)
+    tl = M.SparseLikelihood(M.Sparse(np.random.default_rng(3).uniform(0.01, 0.2, nd), assoc, 0.0)).bind_tree(topo)
+else:
+    mu, sigma = S.random_spd_problem(nd, seed=3)
+    tl = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
 pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo)
 ps, _ = M.proposals(topo, [], calibrations_available=True)
 s0 = S.random_states(topo, B, seed=4)
@@ -37,5 +42,10 @@ dt = time.perf_counter() - t0
 assert "segments" in smp.last_path(), smp.last_path()
 tk = ta[:6].mean(axis=1)
 print("us per lock step %.2f (n_nodes %d, chains %d, %d steps of kinds %s in one launch; with tracing)" % (1e6 * dt / steps, topo.n_nodes, B, steps, kinds))
-for nm, v in zip(["loop head + draws", "propose", "list of moved distances", "ln prior", "waiting for |z'|^2", "decision + commit"], tk):
+for nm, v in zip(["loop head + draws", "propose", "posting the transform", "ln prior", "waiting for |z'|^2 / q'", "decision + commit"], tk):
     print("  %-26s %5.1f %%   (%.0f ticks per step)" % (nm, 100 * v / tk.sum(), v / steps))
+if sparse:
+    lk = ta[8:13].mean(axis=1)
+    print("  likelihood wave (sparse):")
+    for nm, v in zip(["waiting for the request", "ahead of it: list from the row, fetches", "request -> deltas, look-ups", "sum + answer posted", "waiting for the decision + commit"], lk):
+        print("    %-36s %5.1f %%   (%.0f ticks per step)" % (nm, 100 * v / lk.sum(), v / steps))
