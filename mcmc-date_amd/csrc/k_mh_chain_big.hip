@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         const double* Hp_ = dyn + mhb_table_doubles(nn) + (size_t)lw * mhb_chain_doubles(nn, NP) + 2 * (size_t)nn;
         const double* Rp_ = Hp_ + nn;
         const int rr_ = T.root_right;
+        MhDev Mt_ = M;                                       // (mh_propose_ranges reads the sub tree sizes -- the chain waves' table in LDS -- and the braces' pointers)
+        Mt_.size = reinterpret_cast<const int32_t*>(dyn) + nn;
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
@@ -201,70 +203,134 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                 if (inc && sp && mhb_moves_likelihood(kind, node)) {
                     // ---- the likelihood wave of a sparse step (k_mh_segment.hip has the same: the slots the written nodes feed, each once)
                     const int tag = (int)gs + 1;
-                    (void)poll(&words->req, tag, 0);
-                    const PropApply A = *A_lds;
-                    const double s1 = words->s1;
+                    // AHEAD of the request, while the chain wave draws the proposal: which nodes the proposal writes follows from its table row
+                    // and the topology alone (mh_propose_ranges) -- hence the list of moved slots, and the first four columns of L^-1 are
+                    // requested at once.  The guess is compared with the transform the proposal posts; the rare mismatch (a proposal that
+                    // bails out on an invalid state) lists again, with a tag of its own.  (The transform's integer fields travel as scalars:
+                    // a struct passed around here ends up in scratch memory.)
+                    struct MhbRanges {
+                        int kind, hlo, hhi, hlo2, hhi2, rlo, rhi, pt1, pt2, rp1, rp2, rp3, brace_lo, brace_hi;
+                    };
+                    auto build_list = [&](int a_kind, int a_hlo, int a_hhi, int a_hlo2, int a_hhi2, int a_rlo, int a_rhi, int a_pt1, int a_pt2, int a_rp1, int a_rp2, int a_rp3, int a_brace_lo, int a_brace_hi, int tagf) __attribute__((always_inline)) -> int {
+                        const MhbRanges A{a_kind, a_hlo, a_hhi, a_hlo2, a_hhi2, a_rlo, a_rhi, a_pt1, a_pt2, a_rp1, a_rp2, a_rp3, a_brace_lo, a_brace_hi};
+                        int cnt = 0;
+                        auto emit = [&](bool active, int node_) {
+                            if (__builtin_amdgcn_ballot_w64(active) == 0) return;
+                            const int slot = active ? (int)ts_of[node_] : -1;
+                            bool mine = false;
+                            if (slot >= 0) mine = atomicMax(&mark[slot], tagf) != tagf;      // (the tags count upwards within a launch)
+                            const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
+                            if (mine) {
+                                const int pos = cnt + (int)__builtin_popcountll(mk & lt_mask);
+                                if (pos < kMhbList) l_j[pos] = slot;
+                            }
+                            cnt += (int)__builtin_popcountll(mk);
+                        };
+                        auto emit_height = [&](bool active, int w) {
+                            emit(active, w);
+                            const int nc = active ? tb_nch_[w] : 0;
+                            emit(nc > 0, active ? tb_first_[w] : 0);
+                            emit(nc > 1, active ? tb_second_[w] : 0);
+                        };
+                        for (int w0 = A.hlo; w0 < A.hhi; w0 += 64) emit_height(w0 + lane < A.hhi, w0 + lane);
+                        for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
+                        for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
+                        {
+                            const int g = lane / 3, r = lane - 3 * g;
+                            int cand = -1;
+                            if (lane < 6) {
+                                const int base = (g == 0) ? A.pt1 : A.pt2;
+                                if (base >= 0) cand = (r == 0) ? base : (tb_nch_[base] >= r) ? (r == 1 ? tb_first_[base] : tb_second_[base]) : -1;
+                            } else if (lane < 9) {
+                                cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
+                            }
+                            emit(cand >= 0, cand >= 0 ? cand : 0);
+                        }
+                        for (int i = A.brace_lo; i < A.brace_hi; ++i) emit_height(lane == 0, M.brace_nodes[i]);
+                        if (cnt > kMhbList) cnt = -1;
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_wave_barrier();
+                        return cnt;
+                    };
+                    PropApply G;
+                    mh_propose_ranges(Mt_, kind, node, G);
+                    int c_kind = G.kind, c_hlo = G.hlo, c_hhi = G.hhi, c_hlo2 = G.hlo2, c_hhi2 = G.hhi2, c_rlo = G.rlo, c_rhi = G.rhi, c_pt1 = G.pt1, c_pt2 = G.pt2, c_rp1 = G.rp1, c_rp2 = G.rp2, c_rp3 = G.rp3, c_brace_lo = G.brace_lo, c_brace_hi = G.brace_hi;
                     int cnt = 0;
-                    double d0 = 0.0;
-                    bool have0 = false;
-                    auto emit = [&](bool active, int node_) {
-                        if (__builtin_amdgcn_ballot_w64(active) == 0) return;
-                        const int slot = active ? (int)ts_of[node_] : -1;
-                        bool mine = false;
-                        if (slot >= 0) mine = atomicExch(&mark[slot], tag) != tag;
-                        const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
-                        if (mine) {
-                            const int pos = cnt + (int)__builtin_popcountll(mk & lt_mask);
+                    double pcol[4][R];                           // the first four columns, requested ahead of the request
+                    for (int pass = 0; pass < 2; ++pass) {
+                        cnt = build_list(c_kind, c_hlo, c_hhi, c_hlo2, c_hhi2, c_rlo, c_rhi, c_pt1, c_pt2, c_rp1, c_rp2, c_rp3, c_brace_lo, c_brace_hi, 2 * tag + pass);
+                        if (cnt > 0) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int m = (u < cnt) ? u : cnt - 1;
+                                const int j = __builtin_amdgcn_readfirstlane(l_j[m]);
+                                const double* wc = V.Wc + (size_t)j * NPadC + lane;
+#pragma unroll
+                                for (int k = 0; k < R; ++k) pcol[u][k] = wc[64 * k];
+                            }
+                        }
+                        if (pass == 1) break;
+                        (void)poll(&words->req, tag, 0);
+                        const int n_kind = A_lds->kind, n_hlo = A_lds->hlo, n_hhi = A_lds->hhi, n_hlo2 = A_lds->hlo2, n_hhi2 = A_lds->hhi2, n_rlo = A_lds->rlo, n_rhi = A_lds->rhi, n_pt1 = A_lds->pt1, n_pt2 = A_lds->pt2, n_rp1 = A_lds->rp1, n_rp2 = A_lds->rp2, n_rp3 = A_lds->rp3, n_brace_lo = A_lds->brace_lo, n_brace_hi = A_lds->brace_hi;
+                        const bool same_ranges = n_kind == c_kind && n_hlo == c_hlo && n_hhi == c_hhi && n_hlo2 == c_hlo2 && n_hhi2 == c_hhi2 && n_rlo == c_rlo && n_rhi == c_rhi && n_pt1 == c_pt1 && n_pt2 == c_pt2 && n_rp1 == c_rp1 && n_rp2 == c_rp2 && n_rp3 == c_rp3 && n_brace_lo == c_brace_lo && n_brace_hi == c_brace_hi;
+                        if (same_ranges) break;
+                        c_kind = n_kind;
+                        c_hlo = n_hlo;
+                        c_hhi = n_hhi;
+                        c_hlo2 = n_hlo2;
+                        c_hhi2 = n_hhi2;
+                        c_rlo = n_rlo;
+                        c_rhi = n_rhi;
+                        c_pt1 = n_pt1;
+                        c_pt2 = n_pt2;
+                        c_rp1 = n_rp1;
+                        c_rp2 = n_rp2;
+                        c_rp3 = n_rp3;
+                        c_brace_lo = n_brace_lo;
+                        c_brace_hi = n_brace_hi;
+                    }
+                    // the listed slots' new distances from the proposed state and the deltas against the current ones (the arithmetic of
+                    // `distances` below)
+                    if (cnt > 0) {
+                        const double s1 = words->s1;
+                        double d0 = 0.0;
+                        bool have0 = false;
+                        for (int m = lane; m < cnt; m += 64) {
+                            const int slot = l_j[m];
                             const int a = ts_node[slot], pa = ts_parent[slot];
-                            double x = (Hp_[pa] - Hp_[a]) * Rp_[a];                      // the arithmetic of `distances` below
+                            double x = (Hp_[pa] - Hp_[a]) * Rp_[a];
                             if (slot == 0) x = x + (Hp_[0] - Hp_[rr_]) * Rp_[rr_];
                             x = x * s1;
-                            if (pos < kMhbList) {
-                                l_j[pos] = slot;
-                                l_dnew[pos] = x;
-                                l_delta[pos] = x - dcur_l[slot];
-                            }
+                            l_dnew[m] = x;
+                            l_delta[m] = x - dcur_l[slot];
                             if (slot == 0) {
                                 d0 = x;
                                 have0 = true;
                             }
                         }
-                        cnt += (int)__builtin_popcountll(mk);
-                    };
-                    auto emit_height = [&](bool active, int w) {
-                        emit(active, w);
-                        const int nc = active ? tb_nch_[w] : 0;
-                        emit(nc > 0, active ? tb_first_[w] : 0);
-                        emit(nc > 1, active ? tb_second_[w] : 0);
-                    };
-                    for (int w0 = A.hlo; w0 < A.hhi; w0 += 64) emit_height(w0 + lane < A.hhi, w0 + lane);
-                    for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
-                    for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
-                    {
-                        const int g = lane / 3, r = lane - 3 * g;
-                        int cand = -1;
-                        if (lane < 6) {
-                            const int base = (g == 0) ? A.pt1 : A.pt2;
-                            if (base >= 0) cand = (r == 0) ? base : (tb_nch_[base] >= r) ? (r == 1 ? tb_first_[base] : tb_second_[base]) : -1;
-                        } else if (lane < 9) {
-                            cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
+                        const uint64_t m0 = __builtin_amdgcn_ballot_w64(have0);
+                        if (lane == 0) words->have0 = (m0 != 0) ? 1 : 0;
+                        if (m0 != 0) {
+                            const double lj1 = log(1.0 / readlane64(d0, (int)__builtin_ctzll(m0)));      // jacobianRootBranch, :393-410
+                            if (lane == 0) words->lj = lj1;
                         }
-                        emit(cand >= 0, cand >= 0 ? cand : 0);
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_wave_barrier();
+                    } else if (lane == 0) {
+                        words->have0 = 0;
                     }
-                    for (int i = A.brace_lo; i < A.brace_hi; ++i) emit_height(lane == 0, M.brace_nodes[i]);
-                    const uint64_t m0 = __builtin_amdgcn_ballot_w64(have0);
-                    if (lane == 0) words->have0 = (m0 != 0) ? 1 : 0;
-                    if (m0 != 0) {
-                        const double lj1 = log(1.0 / readlane64(d0, (int)__builtin_ctzll(m0)));      // jacobianRootBranch, :393-410
-                        if (lane == 0) words->lj = lj1;
-                    }
-                    if (cnt > kMhbList) cnt = -1;
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
                     double zp[R];
 #pragma unroll
                     for (int k = 0; k < R; ++k) zp[k] = z_l[64 * k + lane];
-                    for (int m0_ = 0; m0_ < cnt; m0_ += 4) {     // four columns in flight
+                    if (cnt > 0) {                               // the first batch: the columns requested ahead of the request
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double dl = (u < cnt) ? l_delta[u] : 0.0;     // (past the end: the last column again with weight 0: exact)
+#pragma unroll
+                            for (int k = 0; k < R; ++k) zp[k] = fma(dl, pcol[u][k], zp[k]);
+                        }
+                    }
+                    for (int m0_ = 4; m0_ < cnt; m0_ += 4) {     // four columns in flight
                         double col[4][R], dl[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {

@@ -184,68 +184,133 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+        MhDev Mt = M;                                        // (mh_propose_ranges reads the sub tree sizes and the braces' pointers)
+        Mt.size = tb_size;
+        // The slots the written nodes of a transform feed -- a written node's own slot, and its daughters' when its height is written -- each
+        // once: the first lane to raise the slot's mark to this list's tag lists it.  Slots only: the new distances follow once the proposal
+        // is there.  (The transform's integer fields as scalars by value: a struct passed around here ends up in scratch memory.)  Returns the
+        // count (the list holds kSegList of them).
+        struct SegRanges {
+            int kind, hlo, hhi, hlo2, hhi2, rlo, rhi, pt1, pt2, rp1, rp2, rp3, brace_lo, brace_hi;
+        };
+        auto build_list = [&](int a_kind, int a_hlo, int a_hhi, int a_hlo2, int a_hhi2, int a_rlo, int a_rhi, int a_pt1, int a_pt2, int a_rp1, int a_rp2, int a_rp3, int a_brace_lo, int a_brace_hi, int tagf) __attribute__((always_inline)) -> int {
+            const SegRanges A{a_kind, a_hlo, a_hhi, a_hlo2, a_hhi2, a_rlo, a_rhi, a_pt1, a_pt2, a_rp1, a_rp2, a_rp3, a_brace_lo, a_brace_hi};
+            int cnt = 0;
+            auto emit = [&](bool active, int node_) {        // (every lane calls it: the ballots are the wave's)
+                if (__builtin_amdgcn_ballot_w64(active) == 0) return;
+                const int slot = active ? (int)ts_of[node_] : -1;
+                bool mine = false;
+                if (slot >= 0) mine = atomicMax(&mark[slot], tagf) != tagf;      // (the tags count upwards within a launch)
+                const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
+                if (mine) {
+                    const int pos = cnt + (int)__builtin_popcountll(mk & lt_mask);
+                    if (pos < kSegList) l_j[pos] = slot;
+                }
+                cnt += (int)__builtin_popcountll(mk);
+            };
+            auto emit_height = [&](bool active, int w) {     // a node whose height is written: its branch and its daughters'
+                emit(active, w);
+                const int nc = active ? tb_nch[w] : 0;
+                emit(nc > 0, active ? tb_first[w] : 0);
+                emit(nc > 1, active ? tb_second[w] : 0);
+            };
+            for (int w0 = A.hlo; w0 < A.hhi; w0 += 64) emit_height(w0 + lane < A.hhi, w0 + lane);
+            for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
+            for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
+            {
+                // the single nodes in ONE pass: lanes 0 .. 2 the first height-written node with its daughters, 3 .. 5 the second, 6 .. 8
+                // the three rate-written ones
+                const int g = lane / 3, r = lane - 3 * g;
+                int cand = -1;
+                if (lane < 6) {
+                    const int base = (g == 0) ? A.pt1 : A.pt2;
+                    if (base >= 0) cand = (r == 0) ? base : (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+                } else if (lane < 9) {
+                    cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
+                }
+                emit(cand >= 0, cand >= 0 ? cand : 0);
+            }
+            for (int i = A.brace_lo; i < A.brace_hi; ++i) {
+                const int x = M.brace_nodes[i];
+                emit_height(lane == 0, x);                   // (SLIDE_BRACE_CONTRA also writes the rates of x and its daughters: the same slots)
+            }
+            if (cnt > kSegList) cnt = -1;                    // (cannot happen for a proposal mh_capi.cpp put into a segment: the chain wave says so)
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // the list is in LDS before any lane reads it
+            __builtin_amdgcn_wave_barrier();
+            return cnt;
+        };
+        int p_cur = sched[0];
+        int kind_cur = M.kind[p_cur], node_cur = M.node[p_cur];
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int tag = (int)gs + 1;
-            (void)seg_poll(w_req, tag, 0);
-            // ---- the distances the written nodes feed: a written node's own slot, and its daughters' when its height is written.  Each
-            // slot once (the first lane to exchange the slot's mark for this step's lists it), with its new distance and the delta.
+            const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p_cur;
+            const int kind_next = M.kind[p_next], node_next = M.node[p_next];      // (the next step's row travels while this step computes)
+            // ---- AHEAD of the request, while the chain wave draws the proposal: which nodes the proposal writes follows from its table row
+            // and the topology alone (mh_propose_ranges), hence the list of moved slots; the first columns of L^-1 they need are touched (one
+            // load per column reaches each of its lines: an L2 miss per line now instead of after the request).  The guess is compared with
+            // the transform the proposal posts; the rare mismatch (a proposal that bails out on an invalid state) lists again.
+            PropApply G;
+            mh_propose_ranges(Mt, kind_cur, node_cur, G);
+            int c_kind = G.kind, c_hlo = G.hlo, c_hhi = G.hhi, c_hlo2 = G.hlo2, c_hhi2 = G.hhi2, c_rlo = G.rlo, c_rhi = G.rhi, c_pt1 = G.pt1, c_pt2 = G.pt2, c_rp1 = G.rp1, c_rp2 = G.rp2, c_rp3 = G.rp3, c_brace_lo = G.brace_lo, c_brace_hi = G.brace_hi;
+            bool c_moves = seg_moves_likelihood(kind_cur, node_cur);
             int cnt = 0;
-            if (*w_moves) {
-                const PropApply A = *A_lds;
-                const double s1 = *w_s1;
-                double d0 = 0.0;                             // the new distance of slot 0, in the lane that listed it
-                bool have0 = false;
-                auto emit = [&](bool active, int node_) {    // (every lane calls it: the ballots are the wave's)
-                    if (__builtin_amdgcn_ballot_w64(active) == 0) return;
-                    const int slot = active ? (int)ts_of[node_] : -1;
-                    bool mine = false;
-                    if (slot >= 0) mine = atomicExch(&mark[slot], tag) != tag;
-                    const uint64_t mk = __builtin_amdgcn_ballot_w64(mine);
-                    if (mine) {
-                        const int pos = cnt + (int)__builtin_popcountll(mk & lt_mask);
-                        // likelihoodFunctionWrapper: distances = (tH * rMu) * sumFirstTwo (times * rates)   (app/Probability.hs:195-207), the
-                        // arithmetic of load_tree (mvn_device.hpp) and of k_mh_step_wg's X1
-                        const int a = ts_node[slot], pa = ts_parent[slot];
-                        double x = (Hp[pa] - Hp[a]) * Rp[a];
-                        if (slot == 0) x = x + (Hp[0] - Hp[rr]) * Rp[rr];
-                        x = x * s1;
-                        if (pos < kSegList) {
-                            l_j[pos] = slot;
-                            l_dnew[pos] = x;
-                            l_delta[pos] = x - dcur[slot];
-                        }
-                        if (slot == 0) {
-                            d0 = x;
-                            have0 = true;
-                        }
+            constexpr int kPre = (R >= 16) ? 1 : (R >= 12) ? 2 : kSegCols;   // (the register file: one column of 16 doubles per lane at R = 16, four columns below R = 12)
+            double pcol[kPre][R];                            // the first columns, requested ahead of the request
+            for (int pass = 0; pass < 2; ++pass) {
+                cnt = c_moves ? build_list(c_kind, c_hlo, c_hhi, c_hlo2, c_hhi2, c_rlo, c_rhi, c_pt1, c_pt2, c_rp1, c_rp2, c_rp3, c_brace_lo, c_brace_hi, 2 * tag + pass) : 0;
+                // the first batch of columns of L^-1 (the list's first slots) is requested now: an L2 miss each, under way while the
+                // proposal is still being drawn
+                if (cnt > 0) {
+#pragma unroll
+                    for (int u = 0; u < kPre; ++u) {
+                        const int m = (u < cnt) ? u : cnt - 1;
+                        const int j = __builtin_amdgcn_readfirstlane(l_j[m]);
+                        const double* wc = V.Wc + (size_t)j * NPad + lane;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) pcol[u][k] = wc[64 * k];
                     }
-                    cnt += (int)__builtin_popcountll(mk);
-                };
-                auto emit_height = [&](bool active, int w) {    // a node whose height is written: its branch and its daughters'
-                    emit(active, w);
-                    const int nc = active ? tb_nch[w] : 0;
-                    emit(nc > 0, active ? tb_first[w] : 0);
-                    emit(nc > 1, active ? tb_second[w] : 0);
-                };
-                for (int w0 = A.hlo; w0 < A.hhi; w0 += 64) emit_height(w0 + lane < A.hhi, w0 + lane);
-                for (int w0 = A.hlo2; w0 < A.hhi2; w0 += 64) emit_height(w0 + lane < A.hhi2, w0 + lane);
-                for (int w0 = A.rlo; w0 < A.rhi; w0 += 64) emit(w0 + lane < A.rhi, w0 + lane);
-                {
-                    // the single nodes in ONE pass: lanes 0 .. 2 the first height-written node with its daughters, 3 .. 5 the second, 6 .. 8
-                    // the three rate-written ones
-                    const int g = lane / 3, r = lane - 3 * g;
-                    int cand = -1;
-                    if (lane < 6) {
-                        const int base = (g == 0) ? A.pt1 : A.pt2;
-                        if (base >= 0) cand = (r == 0) ? base : (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
-                    } else if (lane < 9) {
-                        cand = (r == 0) ? A.rp1 : (r == 1) ? A.rp2 : A.rp3;
-                    }
-                    emit(cand >= 0, cand >= 0 ? cand : 0);
                 }
-                for (int i = A.brace_lo; i < A.brace_hi; ++i) {
-                    const int x = M.brace_nodes[i];
-                    emit_height(lane == 0, x);               // (SLIDE_BRACE_CONTRA also writes the rates of x and its daughters: the same slots)
+                if (pass == 1) break;
+                (void)seg_poll(w_req, tag, 0);
+                const bool moves = *w_moves != 0;
+                const int n_kind = A_lds->kind, n_hlo = A_lds->hlo, n_hhi = A_lds->hhi, n_hlo2 = A_lds->hlo2, n_hhi2 = A_lds->hhi2, n_rlo = A_lds->rlo, n_rhi = A_lds->rhi, n_pt1 = A_lds->pt1, n_pt2 = A_lds->pt2, n_rp1 = A_lds->rp1, n_rp2 = A_lds->rp2, n_rp3 = A_lds->rp3, n_brace_lo = A_lds->brace_lo, n_brace_hi = A_lds->brace_hi;
+                const bool same_ranges = n_kind == c_kind && n_hlo == c_hlo && n_hhi == c_hhi && n_hlo2 == c_hlo2 && n_hhi2 == c_hhi2 && n_rlo == c_rlo && n_rhi == c_rhi && n_pt1 == c_pt1 && n_pt2 == c_pt2 && n_rp1 == c_rp1 && n_rp2 == c_rp2 && n_rp3 == c_rp3 && n_brace_lo == c_brace_lo && n_brace_hi == c_brace_hi;
+                if (moves == c_moves && (!moves || same_ranges)) break;
+                c_kind = n_kind;
+                c_hlo = n_hlo;
+                c_hhi = n_hhi;
+                c_hlo2 = n_hlo2;
+                c_hhi2 = n_hhi2;
+                c_rlo = n_rlo;
+                c_rhi = n_rhi;
+                c_pt1 = n_pt1;
+                c_pt2 = n_pt2;
+                c_rp1 = n_rp1;
+                c_rp2 = n_rp2;
+                c_rp3 = n_rp3;
+                c_brace_lo = n_brace_lo;
+                c_brace_hi = n_brace_hi;
+                c_moves = moves;
+            }
+            // ---- the listed slots' new distances from the proposed state (LDS) and the deltas against the current ones:
+            // likelihoodFunctionWrapper, distances = (tH * rMu) * sumFirstTwo (times * rates) (app/Probability.hs:195-207) -- the arithmetic of
+            // load_tree (mvn_device.hpp) and of k_mh_step_wg's X1
+            if (cnt > 0) {
+                const double s1 = *w_s1;
+                double d0 = 0.0;                             // the new distance of slot 0, in the lane that holds it
+                bool have0 = false;
+                for (int m = lane; m < cnt; m += 64) {
+                    const int slot = l_j[m];
+                    const int a = ts_node[slot], pa = ts_parent[slot];
+                    double x = (Hp[pa] - Hp[a]) * Rp[a];
+                    if (slot == 0) x = x + (Hp[0] - Hp[rr]) * Rp[rr];
+                    x = x * s1;
+                    l_dnew[m] = x;
+                    l_delta[m] = x - dcur[slot];
+                    if (slot == 0) {
+                        d0 = x;
+                        have0 = true;
+                    }
                 }
                 const uint64_t m0 = __builtin_amdgcn_ballot_w64(have0);
                 if (lane == 0) *w_have0 = (m0 != 0) ? 1 : 0;
@@ -253,15 +318,24 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
                     const double lj1 = log(1.0 / mh_readlane64(d0, (int)__builtin_ctzll(m0)));     // jacobianRootBranch, :393-410
                     if (lane == 0) *w_lj = lj1;
                 }
-                if (cnt > kSegList) cnt = -1;                // (cannot happen for a proposal mh_capi.cpp put into a segment: the chain wave says so)
-                __builtin_amdgcn_s_waitcnt(0xc07f);          // the list is in LDS before any lane reads it
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // the list's values are in LDS before any lane reads them
                 __builtin_amdgcn_wave_barrier();
+            } else if (lane == 0) {
+                *w_have0 = 0;
             }
             double zp[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) zp[k] = zc[k];
             // kSegCols columns in flight: a column is an L2 miss (W is 8 MB at N = 1023), a batch costs its latency once
-            for (int m0 = 0; m0 < cnt; m0 += kSegCols) {
+            if (cnt > 0) {                                   // the first batch: the columns requested ahead of the request
+#pragma unroll
+                for (int u = 0; u < kPre; ++u) {
+                    const double dl = (u < cnt) ? l_delta[u] : 0.0;    // (past the end: the last column again with weight 0: exact)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) zp[k] = fma(dl, pcol[u][k], zp[k]);
+                }
+            }
+            for (int m0 = kPre; m0 < cnt; m0 += kSegCols) {
                 double col[kSegCols][R], dl[kSegCols];
 #pragma unroll
                 for (int u = 0; u < kSegCols; ++u) {
@@ -294,6 +368,9 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
             }
+            p_cur = p_next;
+            kind_cur = kind_next;
+            node_cur = node_next;
         }
         if (valid) {
 #pragma unroll
