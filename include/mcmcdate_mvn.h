@@ -72,7 +72,10 @@ const char* mcd_last_error(void);
  * variable MCD_WIDE=0|1, read when the library is loaded, sets its initial value to SWEEP | MULTIPLY).  Both return the previous value.
  * The gradient entry points follow the same choice; above N = 256 the multiply form uses the gradient rows (`G`, `g_heights`)
  * as scratch while it runs: a call whose gradient array IS an input array (in place) takes the sweeps instead; partially
- * overlapping arrays are not supported by either form.
+ * overlapping arrays are not supported by either form.  Above N = 768 the gradients have no sweep form (sixteen row blocks of both
+ * sweeps' staging do not fit the register file): whatever the batch and the form asked for they take the row-split form in pieces
+ * of at most 1024 chains; mcd_mvn_grad_batch may still be called in place, mcd_tree_grad_batch may write g_heights over heights and
+ * g_rates over rates, but an output over the OTHER input array is refused there (MCD_ERR_HIP / invalid value).
  * Stream capture: every entry point that takes a stream may be captured into a hipGraph.  The row-split form gives a stream
  * under capture a scratch set of the capture's own, so a graph may be replayed on any stream while eager calls go on on the
  * stream it was captured from; two executable graphs instantiated from ONE capture must not be replayed concurrently.

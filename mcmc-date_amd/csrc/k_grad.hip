@@ -49,15 +49,23 @@ template <int R>
 static hipError_t launch_grad_R(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G,
                                 int64_t ldg, hipStream_t st)
 {
+    // (the gradient holds the forward AND the backward sweep's staging: above R = 6 four compute waves per workgroup, and at R = 12 four
+    // loader waves, no longer fit two waves per SIMD -- 140 .. 1 219 spilled registers -- so those sizes take two compute waves, and two
+    // loaders from R = 12: one wave per SIMD, the whole register file.  The sweeps are the fallback there: up to 1024 chains the row split
+    // serves the gradient, from 2048 the multiply form.)
     auto go = [&](auto cw_tag) {
-        constexpr int CW = decltype(cw_tag)::value, LW = Cfg<R>::LW;
+        constexpr int CW = decltype(cw_tag)::value, LW = (R == 12) ? 2 : Cfg<R>::LW;
         const unsigned grid = (unsigned)((batch + CW - 1) / CW);
         hipLaunchKernelGGL((k_grad<R, 1, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, X, ldx, batch, ll, G, ldg);
     };
-    if (pick_geometry(batch).cw == 2)
+    if constexpr (R >= 8) {
         go(std::integral_constant<int, 2>{});
-    else
-        go(std::integral_constant<int, 4>{});
+    } else {
+        if (pick_geometry(batch).cw == 2)
+            go(std::integral_constant<int, 2>{});
+        else
+            go(std::integral_constant<int, 4>{});
+    }
     return hipGetLastError();
 }
 
@@ -102,15 +110,29 @@ hipError_t launch_grad(const MvnDev& M, const double* X, int64_t ldx, int64_t ba
     }
     if (M.R == 6 || M.R == 8) return launch_grad_g1(M, X, ldx, batch, ll, G, ldg, st);
     if (M.R == 12) return launch_grad_g2(M, X, ldx, batch, ll, G, ldg, st);
-    if (M.R == 16) return launch_grad_g3(M, X, ldx, batch, ll, G, ldg, st);
+    if (M.R == 16) {
+        // N > 768: no sweep form of the gradient (16 row blocks of both sweeps' staging do not fit two waves per SIMD: 260 .. 1 200 spilled
+        // registers; it was the fallback only -- 207 us at N = 1024 x 512 chains against the row split's 42): whatever the batch and
+        // the form asked for, the row split in pieces of at most 1024 chains (in place is fine: its first pass has read every x)
+        if (M.split == nullptr) return hipErrorInvalidValue;
+        for (int64_t c0 = 0; c0 < batch; c0 += kSplitMaxBatch) {
+            const int64_t cnt = (batch - c0 < kSplitMaxBatch) ? batch - c0 : kSplitMaxBatch;
+            if (hipError_t e = launch_grad_split(M, X + c0 * ldx, ldx, cnt, ll + c0, G + c0 * ldg, ldg, st)) return e;
+        }
+        return hipSuccess;
+    }
 #else
 hipError_t MCD_CAT(launch_grad_g, MCD_RGROUP)(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, double* G, int64_t ldg,
                        hipStream_t st)
 {
 #endif
+#if MCD_RGROUP == 3
+    return hipErrorInvalidValue;                           // (R = 16: launch_grad takes the row split, see there)
+#else
 #define CALL(R) launch_grad_R<R>(M, X, ldx, batch, ll, G, ldg, st)
     MCD_DISPATCH_R(M.R, CALL)
 #undef CALL
+#endif
 }
 
 }  // namespace mcd

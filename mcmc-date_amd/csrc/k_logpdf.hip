@@ -52,9 +52,9 @@ static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx,
     Geometry g = pick_geometry(batch);
     if (g.cw == 2)
         launch_geom<R, 1, 2, Cfg<R>::LW>(M, X, ldx, batch, ll, st);
-    else if (g.bt == 1)
+    else if (g.bt == 1 || R >= 16)                         // (two chains per compute wave do not fit the register file at R = 16: 1 048 spilled registers)
         launch_geom<R, 1, 4, Cfg<R>::LW>(M, X, ldx, batch, ll, st);
-    else
+    else if constexpr (R < 16)
         launch_geom<R, 2, 4, Cfg<R>::LW>(M, X, ldx, batch, ll, st);
     return hipGetLastError();
 }

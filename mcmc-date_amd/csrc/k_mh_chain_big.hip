@@ -969,7 +969,10 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
 // workgroups (one workgroup per CU: 512 chains per round), state + tables + the 64 KiB ring within a CU's LDS
 bool mh_chain_big_available(const MhDev& M, const MvnDev& V)
 {
-    if (V.R < 1 || V.R > 8 || M.n_nodes > 64 * V.R + 2 || M.batch > 1024) return false;   // (1024 chains: two rounds of workgroups, still ahead of two launches per step)
+    // (R <= 4: up to 258 nodes.  Round 3 also built R = 6 and 8 -- 514 nodes -- which the segment kernel has superseded from 259 nodes and which
+    // did not fit the register file: 204 / 420 bytes of scratch per lane; removed in round 4.  1024 chains: two rounds of workgroups, still
+    // ahead of two launches per step)
+    if (V.R < 1 || V.R > 4 || M.n_nodes > 64 * V.R + 2 || M.batch > 1024) return false;
     return mhb_lds_bytes(M.n_nodes, M.n_prop, V.R) + 64 * 1024 <= 160 * 1024;
 }
 
@@ -1005,8 +1008,6 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
         case 2: return launch_big_R<2>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         case 3: return launch_big_R<3>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         case 4: return launch_big_R<4>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
-        case 6: return launch_big_R<6>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
-        case 8: return launch_big_R<8>(M, V0, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
         default: return hipErrorInvalidValue;
         }
     }
@@ -1015,8 +1016,6 @@ hipError_t launch_mh_chain_big(const MhDev& M, const MvnDev& V, const TreeDev& T
     case 2: return launch_big_R<2>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     case 3: return launch_big_R<3>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     case 4: return launch_big_R<4>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
-    case 6: return launch_big_R<6>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
-    case 8: return launch_big_R<8>(M, V, T, P, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -89,16 +89,21 @@ static hipError_t launch_tree_grad_R(const MvnDev& M, const TreeDev& T, const do
                                      const double* tH, const double* rMu, int64_t batch, double* ll, double* gH,
                                      double* gR, double* gtH, double* grMu, hipStream_t st)
 {
+    // (as k_grad.hip: from R = 8 two compute waves per workgroup, from R = 12 two loader waves -- one wave per SIMD, no spilled registers)
     auto go = [&](auto cw_tag) {
-        constexpr int CW = decltype(cw_tag)::value, LW = Cfg<R>::LW;
+        constexpr int CW = decltype(cw_tag)::value, LW = (R == 12) ? 2 : Cfg<R>::LW;
         const unsigned grid = (unsigned)((batch + CW - 1) / CW);
         hipLaunchKernelGGL((k_tree_grad<R, CW, LW>), dim3(grid), dim3(64 * (CW + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch,
                        ll, gH, gR, gtH, grMu);
     };
-    if (pick_geometry(batch).cw == 2)
+    if constexpr (R >= 8) {
         go(std::integral_constant<int, 2>{});
-    else
-        go(std::integral_constant<int, 4>{});
+    } else {
+        if (pick_geometry(batch).cw == 2)
+            go(std::integral_constant<int, 2>{});
+        else
+            go(std::integral_constant<int, 4>{});
+    }
     return hipGetLastError();
 }
 
@@ -147,16 +152,32 @@ hipError_t launch_tree_grad(const MvnDev& M, const TreeDev& T, const double* H, 
     }
     if (M.R == 6 || M.R == 8) return launch_tree_grad_g1(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
     if (M.R == 12) return launch_tree_grad_g2(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
-    if (M.R == 16) return launch_tree_grad_g3(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st);
+    if (M.R == 16) {
+        // N > 768: no sweep form of the tree gradient (k_grad.hip has the reason): the row split in pieces of at most 1024 chains, whatever
+        // the batch and the form asked for.  Its one restriction: an output that aliases the OTHER input array (the height gradient over the
+        // rates or the reverse) is refused -- include/mcmcdate_mvn.h says so.
+        if (M.split == nullptr || (const double*)gH == Rt || (const double*)gR == H) return hipErrorInvalidValue;
+        for (int64_t c0 = 0; c0 < batch; c0 += kSplitMaxBatch) {
+            const int64_t cnt = (batch - c0 < kSplitMaxBatch) ? batch - c0 : kSplitMaxBatch;
+            if (hipError_t e = launch_tree_grad_split(M, T, H + c0 * lds, Rt + c0 * lds, lds, tH + c0, rMu + c0, cnt, ll + c0, gH + c0 * lds, gR + c0 * lds,
+                                                      gtH + c0, grMu + c0, st))
+                return e;
+        }
+        return hipSuccess;
+    }
 #else
 hipError_t MCD_CAT(launch_tree_grad_g, MCD_RGROUP)(const MvnDev& M, const TreeDev& T, const double* H, const double* Rt, int64_t lds,
                             const double* tH, const double* rMu, int64_t batch, double* ll, double* gH, double* gR,
                             double* gtH, double* grMu, hipStream_t st)
 {
 #endif
+#if MCD_RGROUP == 3
+    return hipErrorInvalidValue;                           // (R = 16: launch_tree_grad takes the row split, see there)
+#else
 #define CALL(R) launch_tree_grad_R<R>(M, T, H, Rt, lds, tH, rMu, batch, ll, gH, gR, gtH, grMu, st)
     MCD_DISPATCH_R(M.R, CALL)
 #undef CALL
+#endif
 }
 
 }  // namespace mcd

@@ -87,7 +87,8 @@ static hipError_t launch_tree_logpdf_R(const MvnDev& M, const TreeDev& T, const 
         if constexpr (PRIOR) {
             // two waves per chain while every workgroup of both roles is resident at once (two of these workgroups fit a CU)
             const int per_wg = waves / 2;
-            const int64_t like_wgs = (batch + g.cw * g.bt - 1) / (g.cw * g.bt);
+            const int bt_eff = (R >= 16) ? 1 : g.bt;
+            const int64_t like_wgs = (batch + g.cw * bt_eff - 1) / (g.cw * bt_eff);
             const bool two = (waves % 2 == 0) && like_wgs + (J.M.batch + per_wg - 1) / per_wg <= 512 &&
                              (size_t)per_wg * mh_prior_role2_doubles(J.M.n_nodes) * sizeof(double) <= (size_t)2 * Cfg<R>::SU * 64 * 16;
             J.wpc = two ? 2 : 1;
@@ -102,6 +103,11 @@ static hipError_t launch_tree_logpdf_R(const MvnDev& M, const TreeDev& T, const 
         const unsigned grid = (unsigned)((batch + 1) / 2) + prior_wgs(2 + LW);
         hipLaunchKernelGGL((k_tree_logpdf<R, 1, 2, LW, PRIOR>), dim3(grid), dim3(64 * (2 + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, J);
     } else if (g.bt == 1) {
+        const unsigned grid = (unsigned)((batch + 3) / 4) + prior_wgs(4 + LW);
+        hipLaunchKernelGGL((k_tree_logpdf<R, 1, 4, LW, PRIOR>), dim3(grid), dim3(64 * (4 + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, J);
+    } else if constexpr (R >= 16) {
+        // (two chains per compute wave do not fit the register file at R = 16: 1 188 spilled registers; such a batch -- more than 4096 chains on
+        // the sweep -- is only reached with the form forced, the automatic choice takes the multiply form there)
         const unsigned grid = (unsigned)((batch + 3) / 4) + prior_wgs(4 + LW);
         hipLaunchKernelGGL((k_tree_logpdf<R, 1, 4, LW, PRIOR>), dim3(grid), dim3(64 * (4 + LW)), 0, st, M, T, H, Rt, lds, tH, rMu, batch, ll, logjac, J);
     } else {                                               // large batches: two chains per compute wave share every factor read

@@ -503,8 +503,18 @@ int mcd_mh_mc3_swap(mcd_mh_t* m, int n_swaps, const double* gathered, int world,
         gathered = D.post;
         world = 1;
         chains_per_rank = D.batch;
-    } else if (world < 1 || chains_per_rank < 1 || (int64_t)world * chains_per_rank < C.total) {
-        return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: world x chains_per_rank does not cover the global chains");
+    } else {
+        // the swap kernel reads global chain c at gathered[c / chains_per_rank][.][c % chains_per_rank] and writes this handle's temperatures at
+        // c - chain0: equal shards, this handle holding exactly the shard of rank chain0 / chains_per_rank -- anything else would silently
+        // read another chain's ln posterior
+        if (world < 1 || chains_per_rank < 1 || (int64_t)world * chains_per_rank != C.total)
+            return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: world x chains_per_rank must equal the global number of chains (%lld)", (long long)C.total);
+        if (chains_per_rank != D.batch)
+            return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: chains_per_rank (%lld) is not this handle's batch (%lld): the shards must be equally large",
+                         (long long)chains_per_rank, (long long)D.batch);
+        if (D.chain0 % chains_per_rank != 0 || D.chain0 / chains_per_rank >= world)
+            return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_mc3_swap: this handle's first chain (%lld) is not the start of a shard of %lld chains", (long long)D.chain0,
+                         (long long)chains_per_rank);
     }
     MHIP_TRY(hipSetDevice(m->device));
     // enqueued on the sampler's stream, behind the run and the all-gather that produced `gathered`: no host synchronisation

@@ -217,7 +217,9 @@ __device__ __forceinline__ void stage_store(const Stage<R, LW>& st, d2* slot, in
 // LDS -> VGPR prefetch distance (column pairs).  One wave per SIMD has nothing else to overlap the
 // ~100-cycle LDS latency with, so the factor values of pair p + LDS_PD are requested before pair p
 // is applied.
-constexpr int LDS_PD = 2;
+// (At R = 16 a prefetch buffer is 16 row blocks deep: one pair ahead there -- with two the gradient kernels, which hold both sweeps'
+// buffers, spill 200 to 1 200 registers.  The sweeps are the fallback at that size: the row split and the multiply form serve it.)
+template <int R> struct LdsPd { static constexpr int PD = (R >= 16) ? 1 : 2; };
 
 // =======================================================================================
 // forward sweep
@@ -229,6 +231,7 @@ __device__ __forceinline__ void fwd_apply(double (&d)[R][BT], const d2* slot, in
     constexpr int jj0 = JJ0;
     constexpr int CP = Cfg<R>::CP;
     constexpr int NK = R - JB;
+    constexpr int LDS_PD = LdsPd<R>::PD;
     constexpr int NBUF = LDS_PD + 1;
     d2 l[NBUF][NK];
 #pragma unroll
@@ -395,6 +398,7 @@ __device__ __forceinline__ void bwd_apply(double (&d)[R][BT], const d2* slot, in
     constexpr int ii0 = II0;
     constexpr int CP = Cfg<R>::CP;
     constexpr int NK = IB + 1;
+    constexpr int LDS_PD = LdsPd<R>::PD;
     constexpr int NBUF = LDS_PD + 1;
     d2 u[NBUF][NK];
     // pairs are visited CP-1, CP-2, ..., 0; q counts visited pairs

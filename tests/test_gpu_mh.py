@@ -223,12 +223,13 @@ def test_workgroup_per_chain_step_gives_the_same_chains(gpu, n_leaves, B, knobs)
         assert np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(g1, g2))
 
 
-@pytest.mark.parametrize("n_leaves,B", [(33, 9), (40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777), (150, 64), (193, 33), (257, 512)])
+@pytest.mark.parametrize("n_leaves,B", [(33, 9), (40, 7), (70, 64), (129, 512), (129, 33), (100, 16), (129, 777)])
 @pytest.mark.parametrize("incremental", ["1", "0"])
 def test_streaming_chain_kernel_equals_two_launch_path(gpu, n_leaves, B, incremental, knobs):
-    """Trees of 65 .. 514 nodes at up to 1024 chains (777: two rounds of workgroups) run the whole schedule in one launch, two
-    chains per workgroup, the factor streamed through the sweep's LDS ring (k_mh_chain_big.hip; 150 / 193 / 257 leaves = 299 / 385 /
-    513 nodes: six and eight 64-row blocks per lane).  The same proposal, prior and sweep
+    """Trees of 65 .. 258 nodes at up to 1024 chains (777: two rounds of workgroups) run the whole schedule in one launch, two
+    chains per workgroup, the factor streamed through the sweep's LDS ring (k_mh_chain_big.hip; round 3 also built it for six and
+    eight 64-row blocks per lane -- up to 514 nodes --, which spilled and which the segment kernel superseded: removed in round 4,
+    those trees are covered by test_incremental_likelihood_on_large_trees and test_large_tree_uses_the_per_phase_path).  The same proposal, prior and sweep
     code on the same numbers as the two-launch path (MCD_MH_PER_PHASE=1) -- odd batches (a chain wave without a chain), two clock
     models, calibrations and a constraint, runs continued by the other path.
     MCD_MH_INCREMENTAL=0 (every proposal through the full sweep): bit-identical traces, states, posteriors, tuning counters, age
@@ -817,7 +818,8 @@ def test_prior_only_node_ages_against_the_references_own_samples(gpu):
     assert dev[(b, True)][0] > 0.01, dev                                            # the determinants move the root by more than 1 %
 
 
-def test_posterior_node_ages_against_the_references_own_samples(gpu, tmp_path):
+@pytest.mark.parametrize("native_sparse", [False, True])
+def test_posterior_node_ages_against_the_references_own_samples(gpu, tmp_path, native_sparse):
     """The reference's own POSTERIOR output pins the whole path -- prepare (with the graphical lasso), likelihood, prior, proposal
     cycle, Jacobians: the node ages of its six chains WITH data on the 7-taxon mtCDNApri analysis
     (`./run -s -f analysis.conf -c ul s r`: SparseMultivariateNormal 0.1, bench/comparison_with_mcmctree/README.md:615-632;
@@ -844,7 +846,9 @@ def test_posterior_node_ages_against_the_references_own_samples(gpu, tmp_path):
     topo = prep.topology
     cal = M.load_calibrations_from_tree(topo, paths["calibration_tree"])
     ht = M.get_mean_root_height(cal)
-    lik = M.MvnLikelihood(prep.lhd).bind_tree(topo)
+    # native_sparse: the Sparse record as it is -- the precision matrix in CSR on the device, mcd_mh_create_sparse, every proposal inside a
+    # segment launch (k_mh_segment_sparse.hip: 13 nodes, all 11 distances fit the list); else the densified record through the dense handle
+    lik = (M.SparseLikelihood(prep.lhd) if native_sparse else M.MvnLikelihood(prep.lhd)).bind_tree(topo)
     pf = M.PriorFunction(ht, "UncorrelatedLogNormal", cal, [], [], topo)
     ps, missing = M.proposals(topo, [], calibrations_available=True)
     assert missing == []
@@ -854,6 +858,7 @@ def test_posterior_node_ages_against_the_references_own_samples(gpu, tmp_path):
     smp.set_initial_state(x0)
     smp.burn_in()
     tr = MO.collect(smp, 8000, period=20)
+    assert ("segments over a sparse precision matrix" in smp.last_path()) == native_sparse
     ages = tr.ages()[:, :, post["nodes"]].reshape(-1, len(post["nodes"]))
     ref = {k: np.array(v) for k, v in post["pooled"].items()}
     dev = np.abs(ages.mean(axis=0) - ref["mean"]) / ref["mean"]

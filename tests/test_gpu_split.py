@@ -154,7 +154,10 @@ def test_row_split_gradient(gpu, n, batch):
     ll_s, G_s = lik.grad(X)
     lik.set_form("auto")
     assert np.max(np.abs(G_s - G)) <= gtol and np.all(np.abs(ll_s - ll) <= tol)
-    assert not np.array_equal(G_s, G)                        # really another kernel
+    if n <= 768:
+        assert not np.array_equal(G_s, G)                    # really another kernel
+    else:
+        assert np.array_equal(G_s, G)                        # (round 4: above N = 768 the gradient has no sweep form -- it spilled -- and takes the row split whatever is asked)
     for Gn in (8, 16, 32):
         with env(MCD_SPLIT_G=Gn):
             a = lik.grad(X)
@@ -205,7 +208,7 @@ def test_row_split_tree_gradient(gpu, leaves, batch):
     sc = max(np.abs(sw[1]).max(), np.abs(sw[2]).max())
     assert np.max(np.abs(sw[1] - out[1])) <= 1e-10 * sc and np.max(np.abs(sw[2] - out[2])) <= 1e-10 * sc
     assert np.max(np.abs(sw[3] - out[3]) / np.abs(sw[3])) <= 1e-9 and np.max(np.abs(sw[4] - out[4]) / np.abs(sw[4])) <= 1e-9
-    assert not np.array_equal(sw[1], out[1])
+    assert np.array_equal(sw[1], out[1]) == (n > 768)        # (above N = 768 the tree gradient has no sweep form since round 4: the row split whatever is asked)
     with env(MCD_SPLIT_G=16, MCD_SPLIT_SCATTER=1):
         og = tl.grad(st)
     assert np.max(np.abs(og[1] - out[1])) <= 1e-10 * sc and np.max(np.abs(og[2] - out[2])) <= 1e-10 * sc

@@ -65,6 +65,18 @@ def test_twin_reproduces_the_references_prior_only_samples(prior_runs):
     assert np.all(np.abs(rel - np.array(fx["relative_height"]["mean"])) <= 0.01 * np.array(fx["relative_height"]["mean"]))
 
 
+@pytest.mark.xfail(strict=True, reason="REPORTED DISCREPANCY, kept visible: with the calibration file AS COMMITTED ('U(100,2.5e-2)' on the root) the prior-only "
+                                        "root age is 15 % above the reference's committed samples; the match above holds under the hypothesis -- inferred from "
+                                        "the samples' own edge, not verifiable from the reference's sources -- that they were drawn with a root bound of 30")
+def test_prior_only_root_age_with_the_calibration_file_as_committed(prior_runs):
+    """The same comparison with the reference's committed input unchanged.  Expected to fail (strict): the day this passes, the inferred
+    bound is no longer needed and the hypothesis should be dropped from README / DESIGN."""
+    fx = A.golden("prior")
+    ref = {k: np.array(v) for k, v in fx["pooled"].items()}
+    _, mean, _, _, _ = summary(prior_runs[None], fx["nodes"])
+    assert np.all(np.abs(mean - ref["mean"]) <= 0.01 * ref["mean"]), (mean, ref["mean"])
+
+
 def test_the_samples_carry_a_root_bound_of_30(prior_runs):
     """The experiment that localises round 2's mismatch.  (1) The reference's root ages stop: no value above 31.6 in 29 100
     samples, the largest of every run within 31.3 .. 31.6, while under the committed bound 'U(100,2.5e-2)' 10 % of the twin's
