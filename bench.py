@@ -92,7 +92,7 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
     return out
 
 
-def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_period=0, swap_steps=0, rehearsal=False):
+def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_period=0, swap_steps=0, rehearsal=False, sparse=False):
     """Lock-step Metropolis-Hastings on the device (the metric's "= MCMC steps/sec x chains" reading):
     a synthetic tree of dimension n (255 for --n 256: 2L - 3 is odd), the reference's whole proposal cycle
     (app/Definitions.hs:127-278) in its shuffled order, B chains per GPU stepping together; one step = one proposal of the cycle,
@@ -110,8 +110,14 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_perio
 
     topo = S.random_topology((n + 3) // 2, seed=seed)
     nd = topo.n_nodes - 2
-    mu, sigma = S.random_spd_problem(nd, seed=seed)
-    tl = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index).bind_tree(topo)
+    if sparse:
+        # the reference's production configuration: the precision matrix kept sparse (band 3 + 4 random entries per row: the density of a
+        # graphical-lasso estimate), mcd_mh_create_sparse
+        _, assoc = S.banded_precision(nd, seed, 3, 4)
+        tl = M.SparseLikelihood(M.Sparse(np.random.default_rng(seed).uniform(0.01, 0.2, nd), assoc, 0.0), device=dev_index).bind_tree(topo)
+    else:
+        mu, sigma = S.random_spd_problem(nd, seed=seed)
+        tl = M.MvnLikelihood.from_covariance(mu, sigma, device=dev_index).bind_tree(topo)
     pf = M.PriorFunction(1.0, "UncorrelatedGamma", [], [], [], topo, device=dev_index)
     ps, _ = M.proposals(topo, [], calibrations_available=True)
     shard = SH.ChainShard(rank, world, world * B)
@@ -182,7 +188,8 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_perio
                      "swaps_tried": mc3.swaps_tried.tolist(), "swaps_accepted": mc3.swaps_accepted.tolist()}
     out = {"value": B * steps / dt, "unit": "proposal steps/s (lock steps x chains)", "us_per_lockstep": 1e6 * dt / steps,
            "n_nodes": int(topo.n_nodes), "dimension": int(nd), "chains": int(B), "lock_steps": int(steps),
-           "proposals_per_iteration": S_iter,
+           "proposals_per_iteration": S_iter, "likelihood": "sparse precision matrix (CSR on the device)" if sparse else "dense factor",
+           "lds_bytes_per_workgroup": smp.last_dynamic_lds(),
            "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device; " + smp.last_path()}
     if swap_info:
         out["mc3"] = swap_info
@@ -271,7 +278,7 @@ def sparse_measure(dev_index, n, B, steps, warm, band=3, extra=4):
     return dt, per, {"n": int(n), "nnz": int(sp.nnz), "chains": int(B), "chains_per_tile": int({True: 16}.get(False, 0)) or None,
                      "kernel_us_per_launch": per * 1e6, "alg_bytes_per_launch": alg, "fp64_tflops": flops,
                      "roofline": {"bound": "hbm", "achieved": alg / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": None}}
+                                  "traffic": measured_traffic(f"sparse_{n}x{B}")[0], "traffic_source": measured_traffic(f"sparse_{n}x{B}")[1]}}
 
 
 def haskell_toolchain():
@@ -476,6 +483,8 @@ def main():
                     help="log-density kernel form (mcd_set_logpdf_form); auto = multiply for N >= 96 and >= 2048 chains, N >= 32 and >= 8192")
     ap.add_argument("--kind", default="logpdf", choices=["logpdf", "grad", "tree", "tree_grad", "prior", "posterior", "mh", "sparse", "e2e"])
     ap.add_argument("--no-mh", action="store_true", help="skip the secondary Metropolis-Hastings measurement of the default run")
+    ap.add_argument("--sparse", action="store_true", help="--kind mh: the likelihood over a sparse precision matrix (mcd_mh_create_sparse), the reference's "
+                    "production configuration; any --dim up to 2046")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -517,7 +526,7 @@ def main():
         if world > 1:
             dist.barrier()
         r = mh_measure(dev_index, n, B, K, W, seed=3, rank=rank, world=world, swap_period=args.swap_period, swap_steps=args.swap_steps,
-                       rehearsal=rehearsal)
+                       rehearsal=rehearsal, sparse=args.sparse)
         elapsed = K * r["us_per_lockstep"] * 1e-6
         ranks = rank_report(dist, world, rank, elapsed, K, ctl_dev, rehearsal, r.get("rccl_comm_ranks"))
         if world > 1:
@@ -527,13 +536,16 @@ def main():
         if rank == 0:
             nd = r["dimension"]
             mh_traffic, mh_traffic_source = None, None
-            try:                                             # measured once per round by tools/collect_profiles_r03.sh
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
-                key = {(257, 512): "mh_257x512", (1025, 512): "mh_1025x512_segments"}.get((r["n_nodes"], B))
+            try:                                             # measured once per round by tools/collect_profiles_r0N.sh
+                import glob
+                fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+                tr = json.load(open(fn))
+                key = {(257, 512, False): "mh_257x512", (1025, 512, False): "mh_1025x512_segments", (2013, 512, True): "mh_sparse_2013x512",
+                       (1025, 512, True): "mh_sparse_1025x512"}.get((r["n_nodes"], B, args.sparse))
                 if key and key in tr:
                     mh_traffic = tr[key]["fetch_bytes_per_lock_step_corrected"] + tr[key].get("write_bytes_per_lock_step", 0.0)
-                    mh_traffic_source = f"profiles/r03_pmc_traffic.json[{key}]"
-            except (OSError, ValueError, KeyError):
+                    mh_traffic_source = f"profiles/{os.path.basename(fn)}[{key}]"
+            except (OSError, ValueError, KeyError, IndexError):
                 pass
             alg_b = (8.0 * (2 * r["n_nodes"] + 2) + 8.0 + (8.0 * nd + 4.0 * nd * (nd + 1)) / B) * B   # SURVEY.md 8(d), tree-state kernel
             print(json.dumps({
@@ -833,6 +845,16 @@ def main():
                     out["mh_config5_share"] = {k: r5[k] for k in ("value", "unit", "us_per_lockstep", "n_nodes", "dimension", "chains", "lock_steps", "what")}
                 except Exception as e:                       # (a secondary field must not take the line down)
                     out["mh_config5_share"] = {"error": repr(e)}
+            if n == 256 and B == 512:
+                # ... and over a SPARSE likelihood, the reference's production configuration (every published timing of the reference uses it): at
+                # config 5's size and at the size of its 1007-taxon example
+                try:
+                    out["mh_sparse"] = []
+                    for dim in (1024, 2012):
+                        rs = mh_measure(dev_index, dim, 512, 4000, 400, sparse=True)
+                        out["mh_sparse"].append({k: rs[k] for k in ("value", "unit", "us_per_lockstep", "n_nodes", "dimension", "chains", "lock_steps", "likelihood", "what")})
+                except Exception as e:
+                    out["mh_sparse"] = {"error": repr(e)}
         if world == 1 and args.kind == "logpdf" and not args.no_mh and B <= 1024:
             out["full_gpu"] = full_gpu_measure(dev_index, n)
         if world == 1 and not args.no_cpu_baseline:

@@ -385,6 +385,9 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t ste
 #define MCD_MH_PATH_SEGMENTS 8                /* 259 .. 1026 nodes: every run of steps between two dense proposals in one launch (state in LDS), a dense proposal by path 6's launches */
 #define MCD_MH_PATH_SEGMENTS_SPARSE 9         /* sparse likelihood, 3 .. 2048 nodes: the same with the quadratic form updated through the rows of the moved distances (k_mh_segment_sparse.hip); a dense proposal by the step kernel + the one-launch full form */
 int mcd_mh_last_path(const mcd_mh_t* m);
+/* LDS bytes per workgroup of the persistent kernel the last mcd_mh_run launched (reporting: a profiler's kernel trace shows the static group
+ * segment only, which is 0 for the kernels that size their LDS at launch); 0 when the run took per-step launches only. */
+int64_t mcd_mh_last_dynamic_lds(const mcd_mh_t* m);
 /* Auto tuning at the end of a tuning period [mcmc]: t' = clamp(t exp(2 (rate - optimal(dim))), 1e-5, 1e3). */
 int mcd_mh_tune(mcd_mh_t* m);
 /* tune: [batch][n_prop]; accepted / tried: counters since the last mcd_mh_tune / mcd_mh_reset_counters. */

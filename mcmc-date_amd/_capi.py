@@ -98,6 +98,7 @@ SYMBOLS = {
     "mcd_mh_reset_counters": (C.c_int, [_vp]),
     "mcd_mh_set_temperatures": (C.c_int, [_vp, _dp]),
     "mcd_mh_last_path": (C.c_int, [_vp]),
+    "mcd_mh_last_dynamic_lds": (C.c_int64, [_vp]),
     "mcd_mh_mc3_init": (C.c_int, [_vp, C.c_int, _dp, C.c_int64, C.c_uint64]),
     "mcd_mh_mc3_swap": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int64]),
     "mcd_mh_mc3_get": (C.c_int, [_vp, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp]),

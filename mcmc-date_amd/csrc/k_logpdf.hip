@@ -50,6 +50,15 @@ template <int R>
 static hipError_t launch_logpdf_R(const MvnDev& M, const double* X, int64_t ldx, int64_t batch, double* ll, hipStream_t st)
 {
     Geometry g = pick_geometry(batch);
+    if constexpr (R == 3 || R == 4) {
+        // Four loader waves beside the two compute waves at 129 .. 256 dimensions (round 4): one wave pulls 13 - 25 B/clk out of the L2, two do not
+        // reach the CU's ingest rate -- N = 256 x 512 chains 7.62 -> 7.41 us per launch, N = 192 5.83 -> 5.50 (same box; 3 waves 8.46 / 6 waves 8.20
+        // against 8.82 / 7.42 for 2 / 4 on a slower box); no gain at one or two row blocks.  mcd_set_option "MCD_LOADERS" = 2 keeps two (A/B).
+        if (g.cw == 2 && opt_or(OPT_LOADERS, 4) == 4) {
+            launch_geom<R, 1, 2, 4>(M, X, ldx, batch, ll, st);
+            return hipGetLastError();
+        }
+    }
     if (g.cw == 2)
         launch_geom<R, 1, 2, Cfg<R>::LW>(M, X, ldx, batch, ll, st);
     else if (g.bt == 1 || R >= 16)                         // (two chains per compute wave do not fit the register file at R = 16: 1 048 spilled registers)

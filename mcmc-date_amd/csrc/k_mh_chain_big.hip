@@ -989,6 +989,7 @@ static hipError_t launch_big_R(const MhDev& M, const MvnDev& V, const TreeDev& T
         if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_chain_big<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) return e;
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
+    note_dynamic_lds(dynb + 64 * 1024);                      // (+ the sweep's static LDS ring)
     hipLaunchKernelGGL(k_mh_chain_big<R>, dim3((unsigned)((M.batch + 1) / 2)), dim3(256), dynb, st, M, V, T, P, sched, n_steps, S, accumulate,
                        step0, seed, trace_alpha, trace_accept);
     return hipGetLastError();

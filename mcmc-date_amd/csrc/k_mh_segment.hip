@@ -406,6 +406,7 @@ static hipError_t launch_segment_RH(const MhDev& M, const MvnDev& V, const TreeD
         if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_segment<R, HELP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
+    note_dynamic_lds(dynb);
     hipLaunchKernelGGL((k_mh_segment<R, HELP>), dim3((unsigned)((M.batch + 1) / 2)), dim3(HELP ? 512 : 256), dynb, st, M, V, T, P, I, sched, n_steps, S, accumulate, step0,
                        seed, trace_alpha, trace_accept, gs_base, summands_kept, Q);
     return hipGetLastError();

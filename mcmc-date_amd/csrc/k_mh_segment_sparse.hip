@@ -514,6 +514,7 @@ static hipError_t launch_sseg(const MhDev& M, const SparseDev& Sp, const TreeDev
         if (hipError_t e = hipFuncSetAttribute((const void*)k_mh_segment_sparse<CPW, HELP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSsegLdsMax)) return e;
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
+    note_dynamic_lds(dynb);
     hipLaunchKernelGGL((k_mh_segment_sparse<CPW, HELP>), dim3((unsigned)((M.batch + CPW - 1) / CPW)), dim3(64 * CPW * (HELP ? 4 : 2)), dynb, st, M, Sp, T, P, I, sched, n_steps, S, accumulate,
                        step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, size_in_lds, list_all);
     return hipGetLastError();

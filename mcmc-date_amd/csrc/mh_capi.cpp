@@ -75,6 +75,7 @@ struct mcd_mh {
     int8_t* d_trace_accept = nullptr;
     size_t trace_cap = 0;
     int last_path = MCD_MH_PATH_NONE;   // which launch structure the last mcd_mh_run took
+    unsigned long long last_lds = 0;    // LDS bytes per workgroup of the persistent kernel that run launched last (0: none)
     bool list_all = false;              // sparse likelihood on a tree whose distance slots all fit the segment kernel's list
     // Metropolis-coupled MCMC (mcd_mh_mc3_*): temperature ranks of all GLOBAL chains, ladder, counters; phase = swap phases done
     mcd::Mc3Dev mc3{};
@@ -455,6 +456,7 @@ int mcd_mh_posterior_device(const mcd_mh_t* cm, const double** post, void** stre
 }
 
 int mcd_mh_last_path(const mcd_mh_t* m) { return m ? m->last_path : mfail(MCD_ERR_INVALID_ARG, "mcd_mh_last_path: NULL handle"); }
+int64_t mcd_mh_last_dynamic_lds(const mcd_mh_t* m) { return m ? (int64_t)m->last_lds : (int64_t)mfail(MCD_ERR_INVALID_ARG, "mcd_mh_last_dynamic_lds: NULL handle"); }
 
 // ---- Metropolis-coupled MCMC: the swap phase (k_mc3.hip) -----------------------------------------------------------------
 int mcd_mh_mc3_init(mcd_mh_t* m, int n_chains, const double* betas, int64_t total_chains, uint64_t seed)
@@ -545,6 +547,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
     if (!m->have_state) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_run: call mcd_mh_set_state first");
     if (n_iter < 0 || S <= 0 || (n_iter > 0 && !schedule)) return mfail(MCD_ERR_INVALID_ARG, "mcd_mh_run: bad schedule");
     if (n_iter == 0) return MCD_OK;
+    mcd::note_dynamic_lds(0);
     mcd::MhDev& D = m->dev;
     const size_t steps = (size_t)n_iter * (size_t)S;
     for (size_t i = 0; i < steps; ++i)
@@ -840,6 +843,7 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
         if (m->sp) m->last_path = MCD_MH_PATH_STEP_WG_SPARSE;
         }
     }
+    m->last_lds = mcd::last_dynamic_lds();
     if (trace_alpha) MHIP_TRY(hipMemcpyAsync(trace_alpha, m->d_trace_alpha, sizeof(double) * steps * B, hipMemcpyDeviceToHost, m->stream));
     if (trace_accept) MHIP_TRY(hipMemcpyAsync(trace_accept, m->d_trace_accept, steps * B, hipMemcpyDeviceToHost, m->stream));
     MHIP_TRY(hipStreamSynchronize(m->stream));

@@ -15,7 +15,7 @@ namespace {
 const char* const kNames[OPT_COUNT] = {
     "MCD_MH_PER_PHASE", "MCD_MH_SEGMENTS", "MCD_MH_INCREMENTAL", "MCD_MH_PRIOR", "MCD_MH_PRIOR_CACHE", "MCD_MH_STEP_WG", "MCD_MH_CHAIN_LW",
     "MCD_MH_INC_SLOTS", "MCD_MH_SPARSE_SLOTS", "MCD_SPLIT", "MCD_SPLIT_G", "MCD_SPLIT_SCATTER", "MCD_SPLIT_NOROT", "MCD_SPLIT_PROBE", "MCD_GEOM",
-    "MCD_WIDE_CT", "MCD_SPARSE_QUAD", "MCD_MH_PRIOR_WAVES"};
+    "MCD_WIDE_CT", "MCD_SPARSE_QUAD", "MCD_MH_PRIOR_WAVES", "MCD_LOADERS"};
 
 struct Table {
     std::atomic<int> v[OPT_COUNT];
@@ -45,6 +45,12 @@ int find(const char* name)
 }  // namespace
 
 int opt_get(Option o) { return table().v[o].load(std::memory_order_relaxed); }
+
+namespace {
+thread_local unsigned long long t_last_lds = 0;
+}
+void note_dynamic_lds(unsigned long long bytes) { t_last_lds = bytes; }
+unsigned long long last_dynamic_lds() { return t_last_lds; }
 
 }  // namespace mcd
 

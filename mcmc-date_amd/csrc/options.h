@@ -26,11 +26,16 @@ enum Option {
     OPT_WIDE_CT,            // 1 | 2 | 4: chains per workgroup / 16 of the multiply form
     OPT_SPARSE_QUAD,        // 1 / 0: force / forbid the one-launch form of the sparse log-density
     OPT_MH_PRIOR_WAVES,     // 0: the segment kernels without their prior waves (the chain wave evaluates the whole ln prior)
+    OPT_LOADERS,            // 2: two loader waves in the column sweep's 512-chain geometry at 129 .. 256 dimensions instead of four (A/B)
     OPT_COUNT
 };
 constexpr int MCD_OPT_UNSET = -2147483647 - 1;
 
 int opt_get(Option o);                                   // MCD_OPT_UNSET or the value
+// reporting: the dynamic LDS (bytes per workgroup) of the persistent Metropolis-Hastings kernel launched last by this thread -- the
+// profiler's kernel trace shows the static group segment only (0 for these kernels); mcd_mh_last_dynamic_lds reads it after a run
+void note_dynamic_lds(unsigned long long bytes);
+unsigned long long last_dynamic_lds();
 inline bool opt_is(Option o, int v) { return opt_get(o) == v; }
 inline int opt_or(Option o, int dflt) { const int v = opt_get(o); return v == MCD_OPT_UNSET ? dflt : v; }
 

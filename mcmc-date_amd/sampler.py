@@ -294,6 +294,10 @@ class Sampler:
         """Which launch structure the last run took (mcd_mh_last_path; PATHS)."""
         return PATHS.get(int(_capi.lib().mcd_mh_last_path(self._h)), "unknown")
 
+    def last_dynamic_lds(self) -> int:
+        """LDS bytes per workgroup of the persistent kernel the last run launched (mcd_mh_last_dynamic_lds)."""
+        return int(_capi.lib().mcd_mh_last_dynamic_lds(self._h))
+
     def autotune(self):
         _capi.check(_capi.lib().mcd_mh_tune(self._h))
 
