@@ -166,10 +166,11 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
 #endif
     __builtin_amdgcn_wave_barrier();
     int p = sched[0];
+    int p_next = sched[n_steps > 1 ? 1 : 0];                // (the schedule's entries two steps ahead: a row's loads need its index)
     PropRow row = mh_load_row(M, p);
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                 // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
-        const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : 0;
+        const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : 0;
         const PropRow row_next = mh_load_row(M, p_next);            // the next step's row travels while this step computes
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: the random draws that depend only on the proposal row and its
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
             age_q += a * a;
         }
         p = p_next;
+        p_next = p_next2;
         row = row_next;
         MH_TICK(4)
     }

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     if (wave >= CW) {
         const int lw = wave - CW;
         int p = sched[0];
+        int p_next = sched[n_steps > 1 ? 1 : 0];             // (the schedule's entries two steps ahead: a row's loads need its index)
         int kind = M.kind[p], node = M.node[p];
         const bool inc = V.Wc != nullptr;
         int sp = inc ? M.sparse[p] : 0;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         MhDev Mt_ = M;                                       // (mh_propose_ranges reads the sub tree sizes -- the chain waves' table in LDS -- and the braces' pointers)
         Mt_.size = reinterpret_cast<const int32_t*>(dyn) + nn;
         for (int64_t gs = 0; gs < n_steps; ++gs) {
-            const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
+            const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
             const int sp_next = inc ? M.sparse[p_next] : 0;
             // z of the current state (start of the launch, then every 256 steps), then the step's own sweep if its proposal is dense
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             kind = kind_next;
             node = node_next;
             sp = sp_next;
+            p_next = p_next2;
         }
         return;
     }
@@ -578,12 +580,13 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         }
     };
     int p = sched[0];
+    int p_next = sched[n_steps > 1 ? 1 : 0];                 // (the schedule's entries two steps ahead: a row's loads need its index)
     PropRow row = mh_load_row(M, p);
     double t_cur = tune[p];
     int row_sparse = inc ? M.sparse[p] : 0;
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
-        const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
+        const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
         const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
         const double t_next = tune[p_next];                  // ... and its tuning parameter (global memory: a load at the point of use stalled the proposal)
         const int sparse_next = inc ? M.sparse[p_next] : 0;
@@ -932,6 +935,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
             }
         }
         p = p_next;
+        p_next = p_next2;
         row = row_next;
         t_cur = t_next;
         row_sparse = sparse_next;

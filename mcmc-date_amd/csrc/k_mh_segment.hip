@@ -150,11 +150,11 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
     // ================================================================ prior waves
     if constexpr (HELP) {
         if (role == 2) {
-            seg_prior_wave<0>(M, P, Pst, L, Q, n_steps, seed, b, lane);
+            seg_prior_wave<0>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
             return;
         }
         if (role == 3) {
-            seg_prior_wave<1>(M, P, Pst, L, Q, n_steps, seed, b, lane);
+            seg_prior_wave<1>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
             return;
         }
     }
@@ -240,10 +240,11 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
             return cnt;
         };
         int p_cur = sched[0];
+        int p_next = sched[n_steps > 1 ? 1 : 0];             // (the schedule's entries two steps ahead: a row's loads need its index)
         int kind_cur = M.kind[p_cur], node_cur = M.node[p_cur];
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int tag = (int)gs + 1;
-            const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p_cur;
+            const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];      // (the next step's row travels while this step computes)
             // ---- AHEAD of the request, while the chain wave draws the proposal: which nodes the proposal writes follows from its table row
             // and the topology alone (mh_propose_ranges), hence the list of moved slots; the first columns of L^-1 they need are touched (one
@@ -256,6 +257,10 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
             int cnt = 0;
             constexpr int kPre = (R >= 16) ? 1 : (R >= 12) ? 2 : kSegCols;   // (the register file: one column of 16 doubles per lane at R = 16, four columns below R = 12)
             double pcol[kPre][R];                            // the first columns, requested ahead of the request
+            // ... and the next kTouch columns TOUCHED: one dword of each of a column's 128-byte lines, so that the lines are on their way into this
+            // XCD's L2 while the proposal is drawn (no registers for their values: the loads after the request then hit L2)
+            constexpr int kTouch = 3;
+            float touch[kTouch] = {0.0f, 0.0f, 0.0f};
             for (int pass = 0; pass < 2; ++pass) {
                 cnt = c_moves ? build_list(c_kind, c_hlo, c_hhi, c_hlo2, c_hhi2, c_rlo, c_rhi, c_pt1, c_pt2, c_rp1, c_rp2, c_rp3, c_brace_lo, c_brace_hi, 2 * tag + pass) : 0;
                 // the first batch of columns of L^-1 (the list's first slots) is requested now: an L2 miss each, under way while the
@@ -268,6 +273,15 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
                         const double* wc = V.Wc + (size_t)j * NPad + lane;
 #pragma unroll
                         for (int k = 0; k < R; ++k) pcol[u][k] = wc[64 * k];
+                    }
+                }
+                if (cnt > kPre) {
+#pragma unroll
+                    for (int u = 0; u < kTouch; ++u) {
+                        const int m = (kPre + u < cnt) ? kPre + u : cnt - 1;
+                        const int j = __builtin_amdgcn_readfirstlane(l_j[m]);
+                        const float* wl = reinterpret_cast<const float*>(V.Wc + (size_t)j * NPad);
+                        if (lane < 4 * R) touch[u] = wl[lane * 32];      // (a column: 64 R doubles = 4 R lines)
                     }
                 }
                 if (pass == 1) break;
@@ -351,6 +365,7 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
 #pragma unroll
                     for (int k = 0; k < R; ++k) zp[k] = fma(dl[u], col[u][k], zp[k]);
             }
+            asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]));      // (the touching loads have landed: their registers are free again)
             double sq = 0.0;
 #pragma unroll
             for (int k = 0; k < R; ++k) sq = fma(zp[k], zp[k], sq);
@@ -369,6 +384,7 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
                 __builtin_amdgcn_wave_barrier();
             }
             p_cur = p_next;
+            p_next = p_next2;
             kind_cur = kind_next;
             node_cur = node_next;
         }
@@ -377,6 +393,7 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
             for (int k = 0; k < R; ++k) I.zcur[b * I.NPz + 64 * k + lane] = zc[k];
             for (int j = lane; j < V.n; j += 64) I.X0[b * (int64_t)V.n + j] = dcur[j];
         }
+        seg_tail_distances(M, Q, words, Hp, Rp, ts_node, ts_parent, rr, V.n, n_steps, b, valid, lane);
         return;
     }
 
@@ -432,9 +449,12 @@ hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, 
 {
     MhSegPending Q{};
     Q.p_acc = -1;
+    Q.p_tail = -1;
     if (pending) Q = *pending;
+    Q.ahead_from = opt_or(OPT_MH_AHEAD_FROM, kSegAheadFrom);
     if (n_steps <= 0) return Q.p_acc >= 0 ? hipErrorInvalidValue : hipSuccess;
     if (Q.p_acc >= 0 && (Q.X1 == nullptr || (Q.z_in_zprop ? I.zprop == nullptr : I.zt == nullptr) || !summands_kept)) return hipErrorInvalidValue;
+    if (Q.p_tail >= M.n_prop || (Q.p_tail >= 0 && (Q.X1_tail == nullptr || M.psum == nullptr || M.psel == nullptr))) return hipErrorInvalidValue;
     if (n_steps > (1 << 28)) return hipErrorInvalidValue;    // (the hand-over words count steps in 30 bits)
     if (!mh_segment_available(M, V) || I.X0 == nullptr || I.zcur == nullptr || I.NPz != 64 * V.R) return hipErrorInvalidValue;
     if (V.R == 6) return launch_segment_R<6>(M, V, T, P, I, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, Q, st);

@@ -179,11 +179,11 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
     // ================================================================ prior waves
     if constexpr (HELP) {
         if (role == 2) {
-            seg_prior_wave<0>(M, P, Pst, L, Q, n_steps, seed, b, lane);
+            seg_prior_wave<0>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
             return;
         }
         if (role == 3) {
-            seg_prior_wave<1>(M, P, Pst, L, Q, n_steps, seed, b, lane);
+            seg_prior_wave<1>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
             return;
         }
     }
@@ -292,10 +292,11 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
         };
         constexpr int W = kSparseEllW;
         int p_cur = sched[0];
+        int p_next = sched[n_steps > 1 ? 1 : 0];             // (the schedule's entries two steps ahead: a row's loads need its index)
         int kind_cur = M.kind[p_cur], node_cur = M.node[p_cur];
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int tag = (int)gs + 1;
-            const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p_cur;
+            const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];      // (the next step's row travels while this step computes)
             // ---- AHEAD of the request, while the chain wave draws the proposal: which nodes the proposal writes follows from its table row
             // and the topology alone (mh_propose_ranges), hence the list of moved slots -- and with the list the current distances of the
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
                 s_cur = s1;
             }
             p_cur = p_next;
+            p_next = p_next2;
             kind_cur = kind_next;
             node_cur = node_next;
             LIK_TICK(4)
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
             for (int i = 0; i < 5; ++i) trace_alpha[(int64_t)(8 + i) * B + b] = (double)lk[i];
 #endif
         if (valid && lane == 0) I.zcur[b] = q;
+        seg_tail_distances(M, Q, words, Hp, Rp, ts_node, ts_parent, rr, n, n_steps, b, valid, lane);
         return;
     }
 
@@ -529,9 +532,12 @@ hipError_t launch_mh_segment_sparse(const MhDev& M, const SparseDev& Sp, const T
 {
     MhSegPending Q{};
     Q.p_acc = -1;
+    Q.p_tail = -1;
     if (pending) Q = *pending;
+    Q.ahead_from = opt_or(OPT_MH_AHEAD_FROM, kSegAheadFrom);
     if (n_steps <= 0) return Q.p_acc >= 0 ? hipErrorInvalidValue : hipSuccess;
     if (Q.p_acc >= 0 && (Q.X1 == nullptr || I.zprop == nullptr || !summands_kept)) return hipErrorInvalidValue;
+    if (Q.p_tail >= M.n_prop || (Q.p_tail >= 0 && (Q.X1_tail == nullptr || M.psum == nullptr || M.psel == nullptr))) return hipErrorInvalidValue;
     if (n_steps > (1 << 22)) return hipErrorInvalidValue;    // (a slot's mark holds the step in 23 bits)
     if (!mh_segment_sparse_available(M, Sp) || I.X0 == nullptr || I.zcur == nullptr || I.NPz != 1) return hipErrorInvalidValue;
     if (list_all && Sp.n > kSsegList) return hipErrorInvalidValue;

@@ -732,21 +732,30 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
             // a dense proposal followed by a segment is decided by that segment's launch (k_mh_segment.hip: MhSegPending), not by a
             // launch of the step kernel that would do nothing else
             mcd::MhSegPending pending{};
+            pending.p_acc = -1;
             bool have_pending = false;
+            // ... and a dense proposal that follows a segment is PROPOSED by that segment's launch, from the state it holds in LDS
+            // (MhSegPending::p_tail), not by a launch of the step kernel that reads everything back first.  MCD_MH_SEG_TAIL=0: by the step kernel.
+            const bool tails = D.psum != nullptr && !mcd::opt_is(mcd::OPT_MH_SEG_TAIL, 0);
+            bool proposed = false;                           // schedule[gs] is already proposed (by the segment before it)
             int64_t gs = 0;
             while (gs < total) {
                 if (inc_mode(schedule[gs]) != 2) {
                     int64_t e = gs + 1;                      // ... up to the next recomputation of z (every 256 steps)
                     while (e < total && inc_mode(schedule[e]) != 2 && (e & 255) != 0) ++e;
+                    if (!have_pending) pending.p_acc = -1;
+                    pending.p_tail = (tails && e < total && inc_mode(schedule[e]) == 2) ? schedule[e] : -1;
+                    pending.X1_tail = X1;
+                    proposed = pending.p_tail >= 0;
                     if (inc_sparse)
                         MHIP_TRY(mcd::launch_mh_segment_sparse(D, *m->sp, *m->tree, *m->prior, I, m->d_sched + gs, e - gs, S, accumulate ? 1 : 0,
                                                                step_base + (uint64_t)gs, m->seed, trace ? m->d_trace_alpha + gs * B : nullptr,
-                                                               trace ? m->d_trace_accept + gs * B : nullptr, gs, summands_kept ? 1 : 0,
-                                                               have_pending ? &pending : nullptr, m->list_all ? 1 : 0, m->stream));
+                                                               trace ? m->d_trace_accept + gs * B : nullptr, gs, summands_kept ? 1 : 0, &pending,
+                                                               m->list_all ? 1 : 0, m->stream));
                     else
                         MHIP_TRY(mcd::launch_mh_segment(D, *m->mvn, *m->tree, *m->prior, I, m->d_sched + gs, e - gs, S, accumulate ? 1 : 0, step_base + (uint64_t)gs,
                                                         m->seed, trace ? m->d_trace_alpha + gs * B : nullptr, trace ? m->d_trace_accept + gs * B : nullptr, gs,
-                                                        summands_kept ? 1 : 0, have_pending ? &pending : nullptr, m->stream));
+                                                        summands_kept ? 1 : 0, &pending, m->stream));
                     have_pending = false;
                     if (D.psum != nullptr) summands_kept = true;
                     if (accumulate) m->n_samples += (e / S) - (gs / S);          // iterations closed by steps gs .. e - 1
@@ -757,12 +766,15 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t S, 
                     continue;
                 }
                 // a dense proposal (and those that follow it directly)
-                if (int rc = need_draws(gs)) return rc;
-                I.mode = 0;
-                I.prop_mode = 2;
-                MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[gs], m->rows[schedule[gs]], (int)(gs & 63), m->step, m->seed, 0, nullptr,
-                                             nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, Vinc, summands_kept ? 0 : 1));
-                if (D.psum != nullptr) summands_kept = true;
+                if (!proposed) {
+                    if (int rc = need_draws(gs)) return rc;
+                    I.mode = 0;
+                    I.prop_mode = 2;
+                    MHIP_TRY(mcd::launch_mh_step(D, *m->prior, -1, 0, schedule[gs], m->rows[schedule[gs]], (int)(gs & 63), m->step, m->seed, 0, nullptr,
+                                                 nullptr, prior_inline, Tx, n_dim, X1, n_dim, m->stream, &I, Vinc, summands_kept ? 0 : 1));
+                    if (D.psum != nullptr) summands_kept = true;
+                }
+                proposed = false;
                 while (true) {
                     const int pa = schedule[gs];
                     if (int rc = z_product(X1, D.post1 + D.batch, (chunked || inc_sparse) ? I.zprop : nullptr)) return rc;

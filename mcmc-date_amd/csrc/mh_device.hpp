@@ -158,6 +158,28 @@ __device__ __forceinline__ PropRow mh_load_row(const MhDev& M, int p)
     return PropRow{M.kind[p], M.node[p], M.n1[p], M.n2[p], M.jac_root[p], M.p0[p], M.p1[p]};
 }
 
+// Loads that travel a step AHEAD in a persistent kernel (the schedule's next entries, the next row of the proposal table, its tuning
+// parameter) must be VECTOR loads: with a uniform address the compiler issues scalar loads, those return out of order and share their
+// counter with LDS -- so the next wait for ANY LDS read (a few instructions later) waits for the prefetch as well, and every step pays a
+// round trip to L2.  mh_vzero() is a zero the compiler cannot see through: an index plus it is a per-lane address, the load a vector
+// load (its own counter, in order).  The loaded integers are made scalars again where they are consumed (mh_row_scalar).
+__device__ __forceinline__ int mh_vzero()
+{
+    int z;
+    __asm__ volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+__device__ __forceinline__ PropRow mh_load_row_ahead(const MhDev& M, int p_plus_vzero)
+{
+    const int p = p_plus_vzero;
+    return PropRow{M.kind[p], M.node[p], M.n1[p], M.n2[p], M.jac_root[p], M.p0[p], M.p1[p]};
+}
+__device__ __forceinline__ PropRow mh_row_scalar(const PropRow& r)
+{
+    return PropRow{__builtin_amdgcn_readfirstlane(r.kind), __builtin_amdgcn_readfirstlane(r.node), __builtin_amdgcn_readfirstlane(r.n1),
+                   __builtin_amdgcn_readfirstlane(r.n2), __builtin_amdgcn_readfirstlane(r.jac_root), r.p0, r.p1};
+}
+
 // The STATE-INDEPENDENT random part of one step: what can be drawn knowing only the proposal row and its tuning
 // parameter.  Gamma-multiplier proposals: the multiplier u, ln (q(1/u) / q(u)) and ln u; truncated-normal proposals:
 // the uniform that goes through the quantile; every step: the acceptance uniform.  The whole-schedule kernel computes

@@ -95,10 +95,12 @@ struct SegHelpWords {
     int done_bd, done_cl;          // ... when the block's summands are those of the state the decision left
     double c1p, c2p;               // the birth-death / the clock block of the ln prior of the proposal
     double sc1[5];                 // chain wave: the proposal's scalars
-    double pad[7];
+    int sel, pad_i;                // ... which buffers of MhDev::psum hold the current summands (the proposal after the segment: into the others)
+    double pad[6];
 };
 static_assert(sizeof(SegHelpWords) == 128, "sixteen doubles of LDS");
 constexpr int kSegHelpDoubles = 16;
+constexpr int kSegAheadFrom = 200;                         // (MhSegPending::ahead_from; measured: profiles/r04_segment_ahead.txt)
 
 // LDS of one chain's CHAIN wave and the constants of its likelihood: set up by the kernel, read by seg_chain_wave
 struct SegChainCtx {
@@ -116,7 +118,7 @@ struct SegChainCtx {
 // kept and new summands in the order of the full evaluation; otherwise every summand.  Pl: the prior's tables with the tree in LDS.
 template <int BLOCK>
 __device__ __forceinline__ void seg_prior_wave(const MhDev& M, const PriorDev& P, const PriorDev& Pst, const SegChainCtx& L, const MhSegPending& Q,
-                                               int64_t n_steps, uint64_t seed, int64_t b, int lane)
+                                               int64_t n_steps, uint64_t seed, int64_t b, bool valid, int lane)
 {
     PriorDev Pl = Pst;                                       // (as the chain wave: the tree's tables from LDS)
     Pl.parent = L.tb_parent;
@@ -253,6 +255,72 @@ __device__ __forceinline__ void seg_prior_wave(const MhDev& M, const PriorDev& P
             if (BLOCK == 0) tbd[v] = old; else tcl[v] = old;     // the overwritten summand back
         }
         seg_post(w_done, tag);
+    }
+    // ---- the dense proposal after the segment (seg_chain_wave, MhSegPending::p_tail): this wave's block of its ln prior, every summand
+    // into the buffer of MhDev::psum that is not the current one -- k_mh_step_wg's proposal half
+    if (Q.p_tail >= 0) {
+        const int tag = (int)n_steps + 1;
+        (void)seg_poll(w_req, tag, 0);
+        const PropApply A = *L.A_lds;
+        double sc1[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sc1[i] = *lds_vdouble(&L.help->sc1[i]);
+        const int sel = *lds_vint(&L.help->sel);
+        const size_t NS = (size_t)((nn - 1 + 63) / 64) * 64;
+        const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
+        const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
+        if (BLOCK == 0) {
+            if (dH || sc1[0] != sc[0] || sc1[1] != sc[1]) {
+                double* s_bd = M.psum + ((size_t)b * 4 + (size_t)((sel & 1) ^ 1)) * NS;
+                const bool near = prior_bd_near(sc1[0], sc1[1]);
+                double bd = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) {
+                    const double t = prior_bd_term(Pl, w, near, sc1[0], sc1[1], Hp);
+                    if (valid) s_bd[w - 1] = t;
+                    bd += t;
+                }
+                const double c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+                if (lane == 0) *w_val = c1p;
+                seg_post(w_resp, tag);
+            }
+        } else {
+            if (dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2)) {
+                double* s_cl = M.psum + ((size_t)b * 4 + 2 + (size_t)(((sel >> 1) & 1) ^ 1)) * NS;
+                if (!(cc.va == sc1[4])) prior_clock_scalars(sc1[4], cc);
+                double cl = 0.0;
+                for (int w = 1 + lane; w < nn; w += 64) {
+                    const double t = prior_clock_term(Pl, w, sc1[4], cc.lg_k, cc.log_t, Hp, Rp);
+                    if (valid) s_cl[w - 1] = t;
+                    cl += t;
+                }
+                const double c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
+                if (lane == 0) *w_val = c2p;
+                seg_post(w_resp, tag);
+            }
+        }
+    }
+}
+
+// The likelihood wave's share of the dense proposal that follows the segment (MhSegPending::p_tail; seg_chain_wave proposes it): every
+// distance of the proposed state and ln jacobianRootBranch -- the arithmetic of k_mh_step_wg's X1 (likelihoodFunctionWrapper,
+// app/Probability.hs:195-207, 393-410).
+template <typename SlotT>
+__device__ __forceinline__ void seg_tail_distances(const MhDev& M, const MhSegPending& Q, SegWords* words, const double* Hp, const double* Rp, const SlotT* ts_node,
+                                                   const SlotT* ts_parent, int rr, int n, int64_t n_steps, int64_t b, bool valid, int lane)
+{
+    if (Q.p_tail < 0) return;
+    (void)seg_poll(lds_vint(&words->req), (int)n_steps + 1, 0);
+    const double s1 = *lds_vdouble(&words->s1);
+    double* x1 = Q.X1_tail + b * (int64_t)n;
+    for (int j = lane; j < n; j += 64) {
+        const int a = ts_node[j], pa = ts_parent[j];
+        double d = (Hp[pa] - Hp[a]) * Rp[a];
+        if (j == 0) d = d + (Hp[0] - Hp[rr]) * Rp[rr];
+        d = d * s1;
+        if (valid) {
+            x1[j] = d;
+            if (j == 0) M.post1[2 * M.batch + b] = log(1.0 / d);
+        }
     }
 }
 
@@ -408,33 +476,47 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
 #else
 #define SEG_TICK(i)
 #endif
-    int p = sched[0];
-    PropRow row = mh_load_row(M, p);
-    double t_cur = tune[p];
-    StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
-    for (int64_t gs = 0; gs < n_steps; ++gs) {
+    // ---- The steps.  A step is a dependent chain -- draw the proposal (special functions of one value per chain), then the ln prior and
+    // the likelihood of the proposed state (the other waves), then the decision -- and this wave idles while the other waves evaluate.  So
+    // it draws the NEXT step's proposal in that time, from the current state: that is the state the next step starts from if this step is
+    // rejected (most are).  After an acceptance the proposal is drawn again from the new state.  One site of mh_propose_params in the loop:
+    //   target = the step that is proposed in this turn of the loop: the step after the one in flight, or -- nothing in flight (the first
+    //   turn, and after an acceptance) -- the step gs itself.
+    // The same functions on the same inputs as a loop that proposes, evaluates and decides one step after the other: the same bits.
+    const int vz = mh_vzero();                               // (mh_device.hpp: what travels ahead is loaded by vector loads)
+    int p_t = sched[0];                                      // the target's row of the proposal table, its tuning parameter
+    PropRow row_t = mh_load_row(M, p_t);
+    double tune_t = tune[p_t];
+    int64_t t_idx = 0;                                       // ... and which step that is
+    int p_n = sched[(n_steps > 1 ? 1 : 0) + vz];             // the step after the target: its row travels a turn ahead
+    PropRow row_n = mh_load_row_ahead(M, p_n);
+    double tune_n = tune[p_n];
+    int p_nn = sched[(n_steps > 2 ? 2 : 0) + vz];            // ... and the schedule's entry after that one (a row's loads need its index: a load of the
+                                                             // index at the point of use made every step wait for two loads in a row)
+    StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step 64 blk + l
+    int64_t blk = -1;
+    // the step in flight: applied to Hp / Rp, posted to the other waves
+    bool inflight = false;
+    PropApply A;
+    double sc1[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double lnqj = 0.0, uacc = 0.0;
+    int p = p_t, jac_root = 0;
+    bool moves = false;
+    int64_t gs = 0;
+    // (small trees: the other waves answer before a proposal is drawn -- drawing ahead would only add the discarded draws after acceptances)
+    const bool ahead = nn >= Q.ahead_from;
+    int64_t to_close = S - (gs_base % S);                    // steps until the next iteration of the cycle closes
+    // a drawn proposal (step gs) goes into flight: applied to Hp / Rp, posted to the other waves
+    auto launch = [&](const PropApply& An, const double (&sc1n)[5], double lnqjn, double uaccn) __attribute__((always_inline)) {
         const int tag = (int)gs + 1;
-        const int p_next = (gs + 1 < n_steps) ? sched[gs + 1] : p;
-        const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
-        const double t_next = tune[p_next];                  // ... and its tuning parameter (global memory: a load at the point of use stalled the proposal)
-        if ((gs & 63) == 0) {
-            // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
-            // parameter (as k_mh_draws does for the two-launch path)
-            const int64_t mine = gs + lane;
-            if (mine < n_steps) {
-                const int pl = sched[mine];
-                pre = mh_step_draws(mh_load_row(M, pl), tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
-            }
-        }
-        const int sl = (int)(gs & 63);
-        const StepDraws dr{mh_readlane64(pre.u, sl), mh_readlane64(pre.lnq, sl), mh_readlane64(pre.logu, sl), mh_readlane64(pre.U, sl),
-                           mh_readlane64(pre.Uacc, sl)};
-        double sc1[5];
+        A = An;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
-        SEG_TICK(0)
-        PropApply A;
-        const double lnqj = mh_propose_params(Ml, row, t_cur, dr, lane, sc1, Hc, Rc, A);
+        for (int i = 0; i < 5; ++i) sc1[i] = sc1n[i];
+        lnqj = lnqjn;
+        uacc = uaccn;
+        p = p_t;
+        jac_root = row_t.jac_root;
+        moves = seg_moves_likelihood(row_t.kind, row_t.node);
         if constexpr (HELP) {
             // (the prior waves read Hp / Rp until they have committed or taken back the previous step's summands)
             if (gs > 0) {
@@ -442,18 +524,17 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
                 (void)seg_poll(lds_vint(&L.help->done_cl), tag - 1, 0);
             }
         }
+        SEG_TICK(6)
         for_write_set(A, [&](int w) {
             double h, r;
             mh_propose_node(Ml, A, w, Hc, Rc, h, r);
             Hp[w] = h;
             Rp[w] = r;
         });
-        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the writes above have landed before any lane reads them
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the writes above have landed before any lane reads them
         __builtin_amdgcn_wave_barrier();
-        SEG_TICK(1)
+        SEG_TICK(7)
         // ---- the likelihood wave takes it from here: the transform (which nodes are written), Hp / Rp, tH * rMu
-        const bool moves = seg_moves_likelihood(row.kind, row.node);
-        double lj1 = lj;
         if (lane == 0) {
             *A_lds = A;
             *w_s1 = sc1[2] * sc1[3];
@@ -463,181 +544,239 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
                 for (int i = 0; i < 5; ++i) L.help->sc1[i] = sc1[i];
             }
         }
-        seg_post(w_req, tag);                                // (every lane stores the same word: the fence is the wave's)
+        seg_post(w_req, tag);                            // (every lane stores the same word: the fence is the wave's)
+        inflight = true;
         SEG_TICK(2)
-        bool bd_scalars = false, need_bd = false, few_bd = false, need_cl = false, few_cl = false, cl_heights = false, mine_bd = false, mine_cl = false;
-        int v_bd = -1, v_cl = -1;
-        double old_bd = 0.0, old_cl = 0.0;                   // the summands this lane overwrites, until the decision
-        double c1p = c1, c2p = c2;
-        ClockCache ccp = cc;
-        // ---- ln prior: only the blocks whose inputs the proposal writes (a superset of "changed": a block re-evaluated on unchanged
-        // inputs returns the same bits)
-        const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
-        const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
-        ccp = cc;                                            // refreshed only if the proposal moved rVar
-        const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
-        if constexpr (!HELP) {
-            const int nbr = A.brace_hi - A.brace_lo;
-            // candidate l of the birth-death block: the nodes whose height the proposal writes, with their daughters (a range is a sub
-            // tree without its root: closed under "daughter of"); -1 = none
-            const int len1 = A.hhi > A.hlo ? A.hhi - A.hlo : 0, len2 = A.hhi2 > A.hlo2 ? A.hhi2 - A.hlo2 : 0;
-            auto cand_bd = [&](int l) -> int {
-                if (l < len1) return A.hlo + l;
-                l -= len1;
-                if (l < len2) return A.hlo2 + l;
-                l -= len2;
-                const int g = l / 3, r = l - 3 * g;
-                int base = -1;
-                if (g == 0) base = A.pt1; else if (g == 1) base = A.pt2; else if (g - 2 < nbr) base = M.brace_nodes[A.brace_lo + g - 2];
-                if (base < 0) return -1;
-                if (r == 0) return base;
-                return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
-            };
-            const int cnt_bd = len1 + len2 + 3 * (2 + nbr);
-            // ... of the clock block (uncorrelated models: a summand depends on its node's rate only): the nodes whose rate is written
-            const int lenr = A.rhi > A.rlo ? A.rhi - A.rlo : 0;
-            const int nbr_r = (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA) ? nbr : 0;
-            auto cand_cl = [&](int l) -> int {
-                if (l < lenr) return A.rlo + l;
-                l -= lenr;
-                if (l < 3) return l == 0 ? A.rp1 : l == 1 ? A.rp2 : A.rp3;
-                l -= 3;
-                const int g = l / 3, r = l - 3 * g;
-                if (g >= nbr_r) return -1;
-                const int base = M.brace_nodes[A.brace_lo + g];
-                if (r == 0) return base;
-                return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
-            };
-            const int cnt_cl = lenr + 3 + 3 * nbr_r;
-            bd_scalars = sc1[0] != sc[0] || sc1[1] != sc[1];
-            need_bd = dH || bd_scalars;
-            few_bd = need_bd && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
-            c1p = c1;
-            v_bd = few_bd ? cand_bd(lane) : -1;
-            mine_bd = few_bd && lane < cnt_bd && v_bd >= 1;
-            if (few_bd) {
-                // in place (a node may come twice: every lane reads the old value before any lane writes -- LDS keeps a wave's order)
-                if (mine_bd) old_bd = tbd[v_bd];
-                const double t = mine_bd ? prior_bd_term(Pl, v_bd, false, sc1[0], sc1[1], Hp) : 0.0;
-                if (mine_bd) tbd[v_bd] = t;
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                double bd = 0.0;
-                for (int w = 1 + lane; w < nn; w += 64) bd += tbd[w];
-                c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
-            } else if (need_bd) {
-                // every summand (the rates moved, or many heights): the sum alone; the summands are evaluated again if the proposal is accepted
-                const bool near = prior_bd_near(sc1[0], sc1[1]);
-                double bd = 0.0;
-                for (int v = 1 + lane; v < nn; v += 64) bd += prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
-                c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
-            }
-            cl_heights = dH && P.clock_model >= 2;    // white noise / autocorrelated: the summands also hold branch durations
-            need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
-            few_cl = need_cl && sc1[4] == sc[4] && P.clock_model < 2 && cnt_cl <= 64;
-            c2p = c2;
-            v_cl = few_cl ? cand_cl(lane) : -1;
-            mine_cl = few_cl && lane < cnt_cl && v_cl >= 1;
-            if (few_cl) {
-                if (mine_cl) old_cl = tcl[v_cl];
-                const double t = mine_cl ? prior_clock_term(Pl, v_cl, sc1[4], cc.lg_k, cc.log_t, Hp, Rp) : 0.0;
-                if (mine_cl) tcl[v_cl] = t;
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                double cl = 0.0;
-                for (int w = 1 + lane; w < nn; w += 64) cl += tcl[w];
-                c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
-            } else if (need_cl) {
-                if (ccp.va != sc1[4]) prior_clock_scalars(sc1[4], ccp);
-                double cl = 0.0;
-                for (int v = 1 + lane; v < nn; v += 64) cl += prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
-                c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
-            }
-        } else {
-            // the two prior waves evaluate their blocks (seg_prior_wave); whether a block has to be evaluated at all is decided here and
-            // there alike (the same expressions on the same numbers)
-            need_bd = dH || sc1[0] != sc[0] || sc1[1] != sc[1];
-            need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2);
-            if (need_bd) {
-                (void)seg_poll(lds_vint(&L.help->resp_bd), tag, 0);
-                c1p = *lds_vdouble(&L.help->c1p);
-            }
-            if (need_cl) {
-                (void)seg_poll(lds_vint(&L.help->resp_cl), tag, 0);
-                c2p = *lds_vdouble(&L.help->c2p);
-            }
+    };
+    while (gs < n_steps) {
+        const int64_t target = inflight ? gs + 1 : gs;
+        const bool do_prop = target < n_steps && (!inflight || ahead);
+        const bool drew_next = inflight && do_prop;          // An is the proposal of the step AFTER the one in flight
+        if (do_prop && target != t_idx) {
+            p_t = __builtin_amdgcn_readfirstlane(p_n);
+            row_t = mh_row_scalar(row_n);
+            tune_t = tune_n;
+            t_idx = target;
+            p_n = p_nn;
+            row_n = mh_load_row_ahead(M, p_n);               // (global memory: a load at the point of use stalled the proposal)
+            tune_n = tune[p_n];
+            p_nn = sched[((target + 2 < n_steps) ? target + 2 : target) + vz];
         }
-        const double lp1 = c0p + c1p + c2p;
-        SEG_TICK(3)
-        // ---- the likelihood wave's answer
-        (void)seg_poll(w_resp, tag, 0);
-        SEG_TICK(4)
-        double ll1 = ll;
-        if (moves) {
-            const double q = *w_q;
-            const int cnt = *w_cnt;
-            if (*w_have0) lj1 = *w_lj;
-            if (cnt < 0) ll = __builtin_nan("");             // more moved distances than the list holds -- cannot happen for a proposal mh_capi.cpp
+        PropApply An;
+        double sc1n[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sc1n[i] = sc[i];
+        double lnqjn = 0.0, uaccn = 0.0;
+        SEG_TICK(0)
+        if (do_prop) {
+            if ((target >> 6) != blk) {
+                // 64 consecutive steps at once, one step per lane: what can be drawn knowing only the proposal row and its tuning
+                // parameter (as k_mh_draws does for the two-launch path)
+                blk = target >> 6;
+                const int64_t mine = (blk << 6) + lane;
+                if (mine < n_steps) {
+                    const int pl = sched[mine];
+                    pre = mh_step_draws(mh_load_row(M, pl), tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
+                }
+            }
+            const int sl = (int)(target & 63);
+            const StepDraws dr{mh_readlane64(pre.u, sl), mh_readlane64(pre.lnq, sl), mh_readlane64(pre.logu, sl), mh_readlane64(pre.U, sl),
+                               mh_readlane64(pre.Uacc, sl)};
+            lnqjn = mh_propose_params(Ml, row_t, tune_t, dr, lane, sc1n, Hc, Rc, An);
+            uaccn = dr.Uacc;
+        }
+        SEG_TICK(1)
+        if (!inflight) {                                     // An proposes step gs itself
+            launch(An, sc1n, lnqjn, uaccn);
+            if (ahead) continue;                             // (the next turn draws the step after it, then takes the answers)
+        }
+        bool start = false;
+        {
+            // ================ the step in flight: ln prior, the likelihood wave's answer, the decision
+            const int tag = (int)gs + 1;
+            bool bd_scalars = false, need_bd = false, few_bd = false, need_cl = false, few_cl = false, cl_heights = false, mine_bd = false, mine_cl = false;
+            int v_bd = -1, v_cl = -1;
+            double old_bd = 0.0, old_cl = 0.0;               // the summands this lane overwrites, until the decision
+            double c1p = c1, c2p = c2;
+            double lj1 = lj;
+            ClockCache ccp = cc;
+            // ---- ln prior: only the blocks whose inputs the proposal writes (a superset of "changed": a block re-evaluated on unchanged
+            // inputs returns the same bits)
+            const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
+            const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
+            ccp = cc;                                        // refreshed only if the proposal moved rVar
+            const double c0p = (dH || sc1[2] != sc[2]) ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
+            if constexpr (!HELP) {
+                const int nbr = A.brace_hi - A.brace_lo;
+                // candidate l of the birth-death block: the nodes whose height the proposal writes, with their daughters (a range is a sub
+                // tree without its root: closed under "daughter of"); -1 = none
+                const int len1 = A.hhi > A.hlo ? A.hhi - A.hlo : 0, len2 = A.hhi2 > A.hlo2 ? A.hhi2 - A.hlo2 : 0;
+                auto cand_bd = [&](int l) -> int {
+                    if (l < len1) return A.hlo + l;
+                    l -= len1;
+                    if (l < len2) return A.hlo2 + l;
+                    l -= len2;
+                    const int g = l / 3, r = l - 3 * g;
+                    int base = -1;
+                    if (g == 0) base = A.pt1; else if (g == 1) base = A.pt2; else if (g - 2 < nbr) base = M.brace_nodes[A.brace_lo + g - 2];
+                    if (base < 0) return -1;
+                    if (r == 0) return base;
+                    return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+                };
+                const int cnt_bd = len1 + len2 + 3 * (2 + nbr);
+                // ... of the clock block (uncorrelated models: a summand depends on its node's rate only): the nodes whose rate is written
+                const int lenr = A.rhi > A.rlo ? A.rhi - A.rlo : 0;
+                const int nbr_r = (A.kind == MCD_PROP_SLIDE_BRACE_CONTRA) ? nbr : 0;
+                auto cand_cl = [&](int l) -> int {
+                    if (l < lenr) return A.rlo + l;
+                    l -= lenr;
+                    if (l < 3) return l == 0 ? A.rp1 : l == 1 ? A.rp2 : A.rp3;
+                    l -= 3;
+                    const int g = l / 3, r = l - 3 * g;
+                    if (g >= nbr_r) return -1;
+                    const int base = M.brace_nodes[A.brace_lo + g];
+                    if (r == 0) return base;
+                    return (tb_nch[base] >= r) ? (r == 1 ? tb_first[base] : tb_second[base]) : -1;
+                };
+                const int cnt_cl = lenr + 3 + 3 * nbr_r;
+                bd_scalars = sc1[0] != sc[0] || sc1[1] != sc[1];
+                need_bd = dH || bd_scalars;
+                few_bd = need_bd && !bd_scalars && cnt_bd <= 64 && !prior_bd_near(sc1[0], sc1[1]);
+                c1p = c1;
+                v_bd = few_bd ? cand_bd(lane) : -1;
+                mine_bd = few_bd && lane < cnt_bd && v_bd >= 1;
+                if (few_bd) {
+                    // in place (a node may come twice: every lane reads the old value before any lane writes -- LDS keeps a wave's order)
+                    if (mine_bd) old_bd = tbd[v_bd];
+                    const double t = mine_bd ? prior_bd_term(Pl, v_bd, false, sc1[0], sc1[1], Hp) : 0.0;
+                    if (mine_bd) tbd[v_bd] = t;
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    double bd = 0.0;
+                    for (int w = 1 + lane; w < nn; w += 64) bd += tbd[w];
+                    c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+                } else if (need_bd) {
+                    // every summand (the rates moved, or many heights): the sum alone; the summands are evaluated again if the proposal is accepted
+                    const bool near = prior_bd_near(sc1[0], sc1[1]);
+                    double bd = 0.0;
+                    for (int v = 1 + lane; v < nn; v += 64) bd += prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
+                    c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+                }
+                cl_heights = dH && P.clock_model >= 2;       // white noise / autocorrelated: the summands also hold branch durations
+                need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || cl_heights;
+                few_cl = need_cl && sc1[4] == sc[4] && P.clock_model < 2 && cnt_cl <= 64;
+                c2p = c2;
+                v_cl = few_cl ? cand_cl(lane) : -1;
+                mine_cl = few_cl && lane < cnt_cl && v_cl >= 1;
+                if (few_cl) {
+                    if (mine_cl) old_cl = tcl[v_cl];
+                    const double t = mine_cl ? prior_clock_term(Pl, v_cl, sc1[4], cc.lg_k, cc.log_t, Hp, Rp) : 0.0;
+                    if (mine_cl) tcl[v_cl] = t;
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    double cl = 0.0;
+                    for (int w = 1 + lane; w < nn; w += 64) cl += tcl[w];
+                    c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], cc.hyper);
+                } else if (need_cl) {
+                    if (ccp.va != sc1[4]) prior_clock_scalars(sc1[4], ccp);
+                    double cl = 0.0;
+                    for (int v = 1 + lane; v < nn; v += 64) cl += prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
+                    c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
+                }
+            } else {
+                // the two prior waves evaluate their blocks (seg_prior_wave); whether a block has to be evaluated at all is decided here and
+                // there alike (the same expressions on the same numbers)
+                need_bd = dH || sc1[0] != sc[0] || sc1[1] != sc[1];
+                need_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2);
+                if (need_bd) {
+                    (void)seg_poll(lds_vint(&L.help->resp_bd), tag, 0);
+                    c1p = *lds_vdouble(&L.help->c1p);
+                }
+                if (need_cl) {
+                    (void)seg_poll(lds_vint(&L.help->resp_cl), tag, 0);
+                    c2p = *lds_vdouble(&L.help->c2p);
+                }
+            }
+            const double lp1 = c0p + c1p + c2p;
+            SEG_TICK(3)
+            // ---- the likelihood wave's answer
+            (void)seg_poll(w_resp, tag, 0);
+            SEG_TICK(4)
+            double ll1 = ll;
+            if (moves) {
+                const double q = *w_q;
+                const int cnt = *w_cnt;
+                if (*w_have0) lj1 = *w_lj;
+                if (cnt < 0) ll = __builtin_nan("");         // more moved distances than the list holds -- cannot happen for a proposal mh_capi.cpp
                                                              // put into a segment; if it does, the chain says so: its ln likelihood is NaN from here
                                                              // on (nothing is accepted, mcd_mh_get_posterior shows it), not a silently wrong value
-            ll1 = (cnt < 0) ? __builtin_nan("") : L.c + (-0.5) * (L.logdet + q);      // :169 (finish_ll)
-        }
-        double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
-        if (row.jac_root) la += (double)row.jac_root * (lj1 - lj);
-        const bool ok = (la >= 0) || (dr.Uacc < exp(la));
-        seg_post(w_dec, 2 * tag + (ok ? 1 : 0));
-        if (ok) {
-            for_write_set(A, [&](int w) {
-                Hc[w] = Hp[w];
-                Rc[w] = Rp[w];
-            });
+                ll1 = (cnt < 0) ? __builtin_nan("") : L.c + (-0.5) * (L.logdet + q);      // :169 (finish_ll)
+            }
+            double la = beta * ((lp1 + ll1) - (lp + ll)) + lnqj;           // heated chains of MC3: posterior^beta; beta = 1 is exact
+            if (jac_root) la += (double)jac_root * (lj1 - lj);
+            // (every lane holds the same numbers: the decision as a scalar, so that the loop's control flow -- what is in flight, whether the
+            // proposal drawn ahead is used -- stays the wave's, not per lane)
+            const bool ok = __builtin_amdgcn_readfirstlane(((la >= 0) || (uacc < exp(la))) ? 1 : 0) != 0;
+            seg_post(w_dec, 2 * tag + (ok ? 1 : 0));
+            if (ok) {
+                for_write_set(A, [&](int w) {
+                    Hc[w] = Hp[w];
+                    Rc[w] = Rp[w];
+                });
 #pragma unroll
-            for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
-            // (few: already in place)  every summand: evaluated again, now to be kept -- the same function results as the sum's
-            if constexpr (!HELP) {
-                if (!few_bd && need_bd) {
-                    const bool near = prior_bd_near(sc1[0], sc1[1]);
-                    for (int v = 1 + lane; v < nn; v += 64) tbd[v] = prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
+                for (int i = 0; i < 5; ++i) sc[i] = sc1[i];
+                // (few: already in place)  every summand: evaluated again, now to be kept -- the same function results as the sum's
+                if constexpr (!HELP) {
+                    if (!few_bd && need_bd) {
+                        const bool near = prior_bd_near(sc1[0], sc1[1]);
+                        for (int v = 1 + lane; v < nn; v += 64) tbd[v] = prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
+                    }
+                    if (!few_cl && need_cl)
+                        for (int v = 1 + lane; v < nn; v += 64) tcl[v] = prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
                 }
-                if (!few_cl && need_cl)
-                    for (int v = 1 + lane; v < nn; v += 64) tcl[v] = prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
+                c0 = c0p;
+                c1 = c1p;
+                c2 = c2p;
+                cc = ccp;
+                lp = lp1;
+                ll = ll1;
+                lj = lj1;
+            } else {
+                for_write_set(A, [&](int w) {
+                    Hp[w] = Hc[w];
+                    Rp[w] = Rc[w];
+                });
+                if constexpr (!HELP) {
+                    if (mine_bd) tbd[v_bd] = old_bd;         // the overwritten summands back
+                    if (mine_cl) tcl[v_cl] = old_cl;
+                }
             }
-            c0 = c0p;
-            c1 = c1p;
-            c2 = c2p;
-            cc = ccp;
-            lp = lp1;
-            ll = ll1;
-            lj = lj1;
-        } else {
-            for_write_set(A, [&](int w) {
-                Hp[w] = Hc[w];
-                Rp[w] = Rc[w];
-            });
-            if constexpr (!HELP) {
-                if (mine_bd) tbd[v_bd] = old_bd;             // the overwritten summands back
-                if (mine_cl) tcl[v_cl] = old_cl;
+            if (lane == 0 && valid) {
+                atomicAdd(&tried[p], 1);                     // (global memory, no value returned: nothing waits for it)
+                if (ok) atomicAdd(&acc[p], 1);
+                if (trace_alpha) trace_alpha[gs * B + b] = la;
+                if (trace_accept) trace_accept[gs * B + b] = ok ? 1 : 0;
             }
-        }
-        if (lane == 0 && valid) {
-            atomicAdd(&tried[p], 1);                         // (global memory, no value returned: nothing waits for it)
-            if (ok) atomicAdd(&acc[p], 1);
-            if (trace_alpha) trace_alpha[gs * B + b] = la;
-            if (trace_accept) trace_accept[gs * B + b] = ok ? 1 : 0;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (accumulate && valid && (gs_base + gs + 1) % S == 0) {      // once per iteration of the cycle: straight into the running sums
-            for (int w = lane; w < nn; w += 64) {
-                const double a = sc[2] * Hc[w];
-                M.age_sum[b * nn + w] += a;
-                M.age_sq[b * nn + w] += a * a;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            to_close -= 1;
+            if (to_close == 0) {                             // once per iteration of the cycle: straight into the running sums
+                to_close = S;
+                if (accumulate && valid) {
+                    for (int w = lane; w < nn; w += 64) {
+                        const double a = sc[2] * Hc[w];
+                        M.age_sum[b * nn + w] += a;
+                        M.age_sq[b * nn + w] += a * a;
+                    }
+                }
             }
+            SEG_TICK(5)
+            gs += 1;
+            inflight = false;
+            if (gs >= n_steps) break;
+            start = !ok && drew_next;                        // rejected: the state An was drawn from is still the current one
         }
-        p = p_next;
-        row = row_next;
-        t_cur = t_next;
-        SEG_TICK(5)
+        if (start) launch(An, sc1n, lnqjn, uaccn);
     }
 #ifdef MCD_SEG_STAMP
     if (trace_alpha && lane == 0 && valid)
@@ -647,6 +786,98 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
         if (n_steps > 0) {
             (void)seg_poll(lds_vint(&L.help->done_bd), (int)n_steps, 0);
             (void)seg_poll(lds_vint(&L.help->done_cl), (int)n_steps, 0);
+        }
+    }
+    // ---- the dense proposal that follows the segment (MhSegPending::p_tail): PROPOSED here, from the state this wave holds in LDS --
+    // k_mh_step_wg's proposal half (k_mh.hip) on the same numbers with the same functions in the same order: H1 / R1 / sc1, the three blocks
+    // of its ln prior (pcomp1, post1[0]), lnqj, its summands in the buffers that are not the current ones, psel's flags; the likelihood
+    // wave writes its distances (seg_tail_distances).  The row-split (or sparse) launch evaluates it, the next launch decides it.
+    int tail_flags = 0;
+    if (Q.p_tail >= 0) {
+        const int pt = Q.p_tail;
+        const PropRow row_t = mh_load_row(M, pt);
+        const StepDraws dr = mh_step_draws(row_t, tune[pt], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)n_steps));     // (every lane the same)
+        double sc1[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sc1[i] = sc[i];
+        PropApply A;
+        const double lnqj = mh_propose_params(Ml, row_t, tune[pt], dr, lane, sc1, Hc, Rc, A);
+        for_write_set(A, [&](int w) {
+            double h, r;
+            mh_propose_node(Ml, A, w, Hc, Rc, h, r);
+            Hp[w] = h;
+            Rp[w] = r;
+        });
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            *w_s1 = sc1[2] * sc1[3];
+            if constexpr (HELP) {
+                *A_lds = A;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) L.help->sc1[i] = sc1[i];
+                L.help->sel = seg_sel;
+            }
+        }
+        seg_post(w_req, (int)n_steps + 1);                   // the likelihood wave (and the prior waves): the proposed state is in Hp / Rp
+        // which blocks the proposal writes (a superset of k_mh_step_wg's "differs": a block evaluated again on unchanged inputs is the same
+        // bits, and psel's flags say which buffers hold the proposal's summands either way)
+        const bool dH = A.hhi > A.hlo || A.hhi2 > A.hlo2 || A.pt1 >= 0 || A.pt2 >= 0 || A.brace_hi > A.brace_lo;
+        const bool dR = A.rhi > A.rlo || A.rp1 >= 0 || A.rp2 >= 0 || A.rp3 >= 0 || (A.brace_hi > A.brace_lo && A.kind == MCD_PROP_SLIDE_BRACE_CONTRA);
+        const bool f_nodes = dH || sc1[2] != sc[2];
+        const bool f_bd = dH || sc1[0] != sc[0] || sc1[1] != sc[1];
+        const bool f_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2);
+        tail_flags = (f_nodes ? 1 : 0) | (f_bd ? 2 : 0) | (f_cl ? 4 : 0);
+        const double c0p = f_nodes ? prior_nodes_wave(Pl, lane, sc1[2], Hp) : c0;
+        double c1p = c1, c2p = c2;
+        if constexpr (HELP) {                                // (seg_prior_wave: the same expressions decide there whether a block is evaluated)
+            if (f_bd) {
+                (void)seg_poll(lds_vint(&L.help->resp_bd), (int)n_steps + 1, 0);
+                c1p = *lds_vdouble(&L.help->c1p);
+            }
+            if (f_cl) {
+                (void)seg_poll(lds_vint(&L.help->resp_cl), (int)n_steps + 1, 0);
+                c2p = *lds_vdouble(&L.help->c2p);
+            }
+        } else {
+        if (f_bd) {
+            double* s_bd = M.psum + ((size_t)b * 4 + (size_t)((seg_sel & 1) ^ 1)) * NS;
+            const bool near = prior_bd_near(sc1[0], sc1[1]);
+            double bd = 0.0;
+            for (int v = 1 + lane; v < nn; v += 64) {
+                const double t = prior_bd_term(Pl, v, near, sc1[0], sc1[1], Hp);
+                if (valid) s_bd[v - 1] = t;
+                bd += t;
+            }
+            c1p = prior_bd_finish(pr_wave_sum(bd), sc1[0], sc1[1]);
+        }
+        if (f_cl) {
+            double* s_cl = M.psum + ((size_t)b * 4 + 2 + (size_t)(((seg_sel >> 1) & 1) ^ 1)) * NS;
+            ClockCache ccp = cc;
+            if (!(ccp.va == sc1[4])) prior_clock_scalars(sc1[4], ccp);
+            double cl = 0.0;
+            for (int v = 1 + lane; v < nn; v += 64) {
+                const double t = prior_clock_term(Pl, v, sc1[4], ccp.lg_k, ccp.log_t, Hp, Rp);
+                if (valid) s_cl[v - 1] = t;
+                cl += t;
+            }
+            c2p = prior_clock_finish(Pl, pr_wave_sum(cl), sc1[3], sc1[4], ccp.hyper);
+        }
+        }
+        if (valid) {
+            for (int w = lane; w < nn; w += 64) {
+                M.H1[b * M.ld + w] = Hp[w];
+                M.R1[b * M.ld + w] = Rp[w];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) M.sc1[i * B + b] = sc1[i];
+                M.pcomp1[b * 3 + 0] = c0p;
+                M.pcomp1[b * 3 + 1] = c1p;
+                M.pcomp1[b * 3 + 2] = c2p;
+                M.lnqj[b] = lnqj;
+                M.post1[b] = c0p + c1p + c2p;
+            }
         }
     }
     if (!valid) return;
@@ -672,7 +903,7 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
             s_bd[v - 1] = tbd[v];
             s_cl[v - 1] = tcl[v];
         }
-        if (lane == 0) reinterpret_cast<int2*>(M.psel)[b] = make_int2(seg_sel, 0);
+        if (lane == 0) reinterpret_cast<int2*>(M.psel)[b] = make_int2(seg_sel, tail_flags);
     }
 }
 

@@ -196,6 +196,11 @@ struct MhSegPending {          // a dense proposal that is still to be decided w
     int8_t* trace_accept;
     const double* X1;          // [batch][n] its distances
     int z_in_zprop;            // its z' is in MhInc::zprop (batches beyond 1024 chains: taken there chunk by chunk), not in the z tiles
+    // ... and the dense proposal that FOLLOWS the segment's last step: proposed by the segment's launch from the state it holds in LDS (what a
+    // launch of k_mh_step_wg would do after reading everything back: H1 / R1 / sc1 / post1 / pcomp1 / lnqj / the summands / its distances)
+    int p_tail;                // its row of the proposal table, -1 = none
+    double* X1_tail;           // [batch][n] its distances
+    int ahead_from;            // trees from this many nodes: the chain wave draws the next step's proposal while the step in flight is evaluated
 };
 bool mh_segment_available(const MhDev& M, const MvnDev& V);
 // the same over a sparse precision matrix (k_mh_segment_sparse.hip); I: X0 = current distances [batch][n], zcur / zprop = the quadratic

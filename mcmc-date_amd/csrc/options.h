@@ -27,6 +27,8 @@ enum Option {
     OPT_SPARSE_QUAD,        // 1 / 0: force / forbid the one-launch form of the sparse log-density
     OPT_MH_PRIOR_WAVES,     // 0: the segment kernels without their prior waves (the chain wave evaluates the whole ln prior)
     OPT_LOADERS,            // 2: two loader waves in the column sweep's 512-chain geometry at 129 .. 256 dimensions instead of four (A/B)
+    OPT_MH_SEG_TAIL,        // 0: a dense proposal that follows a segment is proposed by a launch of the step kernel, not by the segment's launch (A/B, tests)
+    OPT_MH_AHEAD_FROM,      // nodes from which a segment kernel's chain wave draws the next proposal ahead of the decision (default: kSegAheadFrom)
     OPT_COUNT
 };
 constexpr int MCD_OPT_UNSET = -2147483647 - 1;

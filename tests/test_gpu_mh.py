@@ -916,13 +916,18 @@ def test_shard_allgather_through_rccl(gpu, golden):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("knob", ["MCD_MH_PRIOR_WAVES", "MCD_MH_SEG_TAIL"])
 @pytest.mark.parametrize("n_leaves,B,sparse", [(200, 33, False), (513, 16, False), (7, 8, True), (300, 17, True), (1007, 5, True)])
-def test_prior_waves_of_the_segment_kernels_give_the_same_chains(gpu, n_leaves, B, sparse, knobs):
+def test_prior_waves_of_the_segment_kernels_give_the_same_chains(gpu, n_leaves, B, sparse, knob, knobs):
     """The segment kernels (k_mh_segment.hip, k_mh_segment_sparse.hip) give every chain two PRIOR waves beside its chain wave and its
     likelihood wave: the birth-death and the clock block of a proposal's ln prior are evaluated by them (mh_segment_device.hpp:
     seg_prior_wave) while the chain wave evaluates the node priors.  The same functions on the same numbers in the same order: with the
     knob MCD_MH_PRIOR_WAVES = 0 (the chain wave evaluates all three blocks, round 3's arrangement) every ln acceptance ratio, decision,
-    state and posterior term is the same bits.  Calibrations and a constraint, so that all three blocks are live; an odd batch."""
+    state and posterior term is the same bits.  Calibrations and a constraint, so that all three blocks are live; an odd batch.
+
+    The same for MCD_MH_SEG_TAIL: a dense proposal that follows a segment is proposed by that segment's launch from the state it holds in
+    LDS (mh_segment_device.hpp: MhSegPending::p_tail, seg_tail_distances) -- k_mh_step_wg's proposal half without the launch and without
+    reading the state back; 0 = by the step kernel."""
     from mcmc_date_amd import synthetic as S
 
     topo = S.random_topology(n_leaves, seed=31)
@@ -944,7 +949,7 @@ def test_prior_waves_of_the_segment_kernels_give_the_same_chains(gpu, n_leaves, 
     sched = np.tile(cyc, (1, 700 // cyc.shape[1] + 1))[:, :700]
     out = {}
     for waves in ("1", "0"):
-        knobs.setenv("MCD_MH_PRIOR_WAVES", waves)
+        knobs.setenv(knob, waves)
         smp = M.Sampler(lik, pf, ps, B, seed=77)
         smp.set_state(s0)
         ta, tk = smp.run_schedule(sched, trace=True)

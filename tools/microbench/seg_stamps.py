@@ -3,7 +3,7 @@ given proposal kinds (MCD_PROP_* numbers, comma separated; default: every kind a
 Build first:  make -C mcmc-date_amd/csrc stamp_seg ;  on the GPU box:  python tools/microbench/seg_stamps.py [n] [chains] [kinds]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MCD_LIB_PATH"] = os.path.join(ROOT, "tools", "microbench", "libsegstamp.so")
+os.environ["MCD_LIB_PATH"] = os.path.join(ROOT, "tools", "microbench", os.environ.get("SEGSTAMPLIB", "libsegstamp.so"))
 sys.path.insert(0, ROOT)
 import numpy as np
 import mcmc_date_amd as M
@@ -40,9 +40,9 @@ t0 = time.perf_counter()
 ta, _ = smp.run_schedule(sched, trace=True)
 dt = time.perf_counter() - t0
 assert "segments" in smp.last_path(), smp.last_path()
-tk = ta[:6].mean(axis=1)
+tk = ta[:8].mean(axis=1)
 print("us per lock step %.2f (n_nodes %d, chains %d, %d steps of kinds %s in one launch; with tracing)" % (1e6 * dt / steps, topo.n_nodes, B, steps, kinds))
-for nm, v in zip(["loop head + draws", "propose", "posting the transform", "ln prior", "waiting for |z'|^2 / q'", "decision + commit"], tk):
+for nm, v in zip(["loop head + draws", "propose", "posting the transform", "ln prior", "waiting for |z'|^2 / q'", "decision + commit", "(start) waiting for the prior waves' done", "(start) applying the transform"], tk):
     print("  %-26s %5.1f %%   (%.0f ticks per step)" % (nm, 100 * v / tk.sum(), v / steps))
 if sparse:
     lk = ta[8:13].mean(axis=1)
