@@ -289,7 +289,7 @@ foreign import ccall unsafe "mcd_mh_get_age_sums"
   c_mh_get_age_sums :: Ptr McdMh -> Ptr CDouble -> Ptr CDouble -> Ptr Int64 -> IO CInt
 
 -- | The lock-step driver over a likelihood whose precision matrix stays sparse on the device (@likelihoodFunction (Sparse ...)@,
--- app/Probability.hs:279; trees of 321 .. 2048 nodes): same arguments as 'c_mh_create' with the sparse tree handle.
+-- app/Probability.hs:279; trees of 3 .. 2048 nodes): same arguments as 'c_mh_create' with the sparse tree handle.
 foreign import ccall unsafe "mcd_mh_create_sparse"
   c_mh_create_sparse ::
     Ptr (Ptr McdMh) -> Ptr McdSparseTree -> Ptr McdPrior -> CInt -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 -> Ptr Int32 ->

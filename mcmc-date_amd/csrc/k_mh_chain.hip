@@ -166,12 +166,13 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
 #endif
     __builtin_amdgcn_wave_barrier();
     int p = sched[0];
-    int p_next = sched[n_steps > 1 ? 1 : 0];                // (the schedule's entries two steps ahead: a row's loads need its index)
+    const int vz = mh_vzero();                              // (mh_device.hpp: what travels ahead is loaded by vector loads)
+    int p_next = sched[(n_steps > 1 ? 1 : 0) + vz];         // (the schedule's entries two steps ahead: a row's loads need its index)
     PropRow row = mh_load_row(M, p);
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                 // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
-        const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : 0;
-        const PropRow row_next = mh_load_row(M, p_next);            // the next step's row travels while this step computes
+        const int p_next2 = sched[((gs + 2 < n_steps) ? gs + 2 : gs) + vz];
+        const PropRow row_next = mh_load_row_ahead(M, p_next);      // the next step's row travels while this step computes
         if ((gs & 63) == 0) {
             // 64 consecutive steps at once, one step per lane: the random draws that depend only on the proposal row and its
             // tuning parameter (gamma multipliers with their ratio and logarithm, the uniforms of the truncated normals
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(64 * WPB * (LW ? 2 : 1)) void k_mh_chain(MhDev M, M
             age_s += a;
             age_q += a * a;
         }
-        p = p_next;
+        p = __builtin_amdgcn_readfirstlane(p_next);
         p_next = p_next2;
-        row = row_next;
+        row = mh_row_scalar(row_next);
         MH_TICK(4)
     }
     if (LW) {                                           // the schedule is over

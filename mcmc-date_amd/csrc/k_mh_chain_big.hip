@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
     if (wave >= CW) {
         const int lw = wave - CW;
         int p = sched[0];
-        int p_next = sched[n_steps > 1 ? 1 : 0];             // (the schedule's entries two steps ahead: a row's loads need its index)
+        const int vz = mh_vzero();                           // (mh_device.hpp: what travels ahead is loaded by vector loads)
+        int p_next = sched[(n_steps > 1 ? 1 : 0) + vz];      // (the schedule's entries two steps ahead: a row's loads need its index)
         int kind = M.kind[p], node = M.node[p];
         const bool inc = V.Wc != nullptr;
         int sp = inc ? M.sparse[p] : 0;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         MhDev Mt_ = M;                                       // (mh_propose_ranges reads the sub tree sizes -- the chain waves' table in LDS -- and the braces' pointers)
         Mt_.size = reinterpret_cast<const int32_t*>(dyn) + nn;
         for (int64_t gs = 0; gs < n_steps; ++gs) {
-            const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
+            const int p_next2 = sched[((gs + 2 < n_steps) ? gs + 2 : gs) + vz];
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];     // (travel while this step streams)
             const int sp_next = inc ? M.sparse[p_next] : 0;
             // z of the current state (start of the launch, then every 256 steps), then the step's own sweep if its proposal is dense
@@ -365,9 +366,9 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                     post(&words->done, tag);                     // (the chain wave may sweep from / write to distances and z again)
                 }
             }
-            kind = kind_next;
-            node = node_next;
-            sp = sp_next;
+            kind = __builtin_amdgcn_readfirstlane(kind_next);
+            node = __builtin_amdgcn_readfirstlane(node_next);
+            sp = __builtin_amdgcn_readfirstlane(sp_next);
             p_next = p_next2;
         }
         return;
@@ -580,14 +581,15 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
         }
     };
     int p = sched[0];
-    int p_next = sched[n_steps > 1 ? 1 : 0];                 // (the schedule's entries two steps ahead: a row's loads need its index)
+    const int vz = mh_vzero();                               // (mh_device.hpp: what travels ahead is loaded by vector loads)
+    int p_next = sched[(n_steps > 1 ? 1 : 0) + vz];          // (the schedule's entries two steps ahead: a row's loads need its index)
     PropRow row = mh_load_row(M, p);
     double t_cur = tune[p];
     int row_sparse = inc ? M.sparse[p] : 0;
     StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};                  // lane l: the state-independent draws of step (gs & ~63) + l
     for (int64_t gs = 0; gs < n_steps; ++gs) {
-        const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
-        const PropRow row_next = mh_load_row(M, p_next);     // the next step's row travels while this step computes
+        const int p_next2 = sched[((gs + 2 < n_steps) ? gs + 2 : gs) + vz];
+        const PropRow row_next = mh_load_row_ahead(M, p_next);   // the next step's row travels while this step computes
         const double t_next = tune[p_next];                  // ... and its tuning parameter (global memory: a load at the point of use stalled the proposal)
         const int sparse_next = inc ? M.sparse[p_next] : 0;
         if ((gs & 63) == 0) {
@@ -934,11 +936,11 @@ __global__ __launch_bounds__(256, 1) void k_mh_chain_big(MhDev M, MvnDev V, Tree
                 M.age_sq[b * nn + w] += a * a;
             }
         }
-        p = p_next;
+        p = __builtin_amdgcn_readfirstlane(p_next);
         p_next = p_next2;
-        row = row_next;
+        row = mh_row_scalar(row_next);
         t_cur = t_next;
-        row_sparse = sparse_next;
+        row_sparse = __builtin_amdgcn_readfirstlane(sparse_next);
         MHB_TICK(5)
     }
 #ifdef MCD_MHB_STAMP

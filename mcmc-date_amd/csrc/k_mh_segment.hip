@@ -240,11 +240,12 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
             return cnt;
         };
         int p_cur = sched[0];
-        int p_next = sched[n_steps > 1 ? 1 : 0];             // (the schedule's entries two steps ahead: a row's loads need its index)
+        const int vz = mh_vzero();                           // (mh_device.hpp: what travels ahead is loaded by vector loads)
+        int p_next = sched[(n_steps > 1 ? 1 : 0) + vz];      // (the schedule's entries two steps ahead: a row's loads need its index)
         int kind_cur = M.kind[p_cur], node_cur = M.node[p_cur];
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int tag = (int)gs + 1;
-            const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
+            const int p_next2 = sched[((gs + 2 < n_steps) ? gs + 2 : gs) + vz];
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];      // (the next step's row travels while this step computes)
             // ---- AHEAD of the request, while the chain wave draws the proposal: which nodes the proposal writes follows from its table row
             // and the topology alone (mh_propose_ranges), hence the list of moved slots; the first columns of L^-1 they need are touched (one
@@ -257,10 +258,6 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
             int cnt = 0;
             constexpr int kPre = (R >= 16) ? 1 : (R >= 12) ? 2 : kSegCols;   // (the register file: one column of 16 doubles per lane at R = 16, four columns below R = 12)
             double pcol[kPre][R];                            // the first columns, requested ahead of the request
-            // ... and the next kTouch columns TOUCHED: one dword of each of a column's 128-byte lines, so that the lines are on their way into this
-            // XCD's L2 while the proposal is drawn (no registers for their values: the loads after the request then hit L2)
-            constexpr int kTouch = 3;
-            float touch[kTouch] = {0.0f, 0.0f, 0.0f};
             for (int pass = 0; pass < 2; ++pass) {
                 cnt = c_moves ? build_list(c_kind, c_hlo, c_hhi, c_hlo2, c_hhi2, c_rlo, c_rhi, c_pt1, c_pt2, c_rp1, c_rp2, c_rp3, c_brace_lo, c_brace_hi, 2 * tag + pass) : 0;
                 // the first batch of columns of L^-1 (the list's first slots) is requested now: an L2 miss each, under way while the
@@ -273,15 +270,6 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
                         const double* wc = V.Wc + (size_t)j * NPad + lane;
 #pragma unroll
                         for (int k = 0; k < R; ++k) pcol[u][k] = wc[64 * k];
-                    }
-                }
-                if (cnt > kPre) {
-#pragma unroll
-                    for (int u = 0; u < kTouch; ++u) {
-                        const int m = (kPre + u < cnt) ? kPre + u : cnt - 1;
-                        const int j = __builtin_amdgcn_readfirstlane(l_j[m]);
-                        const float* wl = reinterpret_cast<const float*>(V.Wc + (size_t)j * NPad);
-                        if (lane < 4 * R) touch[u] = wl[lane * 32];      // (a column: 64 R doubles = 4 R lines)
                     }
                 }
                 if (pass == 1) break;
@@ -365,7 +353,6 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
 #pragma unroll
                     for (int k = 0; k < R; ++k) zp[k] = fma(dl[u], col[u][k], zp[k]);
             }
-            asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]));      // (the touching loads have landed: their registers are free again)
             double sq = 0.0;
 #pragma unroll
             for (int k = 0; k < R; ++k) sq = fma(zp[k], zp[k], sq);
@@ -385,8 +372,8 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
             }
             p_cur = p_next;
             p_next = p_next2;
-            kind_cur = kind_next;
-            node_cur = node_next;
+            kind_cur = __builtin_amdgcn_readfirstlane(kind_next);
+            node_cur = __builtin_amdgcn_readfirstlane(node_next);
         }
         if (valid) {
 #pragma unroll
@@ -398,7 +385,7 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
     }
 
     // ================================================================ chain waves (mh_segment_device.hpp: shared with the sparse kernel)
-    seg_chain_wave<HELP>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
+    seg_chain_wave<HELP, false>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
 }
 
 // trees whose factor takes 6 .. 16 register blocks (259 .. 1026 nodes: below that the streaming chain kernel's in-kernel sweeps of

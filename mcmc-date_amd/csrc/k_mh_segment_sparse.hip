@@ -292,11 +292,12 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
         };
         constexpr int W = kSparseEllW;
         int p_cur = sched[0];
-        int p_next = sched[n_steps > 1 ? 1 : 0];             // (the schedule's entries two steps ahead: a row's loads need its index)
+        const int vz = mh_vzero();                           // (mh_device.hpp: what travels ahead is loaded by vector loads)
+        int p_next = sched[(n_steps > 1 ? 1 : 0) + vz];      // (the schedule's entries two steps ahead: a row's loads need its index)
         int kind_cur = M.kind[p_cur], node_cur = M.node[p_cur];
         for (int64_t gs = 0; gs < n_steps; ++gs) {
             const int tag = (int)gs + 1;
-            const int p_next2 = (gs + 2 < n_steps) ? sched[gs + 2] : p_next;
+            const int p_next2 = sched[((gs + 2 < n_steps) ? gs + 2 : gs) + vz];
             const int kind_next = M.kind[p_next], node_next = M.node[p_next];      // (the next step's row travels while this step computes)
             // ---- AHEAD of the request, while the chain wave draws the proposal: which nodes the proposal writes follows from its table row
             // and the topology alone (mh_propose_ranges), hence the list of moved slots -- and with the list the current distances of the
@@ -475,8 +476,8 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
             }
             p_cur = p_next;
             p_next = p_next2;
-            kind_cur = kind_next;
-            node_cur = node_next;
+            kind_cur = __builtin_amdgcn_readfirstlane(kind_next);
+            node_cur = __builtin_amdgcn_readfirstlane(node_next);
             LIK_TICK(4)
         }
 #ifdef MCD_SEG_STAMP
@@ -489,7 +490,11 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
     }
 
     // ================================================================ chain waves (mh_segment_device.hpp: shared with the dense kernel)
-    seg_chain_wave<HELP>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
+    // (two instances with the prior waves: small trees take the plain loop, mh_segment_device.hpp)
+    if (HELP && nn < Q.ahead_from)
+        seg_chain_wave<HELP, HELP>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
+    else
+        seg_chain_wave<HELP, false>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
 }
 
 // any tree of 3 .. 2048 nodes whose tables and one chain fit a CU's LDS, the symmetric part of the matrix on the device

@@ -447,7 +447,7 @@ public:
         for (auto& p : table_) stepsPerIteration_ += p.weight;
     }
     // the same sampler over a likelihood whose precision matrix stays sparse on the device (likelihoodFunction (Sparse ...),
-    // app/Probability.hs:279): trees of 321 .. 2048 nodes (mcd_mh_create_sparse)
+    // app/Probability.hs:279): trees of 3 .. 2048 nodes (mcd_mh_create_sparse)
     Sampler(const SparseLikelihood& lik, const PriorFunction& prior, std::vector<Proposal> table, int64_t batch, uint64_t seed)
         : topo_(lik.topology()), table_(std::move(table)), batch_(batch)
     {
