@@ -89,7 +89,9 @@ const char* mcd_last_error(void);
  * getenv() per launch: a stray variable silently changed the launch structure and the rounding of a run, and getenv() races with setenv()
  * in a threaded host such as the reference's, mcmc-date.cabal:42-43).  name = "MCD_MH_SEGMENTS", "MCD_MH_INCREMENTAL", "MCD_MH_PER_PHASE",
  * "MCD_MH_PRIOR", "MCD_MH_PRIOR_CACHE", "MCD_MH_STEP_WG", "MCD_MH_CHAIN_LW", "MCD_MH_INC_SLOTS", "MCD_MH_SPARSE_SLOTS", "MCD_SPLIT", "MCD_SPLIT_G",
- * "MCD_SPLIT_SCATTER", "MCD_SPLIT_NOROT", "MCD_SPLIT_PROBE", "MCD_GEOM", "MCD_WIDE_CT", "MCD_SPARSE_QUAD"; value = a decimal integer, NULL or ""
+ * "MCD_SPLIT_SCATTER", "MCD_SPLIT_NOROT", "MCD_SPLIT_PROBE", "MCD_GEOM", "MCD_WIDE_CT", "MCD_SPARSE_QUAD", "MCD_MH_PRIOR_WAVES", "MCD_LOADERS",
+ * "MCD_MH_SEG_TAIL" (0: a dense proposal after a segment is proposed by the step kernel), "MCD_MH_AHEAD_FROM" (nodes from which a segment's chain
+ * wave draws the next proposal ahead of the decision); value = a decimal integer, NULL or ""
  * = back to the default.  What each knob does is said where it acts (mcd_mh_run, the forms above).  The environment variables of the same
  * names are read ONCE, when the library is loaded, as initial values -- never afterwards.  No knob changes a result beyond rounding.
  */
@@ -382,8 +384,8 @@ int mcd_mh_run(mcd_mh_t* m, const int32_t* schedule, int64_t n_iter, int32_t ste
 #define MCD_MH_PATH_STEP_WG_X 5               /* workgroup-per-chain step leaving distances + plain-vector likelihood launch */
 #define MCD_MH_PATH_STEP_WG_INCREMENTAL 6     /* the same, the likelihood launch only for proposals that move many distances (k_mh_inc.hip) */
 #define MCD_MH_PATH_STEP_WG_SPARSE 7          /* workgroup-per-chain step leaving distances + the sparse product on them (mcd_mh_create_sparse) */
-#define MCD_MH_PATH_SEGMENTS 8                /* 259 .. 1026 nodes: every run of steps between two dense proposals in one launch (state in LDS), a dense proposal by path 6's launches */
-#define MCD_MH_PATH_SEGMENTS_SPARSE 9         /* sparse likelihood, 3 .. 2048 nodes: the same with the quadratic form updated through the rows of the moved distances (k_mh_segment_sparse.hip); a dense proposal by the step kernel + the one-launch full form */
+#define MCD_MH_PATH_SEGMENTS 8                /* 259 .. 1026 nodes: every run of steps between two dense proposals in one launch (state in LDS); a dense proposal: proposed by the segment before it (else by path 6's step kernel) + the row-split launch */
+#define MCD_MH_PATH_SEGMENTS_SPARSE 9         /* sparse likelihood, 3 .. 2048 nodes: the same with the quadratic form updated through the rows of the moved distances (k_mh_segment_sparse.hip); a dense proposal: proposed by the segment before it + the one-launch full form */
 int mcd_mh_last_path(const mcd_mh_t* m);
 /* LDS bytes per workgroup of the persistent kernel the last mcd_mh_run launched (reporting: a profiler's kernel trace shows the static group
  * segment only, which is 0 for the kernels that size their LDS at launch); 0 when the run took per-step launches only. */

@@ -364,9 +364,9 @@ PATHS = {0: "none", 1: "whole schedule in one launch, factor resident in LDS", 2
          5: "two launches per lock step: workgroup-per-chain step kernel leaving distances + plain-vector likelihood",
          6: "workgroup-per-chain step kernel + a likelihood launch only for proposals that move many distances (the others: columns of L^-1 on the kept z)",
          7: "two launches per lock step: workgroup-per-chain step kernel leaving distances + the sparse product (precision matrix in CSR)",
-         8: "segments: the steps between two dense proposals in one launch with the chains' states in LDS; a dense proposal by the step kernel and a likelihood launch",
+         8: "segments: the steps between two dense proposals in one launch with the chains' states in LDS; a dense proposal is proposed by the segment before it and evaluated by a likelihood launch",
          9: "segments over a sparse precision matrix: the steps between two dense proposals in one launch, the quadratic form updated through the rows of the "
-            "moved distances; a dense proposal by the step kernel and the one-launch full form"}
+            "moved distances; a dense proposal is proposed by the segment before it and evaluated by the one-launch full form"}
 
 
 def philox4x32(counter, key):

@@ -960,3 +960,58 @@ def test_prior_waves_of_the_segment_kernels_give_the_same_chains(gpu, n_leaves, 
     for f in ("time_birth_rate", "time_death_rate", "time_height", "heights", "rate_mean", "rate_variance", "rates"):
         assert np.array_equal(getattr(a[2], f), getattr(b[2], f)), f
     assert np.array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_dense_proposals_at_every_position_of_a_segmented_run(gpu, sparse, knobs):
+    """A schedule made by hand around the places where the segment path changes hands (mh_capi.cpp): a dense proposal (one that moves every
+    distance: the scalings of the time height and of the rate mean) as the run's first step, directly after another dense one, as the step a
+    recomputation of z / q falls on (every 256th), as the step after it, and as the run's last step -- proposed by the preceding segment's
+    launch where there is one (MhSegPending::p_tail), by the step kernel otherwise, decided by the following segment's launch or by the step
+    kernel.  Every ln acceptance ratio, decision, state and posterior term equals the run with MCD_MH_SEG_TAIL = 0 bit for bit, and the run
+    with two launches per step (MCD_MH_SEGMENTS = 0) in its decisions and states."""
+    from mcmc_date_amd import synthetic as S
+    from mcmc_date_amd import sampler as SM
+
+    topo = S.random_topology(180, seed=9)
+    n = topo.n_nodes - 2
+    B = 7
+    if sparse:
+        _, assoc = S.banded_precision(n, seed=n)
+        lik = M.SparseLikelihood(M.Sparse(np.random.default_rng(1).uniform(0.01, 0.2, n), assoc, 0.0)).bind_tree(topo)
+    else:
+        mu, sigma = S.random_spd_problem(n, seed=n)
+        lik = M.MvnLikelihood.from_covariance(mu, sigma).bind_tree(topo)
+    pf = M.PriorFunction(1.0, "UncorrelatedGamma", [M.Calibration("root", 0, 0.9, 0.025, 1.3, 0.025)], [], [], topo)
+    ps, _ = M.proposals(topo, [], calibrations_available=True)
+    tab = M.table_arrays(ps)
+    dense = [i for i in range(len(ps)) if tab["kind"][i] == SM.SCALE_SCALAR and tab["node"][i] in (SM.TIME_HEIGHT, SM.RATE_MEAN)]
+    few = [i for i in range(len(ps)) if tab["kind"][i] in (SM.SLIDE_NODE, SM.SCALE_BRANCH_RATE)]
+    assert len(dense) == 2 and len(few) > 100
+    rng = np.random.default_rng(4)
+    sched = rng.choice(few, size=600).astype(np.int32)
+    for pos, d in ((0, 0), (40, 0), (41, 1), (42, 0), (255, 1), (256, 0), (257, 1), (300, 0), (511, 0), (512, 1), (599, 1)):
+        sched[pos] = dense[d]
+    sched = sched[None, :]
+    s0 = S.random_states(topo, B, seed=5)
+    s0.time_birth_rate = np.full(B, 1.0); s0.time_death_rate = np.full(B, 0.8); s0.rate_variance = np.full(B, 0.3)
+    out = {}
+    for name, knob, val in (("tail", None, None), ("step kernel", "MCD_MH_SEG_TAIL", "0"), ("two launches", "MCD_MH_SEGMENTS", "0")):
+        if knob:
+            knobs.setenv(knob, val)
+        smp = M.Sampler(lik, pf, ps, B, seed=21)
+        smp.set_state(s0)
+        ta, tk = smp.run_schedule(sched, trace=True)
+        ta2, tk2 = smp.run_schedule(sched[:, :301], trace=True)      # (a second run: starts on a dense proposal, ends on one)
+        assert ("segments" in smp.last_path()) == (name != "two launches"), smp.last_path()
+        out[name] = (np.concatenate([ta, ta2]), np.concatenate([tk, tk2]), smp.state(), smp.posterior())
+        if knob:
+            knobs.delenv(knob)
+    a, b, c = out["tail"], out["step kernel"], out["two launches"]
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    assert 0.02 < a[1].mean() < 0.98 and a[1][[0, 40, 41, 256, 599]].any()
+    assert np.array_equal(a[1], c[1])
+    np.testing.assert_allclose(a[0], c[0], rtol=0, atol=1e-6)
+    for f in ("time_birth_rate", "time_death_rate", "time_height", "heights", "rate_mean", "rate_variance", "rates"):
+        assert np.array_equal(getattr(a[2], f), getattr(b[2], f)), f
+        assert np.array_equal(getattr(a[2], f), getattr(c[2], f)), f
