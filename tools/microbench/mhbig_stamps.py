@@ -3,7 +3,7 @@ loop head | propose | prior | distances | first ring barrier + sweep | accept.
 Build first:  make -C mcmc-date_amd/csrc stamp_mhbig ;  on the GPU box:  python tools/microbench/mhbig_stamps.py [n] [chains] [steps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MCD_LIB_PATH"] = os.path.join(ROOT, "tools", "microbench", "libmhbigstamp.so")
+os.environ["MCD_LIB_PATH"] = os.path.join(ROOT, "tools", "microbench", os.environ.get("MHBSTAMPLIB", "libmhbigstamp.so"))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
