@@ -92,7 +92,8 @@ def cpu_baseline(n, mu, sigma, X, budget_s=12.0):
     return out
 
 
-def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_period=0, swap_steps=0, rehearsal=False, sparse=False, repeats=1):
+def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_period=0, swap_steps=0, rehearsal=False, sparse=False, repeats=1,
+               tune_periods=0):
     """Lock-step Metropolis-Hastings on the device (the metric's "= MCMC steps/sec x chains" reading):
     a synthetic tree of dimension n (255 for --n 256: 2L - 3 is odd), the reference's whole proposal cycle
     (app/Definitions.hs:127-278) in its shuffled order, B chains per GPU stepping together; one step = one proposal of the cycle,
@@ -101,7 +102,11 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_perio
     swap_period = P > 0 (BASELINE.json config 5; `mc3 (MC3Settings (NChains 4) (SwapPeriod P) (NSwaps 3))`, app/Main.hs:476-478):
     every P iterations of the cycle (or every `swap_steps` lock steps, for rehearsals shorter than an iteration) the ranks
     all-gather their [3][B] ln posteriors on the sampler's stream (mcd_shard_allgather: RCCL over xGMI) and every rank runs the
-    swap phase of all groups on the gathered values (mcd_mh_mc3_swap) -- inside the timed region.  Returns a dict for the JSON line."""
+    swap phase of all groups on the gathered values (mcd_mh_mc3_swap) -- inside the timed region.  tune_periods = T > 0: before the
+    warm-up, T periods of one iteration of the cycle each followed by `mcmc`'s auto-tuning (mcd_mh_tune) -- the reference always samples
+    with tuned proposals (burnIn = BurnInWithCustomAutoTuning, app/Definitions.hs:420-424); the untuned default accepts most proposals,
+    which is the expensive case for the persistent kernels (a proposal drawn ahead is thrown away after an acceptance).  The line says
+    which acceptance rate the timed steps had.  Returns a dict for the JSON line."""
     import torch
 
     import mcmc_date_amd as M
@@ -161,7 +166,11 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_perio
                 phases[0] += 1
             pos = nxt
 
+    for _ in range(int(tune_periods)):
+        smp.run_schedule(M.cycle_schedule(ps, 1, np.random.default_rng(100 + _)))
+        smp.autotune()
     advance(0, warm)
+    smp.reset_counters()
     if mc3 is not None and warm < period:                      # the first phase of a short run: exercised once outside the clock
         mc3.swap()
     torch.cuda.synchronize()
@@ -184,6 +193,7 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_perio
         advance(warm + steps, warm + 2 * steps)
         torch.cuda.synchronize()
         dt = min(dt, time.perf_counter() - t0)
+    _, n_acc, n_try = smp.tuning()
     post = smp.posterior()
     assert np.all(np.isfinite(post)), "non-finite ln posterior after the Metropolis-Hastings run"
     if mc3 is not None:
@@ -198,6 +208,7 @@ def mh_measure(dev_index, n, B, steps, warm, seed=3, rank=0, world=1, swap_perio
            "n_nodes": int(topo.n_nodes), "dimension": int(nd), "chains": int(B), "lock_steps": int(steps),
            "proposals_per_iteration": S_iter, "likelihood": "sparse precision matrix (CSR on the device)" if sparse else "dense factor",
            "lds_bytes_per_workgroup": smp.last_dynamic_lds(),
+           "acceptance_rate": float(n_acc.sum()) / max(1.0, float(n_try.sum())), "tune_periods": int(tune_periods),
            "what": "reference proposal cycle (16 kinds), prior + likelihood + accept/reject on the device; " + smp.last_path()}
     if swap_info:
         out["mc3"] = swap_info
@@ -483,6 +494,8 @@ def main():
     ap.add_argument("--chains", type=int, default=512, help="chains per GPU")
     ap.add_argument("--swap-period", type=int, default=0, help="--kind mh: MC3 swap phase (all-gather of the ln posteriors + swaps) every P "
                     "iterations of the proposal cycle, config 5; other kinds: all-gather ll every P steps (0 = off)")
+    ap.add_argument("--tune-periods", type=int, default=0, help="--kind mh: auto-tuning periods (one iteration of the cycle each) before the warm-up: "
+                    "the reference samples with tuned proposals; default 0 = the initial tuning parameters (most proposals accepted)")
     ap.add_argument("--swap-steps", type=int, default=0, help="--kind mh: swap phase every Q lock steps instead (rehearsals shorter than an iteration)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
     ap.add_argument("--graph-chunk", type=int, default=100, help="steps captured per hipGraph")
@@ -533,7 +546,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        r = mh_measure(dev_index, n, B, K, W, seed=3, rank=rank, world=world, swap_period=args.swap_period, swap_steps=args.swap_steps,
+        r = mh_measure(dev_index, n, B, K, W, seed=3, rank=rank, world=world, swap_period=args.swap_period, swap_steps=args.swap_steps, tune_periods=args.tune_periods,
                        rehearsal=rehearsal, sparse=args.sparse)
         elapsed = K * r["us_per_lockstep"] * 1e-6
         ranks = rank_report(dist, world, rank, elapsed, K, ctl_dev, rehearsal, r.get("rccl_comm_ranks"))

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
     SegWords* words = reinterpret_cast<SegWords*>(reinterpret_cast<double*>(mark + NPad));
     SegHelpWords* help = reinterpret_cast<SegHelpWords*>(reinterpret_cast<double*>(words) + 8);
     PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(help) + kSegHelpDoubles);
+    SegSpec* spec = reinterpret_cast<SegSpec*>(reinterpret_cast<double*>(A_lds) + kSegApplyDoubles);
     lds_vint_t* w_req = lds_vint(&words->req);
     lds_vint_t* w_moves = lds_vint(&words->moves);
     lds_vint_t* w_resp = lds_vint(&words->resp);
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
         ts_of[v] = -1;
     }
     if (role == 0 && lane == 0) {
+        spec->word = 0;
         help->resp_bd = 0;
         help->resp_cl = 0;
         help->done_bd = 0;
@@ -145,16 +147,17 @@ __global__ __launch_bounds__(HELP ? 512 : 256, 1) void k_mh_segment(MhDev M, Mvn
     L.tcl = tcl;
     L.words = words;
     L.A_lds = A_lds;
+    L.spec = spec;
     L.c = V.c;
     L.logdet = V.logdet;
     // ================================================================ prior waves
     if constexpr (HELP) {
         if (role == 2) {
-            seg_prior_wave<0>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
+            seg_prior_wave<0>(M, P, Pst, L, Q, sched, n_steps, step0, seed, b, valid, lane);
             return;
         }
         if (role == 3) {
-            seg_prior_wave<1>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
+            seg_prior_wave<1>(M, P, Pst, L, Q, sched, n_steps, step0, seed, b, valid, lane);
             return;
         }
     }
@@ -439,6 +442,7 @@ hipError_t launch_mh_segment(const MhDev& M, const MvnDev& V, const TreeDev& T, 
     Q.p_tail = -1;
     if (pending) Q = *pending;
     Q.ahead_from = opt_or(OPT_MH_AHEAD_FROM, kSegAheadFrom);
+    Q.prior_draws = (!opt_is(OPT_MH_PRIOR_DRAWS, 0) && !opt_is(OPT_MH_PRIOR_WAVES, 0)) ? 1 : 0;
     if (n_steps <= 0) return Q.p_acc >= 0 ? hipErrorInvalidValue : hipSuccess;
     if (Q.p_acc >= 0 && (Q.X1 == nullptr || (Q.z_in_zprop ? I.zprop == nullptr : I.zt == nullptr) || !summands_kept)) return hipErrorInvalidValue;
     if (Q.p_tail >= M.n_prop || (Q.p_tail >= 0 && (Q.X1_tail == nullptr || M.psum == nullptr || M.psel == nullptr))) return hipErrorInvalidValue;

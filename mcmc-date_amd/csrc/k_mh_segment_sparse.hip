@@ -42,7 +42,8 @@ __host__ __device__ inline size_t sseg_table_doubles(int n_nodes, int np, int si
 // (int32 [np]); eight words of hand-over; the proposal's per-node transform.
 __host__ __device__ inline size_t sseg_chain_doubles(int n_nodes, int np)
 {
-    return 6 * (size_t)n_nodes + 2 * (size_t)kSsegListAlloc + (size_t)kSsegListAlloc / 2 + (size_t)np / 2 + 8 + (size_t)kSegHelpDoubles + (size_t)kSegApplyDoubles;
+    return 6 * (size_t)n_nodes + 2 * (size_t)kSsegListAlloc + (size_t)kSsegListAlloc / 2 + (size_t)np / 2 + 8 + (size_t)kSegHelpDoubles + (size_t)kSegApplyDoubles +
+           (size_t)kSegSpecDoubles;
 }
 __host__ __device__ inline size_t sseg_lds_bytes(int n_nodes, int np, int cpw, int size_in_lds)
 {
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
     SegWords* words = reinterpret_cast<SegWords*>(reinterpret_cast<double*>(mark + NPad));
     SegHelpWords* help = reinterpret_cast<SegHelpWords*>(reinterpret_cast<double*>(words) + 8);
     PropApply* A_lds = reinterpret_cast<PropApply*>(reinterpret_cast<double*>(help) + kSegHelpDoubles);
+    SegSpec* spec = reinterpret_cast<SegSpec*>(reinterpret_cast<double*>(A_lds) + kSegApplyDoubles);
     lds_vint_t* w_req = lds_vint(&words->req);
     lds_vint_t* w_moves = lds_vint(&words->moves);
     lds_vint_t* w_resp = lds_vint(&words->resp);
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
         words->dec = 0;
         words->cnt = 0;
         words->have0 = 0;
+        spec->word = 0;
         help->resp_bd = 0;
         help->resp_cl = 0;
         help->done_bd = 0;
@@ -174,16 +177,17 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
     L.tcl = tcl;
     L.words = words;
     L.A_lds = A_lds;
+    L.spec = spec;
     L.c = Sp.c;
     L.logdet = Sp.logdet;
     // ================================================================ prior waves
     if constexpr (HELP) {
         if (role == 2) {
-            seg_prior_wave<0>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
+            seg_prior_wave<0>(M, P, Pst, L, Q, sched, n_steps, step0, seed, b, valid, lane);
             return;
         }
         if (role == 3) {
-            seg_prior_wave<1>(M, P, Pst, L, Q, n_steps, seed, b, valid, lane);
+            seg_prior_wave<1>(M, P, Pst, L, Q, sched, n_steps, step0, seed, b, valid, lane);
             return;
         }
     }
@@ -490,8 +494,8 @@ __global__ __launch_bounds__(64 * CPW * (HELP ? 4 : 2), 1) void k_mh_segment_spa
     }
 
     // ================================================================ chain waves (mh_segment_device.hpp: shared with the dense kernel)
-    // (two instances with the prior waves: small trees take the plain loop, mh_segment_device.hpp)
-    if (HELP && nn < Q.ahead_from)
+    // (two instances with the prior waves: the plain loop for small trees when no prior wave draws -- MCD_MH_PRIOR_DRAWS = 0)
+    if (HELP && !Q.prior_draws && nn < Q.ahead_from)
         seg_chain_wave<HELP, HELP>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
     else
         seg_chain_wave<HELP, false>(M, P, Pst, L, Q, sched, n_steps, S, accumulate, step0, seed, trace_alpha, trace_accept, gs_base, summands_kept, b, valid, lane);
@@ -540,6 +544,7 @@ hipError_t launch_mh_segment_sparse(const MhDev& M, const SparseDev& Sp, const T
     Q.p_tail = -1;
     if (pending) Q = *pending;
     Q.ahead_from = opt_or(OPT_MH_AHEAD_FROM, kSegAheadFrom);
+    Q.prior_draws = (!opt_is(OPT_MH_PRIOR_DRAWS, 0) && !opt_is(OPT_MH_PRIOR_WAVES, 0)) ? 1 : 0;
     if (n_steps <= 0) return Q.p_acc >= 0 ? hipErrorInvalidValue : hipSuccess;
     if (Q.p_acc >= 0 && (Q.X1 == nullptr || I.zprop == nullptr || !summands_kept)) return hipErrorInvalidValue;
     if (Q.p_tail >= M.n_prop || (Q.p_tail >= 0 && (Q.X1_tail == nullptr || M.psum == nullptr || M.psel == nullptr))) return hipErrorInvalidValue;

@@ -11,6 +11,19 @@
 namespace mcd {
 
 constexpr int kSegApplyDoubles = (int)((sizeof(PropApply) + 7) / 8);   // the proposal's per-node transform, chain wave -> likelihood wave
+// The CLOCK prior wave also draws the NEXT step's proposal (MhSegPending::prior_draws): a step's two prior waves idle for most of it -- on
+// a proposal that moves heights only the clock wave of an uncorrelated model has nothing to do at all -- while the chain wave would draw the
+// next proposal only after the decision (or, round 4's first arrangement, ahead of it in its own idle time -- and then again after every
+// acceptance).  The prior wave draws from the current state (what the next step starts from if this one is rejected: most are) with its
+// own copy of the 64-step draw blocks and the scalars it keeps anyway; the chain wave takes the transform from here after a rejection
+// and draws itself after an acceptance.  The same function on the same inputs: the same bits.
+struct SegSpec {
+    PropApply A;                   // the transform of step `word` - 1, its proposed scalars, ln (q-ratio * Jacobian)
+    double sc1[5];
+    double lnqj;
+    int word, pad;
+};
+constexpr int kSegSpecDoubles = (int)((sizeof(SegSpec) + 7) / 8);
 #ifndef MCD_SEG_COLS
 #define MCD_SEG_COLS 4
 #endif
@@ -30,7 +43,8 @@ __host__ __device__ inline size_t seg_table_doubles(int n_nodes, int np) { retur
 // int32); the slots' marks (int32 [np]); eight words of hand-over; the proposal's per-node transform.
 __host__ __device__ inline size_t seg_chain_doubles(int n_nodes, int np)
 {
-    return 6 * (size_t)n_nodes + (size_t)np + 2 * (size_t)kSegList + (size_t)kSegList / 2 + (size_t)np / 2 + 8 + 16 /* SegHelpWords */ + (size_t)kSegApplyDoubles;
+    return 6 * (size_t)n_nodes + (size_t)np + 2 * (size_t)kSegList + (size_t)kSegList / 2 + (size_t)np / 2 + 8 + 16 /* SegHelpWords */ + (size_t)kSegApplyDoubles +
+           (size_t)kSegSpecDoubles;
 }
 
 __host__ __device__ inline size_t seg_lds_bytes(int n_nodes, int np) { return sizeof(double) * (seg_table_doubles(n_nodes, np) + 2 * seg_chain_doubles(n_nodes, np)); }
@@ -109,6 +123,7 @@ struct SegChainCtx {
     double *Hc, *Rc, *Hp, *Rp, *tbd, *tcl;                          // [n_nodes] each: current / proposed state, summands of the two blocks
     SegWords* words;
     PropApply* A_lds;
+    SegSpec* spec;                                                  // (HELP: the next step's proposal, drawn by the clock prior wave)
     double c, logdet;                                               // ll = c - 1/2 (logdet + q)
 };
 
@@ -118,7 +133,8 @@ struct SegChainCtx {
 // kept and new summands in the order of the full evaluation; otherwise every summand.  Pl: the prior's tables with the tree in LDS.
 template <int BLOCK>
 __device__ __forceinline__ void seg_prior_wave(const MhDev& M, const PriorDev& P, const PriorDev& Pst, const SegChainCtx& L, const MhSegPending& Q,
-                                               int64_t n_steps, uint64_t seed, int64_t b, bool valid, int lane)
+                                               const int32_t* __restrict__ sched, int64_t n_steps, uint64_t step0, uint64_t seed, int64_t b, bool valid,
+                                               int lane)
 {
     PriorDev Pl = Pst;                                       // (as the chain wave: the tree's tables from LDS)
     Pl.parent = L.tb_parent;
@@ -146,6 +162,24 @@ __device__ __forceinline__ void seg_prior_wave(const MhDev& M, const PriorDev& P
     for (int i = 0; i < 5; ++i) sc[i] = (took ? M.sc1 : M.sc)[i * B + b];
     ClockCache cc{__builtin_nan(""), 0.0, 0.0, 0.0};
     if (BLOCK == 1) prior_clock_scalars(sc[4], cc);
+    // (SegSpec) the clock wave draws the next step's proposal: the chain's tables, tuning parameters and draw blocks as the chain wave has them
+    const bool draws = Q.prior_draws != 0;
+    MhDev Ml = M;
+    Ml.parent = L.tb_parent;
+    Ml.size = L.tb_size;
+    const double* tune = M.tune + b * M.n_prop;
+    const int vz = mh_vzero();
+    int p_n = 0, p_nn = 0;
+    PropRow row_n{0, 0, 0, 0, 0, 0.0, 0.0};
+    double tune_n = 0.0;
+    StepDraws pre{1.0, 0.0, 0.0, 0.5, 0.5};
+    int64_t blk = -1;
+    if (draws) {
+        p_n = sched[(n_steps > 1 ? 1 : 0) + vz];             // the row of step gs + 1 travels a step ahead, the schedule's entry after it two
+        row_n = mh_load_row_ahead(M, p_n);
+        tune_n = tune[p_n];
+        p_nn = sched[(n_steps > 2 ? 2 : 0) + vz];
+    }
     for (int64_t gs = 0; gs < n_steps; ++gs) {
         const int tag = (int)gs + 1;
         (void)seg_poll(w_req, tag, 0);
@@ -237,6 +271,43 @@ __device__ __forceinline__ void seg_prior_wave(const MhDev& M, const PriorDev& P
             }
         }
         if (need) seg_post(w_resp, tag);
+        if (draws && gs + 1 < n_steps) {
+            // ---- the proposal of step gs + 1 from the CURRENT state (read while the chain wave may already commit an accepted step gs: then
+            // what is drawn here is not used).  The wave whose block this step does not need draws it -- the clock wave if both or neither do
+            // (the same expressions on the same numbers in both waves).
+            const bool n_bd = dH || sc1[0] != sc[0] || sc1[1] != sc[1];
+            const bool n_cl = dR || sc1[3] != sc[3] || sc1[4] != sc[4] || (dH && P.clock_model >= 2);
+            const int drawer = (n_cl && !n_bd) ? 0 : 1;
+            const int64_t t = gs + 1;
+            if (drawer == BLOCK) {
+                if ((t >> 6) != blk) {
+                    blk = t >> 6;
+                    const int64_t mine = (blk << 6) + lane;
+                    if (mine < n_steps) {
+                        const int pl = sched[mine];
+                        pre = mh_step_draws(mh_load_row(M, pl), tune[pl], mh_rng(seed, M.chain0 + b, step0 + (uint64_t)mine));
+                    }
+                }
+                const int sl = (int)(t & 63);
+                const StepDraws dr{mh_readlane64(pre.u, sl), mh_readlane64(pre.lnq, sl), mh_readlane64(pre.logu, sl), mh_readlane64(pre.U, sl), 0.5};
+                double scn[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) scn[i] = sc[i];
+                PropApply An;
+                const double lqn = mh_propose_params(Ml, mh_row_scalar(row_n), tune_n, dr, lane, scn, L.Hc, L.Rc, An);
+                if (lane == 0) {
+                    L.spec->A = An;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) L.spec->sc1[i] = scn[i];
+                    L.spec->lnqj = lqn;
+                }
+                seg_post(lds_vint(&L.spec->word), (int)t + 1);
+            }
+            p_n = p_nn;                                      // the row after it: on its way until the next step's draw
+            row_n = mh_load_row_ahead(M, p_n);
+            tune_n = tune[p_n];
+            p_nn = sched[((t + 2 < n_steps) ? t + 2 : t) + vz];
+        }
         const int d = seg_poll(w_dec, tag, 1);
         if (d & 1) {
             // (few: already in place)  every summand: evaluated again, now to be kept -- the same function results as the sum's
@@ -504,7 +575,8 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
     bool moves = false;
     int64_t gs = 0;
     // (small trees: the other waves answer before a proposal is drawn -- drawing ahead would only add the discarded draws after acceptances)
-    const bool ahead = !PLAIN && nn >= Q.ahead_from;
+    const bool dual = !PLAIN && HELP && Q.prior_draws != 0;  // (SegSpec) the next proposal drawn for both outcomes of the decision
+    const bool ahead = !PLAIN && (nn >= Q.ahead_from || dual);
     int64_t to_close = S - (gs_base % S);                    // steps until the next iteration of the cycle closes
     // a drawn proposal (step gs) goes into flight: applied to Hp / Rp, posted to the other waves
     auto launch = [&](const PropApply& An, const double (&sc1n)[5], double lnqjn, double uaccn) __attribute__((always_inline)) {
@@ -585,7 +657,14 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
             const int sl = (int)(target & 63);
             const StepDraws dr{mh_readlane64(pre.u, sl), mh_readlane64(pre.lnq, sl), mh_readlane64(pre.logu, sl), mh_readlane64(pre.U, sl),
                                mh_readlane64(pre.Uacc, sl)};
-            lnqjn = mh_propose_params(Ml, row_t, tune_t, dr, lane, sc1n, Hc, Rc, An);
+            // (SegSpec) with a prior wave drawing the next proposal from the CURRENT state -- the branch "this step is rejected" --, this wave
+            // draws it from the PROPOSED state: the branch "accepted".  Whatever the decision, the next proposal is there.
+            const bool from_proposed = dual && inflight;
+            if (from_proposed) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) sc1n[i] = sc1[i];
+            }
+            lnqjn = mh_propose_params(Ml, row_t, tune_t, dr, lane, sc1n, from_proposed ? Hp : Hc, from_proposed ? Rp : Rc, An);
             uaccn = dr.Uacc;
         }
         SEG_TICK(1)
@@ -777,7 +856,18 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
             gs += 1;
             inflight = false;
             if (gs >= n_steps) break;
-            start = !ok && drew_next;                        // rejected: the state An was drawn from is still the current one
+            if (dual) {
+                start = drew_next;                           // accepted: An was drawn from the state that is now the current one
+                if (!ok && drew_next) {                      // rejected: the prior wave's draw from the state that still is
+                    (void)seg_poll(lds_vint(&L.spec->word), (int)gs + 1, 0);
+                    An = L.spec->A;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) sc1n[i] = L.spec->sc1[i];
+                    lnqjn = L.spec->lnqj;
+                }
+            } else {
+                start = !ok && drew_next;                    // rejected: the state An was drawn from is still the current one
+            }
         }
         if constexpr (AHEAD) {
             if (start) launch(An, sc1n, lnqjn, uaccn);

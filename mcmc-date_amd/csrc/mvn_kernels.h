@@ -201,6 +201,7 @@ struct MhSegPending {          // a dense proposal that is still to be decided w
     int p_tail;                // its row of the proposal table, -1 = none
     double* X1_tail;           // [batch][n] its distances
     int ahead_from;            // trees from this many nodes: the chain wave draws the next step's proposal while the step in flight is evaluated
+    int prior_draws;           // the clock prior wave draws the next step's proposal (segment kernels with prior waves; mh_segment_device.hpp: SegSpec)
 };
 bool mh_segment_available(const MhDev& M, const MvnDev& V);
 // the same over a sparse precision matrix (k_mh_segment_sparse.hip); I: X0 = current distances [batch][n], zcur / zprop = the quadratic

@@ -15,7 +15,7 @@ namespace {
 const char* const kNames[OPT_COUNT] = {
     "MCD_MH_PER_PHASE", "MCD_MH_SEGMENTS", "MCD_MH_INCREMENTAL", "MCD_MH_PRIOR", "MCD_MH_PRIOR_CACHE", "MCD_MH_STEP_WG", "MCD_MH_CHAIN_LW",
     "MCD_MH_INC_SLOTS", "MCD_MH_SPARSE_SLOTS", "MCD_SPLIT", "MCD_SPLIT_G", "MCD_SPLIT_SCATTER", "MCD_SPLIT_NOROT", "MCD_SPLIT_PROBE", "MCD_GEOM",
-    "MCD_WIDE_CT", "MCD_SPARSE_QUAD", "MCD_MH_PRIOR_WAVES", "MCD_LOADERS", "MCD_MH_SEG_TAIL", "MCD_MH_AHEAD_FROM"};
+    "MCD_WIDE_CT", "MCD_SPARSE_QUAD", "MCD_MH_PRIOR_WAVES", "MCD_LOADERS", "MCD_MH_SEG_TAIL", "MCD_MH_AHEAD_FROM", "MCD_MH_PRIOR_DRAWS"};
 
 struct Table {
     std::atomic<int> v[OPT_COUNT];

@@ -29,6 +29,7 @@ enum Option {
     OPT_LOADERS,            // 2: two loader waves in the column sweep's 512-chain geometry at 129 .. 256 dimensions instead of four (A/B)
     OPT_MH_SEG_TAIL,        // 0: a dense proposal that follows a segment is proposed by a launch of the step kernel, not by the segment's launch (A/B, tests)
     OPT_MH_AHEAD_FROM,      // nodes from which a segment kernel's chain wave draws the next proposal ahead of the decision (default: kSegAheadFrom)
+    OPT_MH_PRIOR_DRAWS,     // 0: the next step's proposal is not drawn by a prior wave (the chain wave draws ahead itself from MCD_MH_AHEAD_FROM nodes; A/B, tests)
     OPT_COUNT
 };
 constexpr int MCD_OPT_UNSET = -2147483647 - 1;

@@ -916,7 +916,7 @@ def test_shard_allgather_through_rccl(gpu, golden):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("knob", ["MCD_MH_PRIOR_WAVES", "MCD_MH_SEG_TAIL"])
+@pytest.mark.parametrize("knob", ["MCD_MH_PRIOR_WAVES", "MCD_MH_SEG_TAIL", "MCD_MH_PRIOR_DRAWS"])
 @pytest.mark.parametrize("n_leaves,B,sparse", [(200, 33, False), (513, 16, False), (7, 8, True), (300, 17, True), (1007, 5, True)])
 def test_prior_waves_of_the_segment_kernels_give_the_same_chains(gpu, n_leaves, B, sparse, knob, knobs):
     """The segment kernels (k_mh_segment.hip, k_mh_segment_sparse.hip) give every chain two PRIOR waves beside its chain wave and its
