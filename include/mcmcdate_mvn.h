@@ -91,7 +91,7 @@ const char* mcd_last_error(void);
  * "MCD_MH_PRIOR", "MCD_MH_PRIOR_CACHE", "MCD_MH_STEP_WG", "MCD_MH_CHAIN_LW", "MCD_MH_INC_SLOTS", "MCD_MH_SPARSE_SLOTS", "MCD_SPLIT", "MCD_SPLIT_G",
  * "MCD_SPLIT_SCATTER", "MCD_SPLIT_NOROT", "MCD_SPLIT_PROBE", "MCD_GEOM", "MCD_WIDE_CT", "MCD_SPARSE_QUAD", "MCD_MH_PRIOR_WAVES", "MCD_LOADERS",
  * "MCD_MH_SEG_TAIL" (0: a dense proposal after a segment is proposed by the step kernel), "MCD_MH_AHEAD_FROM" (nodes from which a segment's chain
- * wave draws the next proposal ahead of the decision); value = a decimal integer, NULL or ""
+ * wave draws the next proposal ahead of the decision), "MCD_MH_PRIOR_DRAWS" (0: no prior wave draws the next proposal's rejected branch); value = a decimal integer, NULL or ""
  * = back to the default.  What each knob does is said where it acts (mcd_mh_run, the forms above).  The environment variables of the same
  * names are read ONCE, when the library is loaded, as initial values -- never afterwards.  No knob changes a result beyond rounding.
  */

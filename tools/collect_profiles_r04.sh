@@ -43,6 +43,9 @@ python3 bench.py --kind mh --steps 8000 --warmup 800 > $OUT/bench_mh.json 2> $OU
 python3 bench.py --kind mh --dim 1024 --chains 512 --swap-period 2 --steps 31826 --warmup 1000 > $OUT/bench_cfg5_1gpu.json 2> $OUT/bench_cfg5_1gpu.log
 python3 bench.py --kind mh --sparse --dim 2012 --chains 512 --steps 8000 --warmup 800 > $OUT/bench_mh_sparse_2013.json 2> $OUT/bench_mh_sparse_2013.log
 python3 bench.py --kind mh --sparse --dim 1024 --chains 512 --steps 8000 --warmup 800 > $OUT/bench_mh_sparse_1025.json 2> $OUT/bench_mh_sparse_1025.log
+python3 bench.py --kind mh --dim 1024 --chains 512 --swap-period 2 --steps 31826 --warmup 1000 --tune-periods 20 > $OUT/bench_cfg5_1gpu_tuned.json 2> $OUT/bench_cfg5_1gpu_tuned.log
+python3 bench.py --kind mh --sparse --dim 2012 --chains 512 --steps 8000 --warmup 800 --tune-periods 20 > $OUT/bench_mh_sparse_2013_tuned.json 2> $OUT/bench_mh_sparse_2013_tuned.log
+python3 bench.py --kind mh --sparse --dim 1024 --chains 512 --steps 8000 --warmup 800 --tune-periods 20 > $OUT/bench_mh_sparse_1025_tuned.json 2> $OUT/bench_mh_sparse_1025_tuned.log
 python3 bench.py --kind sparse --dim 2011 --chains 512 --steps 300 --warmup 30 > $OUT/bench_sparse.json 2> $OUT/bench_sparse.log
 python3 bench.py --kind sparse --dim 256 --chains 512 --steps 300 --warmup 30 > $OUT/bench_sparse_256.json 2> $OUT/bench_sparse_256.log
 python3 bench.py --kind e2e > $OUT/bench_e2e.json 2> $OUT/bench_e2e.log
@@ -112,7 +115,7 @@ traffic["note"] = ("rocprofv3 --pmc, separate passes per counter; KiB per dispat
 json.dump(traffic, open(os.path.join(out, "r04_pmc_traffic.json"), "w"), indent=1)
 json.dump(traces, open(os.path.join(out, "r04_kernel_trace_summary.json"), "w"), indent=1)
 for name in ("bench_default.json", "bench_driver.json", "bench_mh.json", "bench_cfg5_1gpu.json", "bench_mh_sparse_2013.json", "bench_mh_sparse_1025.json", "bench_sparse.json",
-             "bench_sparse_256.json", "bench_e2e.json"):
+             "bench_sparse_256.json", "bench_e2e.json", "bench_cfg5_1gpu_tuned.json", "bench_mh_sparse_2013_tuned.json", "bench_mh_sparse_1025_tuned.json"):
     src = os.path.join(base, name)
     if os.path.exists(src):
         open(os.path.join(out, "r04_" + name), "w").write("".join(l for l in open(src) if l.startswith("{")))
