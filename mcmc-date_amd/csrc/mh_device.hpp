@@ -227,6 +227,28 @@ struct PropApply {
     double hmul, hmul2, rmul, radd, pv1, pv2, rm1, rm2, rm3, brace_delta;
 };
 
+// The integer fields of a transform are the same in every lane: as scalars (SGPRs) they turn the range tests and the rarely taken paths
+// of mh_propose_node (the division, the guarded rates, the braces' loop) into scalar branches instead of predicated vector code.
+__device__ __forceinline__ void mh_apply_scalars(PropApply& A)
+{
+    A.kind = __builtin_amdgcn_readfirstlane(A.kind);
+    A.hlo = __builtin_amdgcn_readfirstlane(A.hlo);
+    A.hhi = __builtin_amdgcn_readfirstlane(A.hhi);
+    A.hlo2 = __builtin_amdgcn_readfirstlane(A.hlo2);
+    A.hhi2 = __builtin_amdgcn_readfirstlane(A.hhi2);
+    A.rlo = __builtin_amdgcn_readfirstlane(A.rlo);
+    A.rhi = __builtin_amdgcn_readfirstlane(A.rhi);
+    A.pt1 = __builtin_amdgcn_readfirstlane(A.pt1);
+    A.pt2 = __builtin_amdgcn_readfirstlane(A.pt2);
+    A.rp1 = __builtin_amdgcn_readfirstlane(A.rp1);
+    A.rp2 = __builtin_amdgcn_readfirstlane(A.rp2);
+    A.rp3 = __builtin_amdgcn_readfirstlane(A.rp3);
+    A.brace_lo = __builtin_amdgcn_readfirstlane(A.brace_lo);
+    A.brace_hi = __builtin_amdgcn_readfirstlane(A.brace_hi);
+    A.rate_positive_guard = __builtin_amdgcn_readfirstlane(A.rate_positive_guard);
+    A.h_divide = __builtin_amdgcn_readfirstlane(A.h_divide);
+}
+
 // proposed height and rate of node w
 __device__ __forceinline__ void mh_propose_node(const MhDev& M, const PropApply& A, int w, const double* H, const double* R, double& h_out,
                                                 double& r_out)

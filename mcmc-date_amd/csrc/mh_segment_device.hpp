@@ -582,6 +582,7 @@ __device__ __forceinline__ void seg_chain_wave(const MhDev& M, const PriorDev& P
     auto launch = [&](const PropApply& An, const double (&sc1n)[5], double lnqjn, double uaccn) __attribute__((always_inline)) {
         const int tag = (int)gs + 1;
         A = An;
+        mh_apply_scalars(A);
 #pragma unroll
         for (int i = 0; i < 5; ++i) sc1[i] = sc1n[i];
         lnqj = lnqjn;
