@@ -98,3 +98,18 @@ def test_one_rank_line_is_unchanged_in_shape(gpu):
     assert line["n_gpus"] == 1 and "ranks" not in line
     for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in line
+
+
+@pytest.mark.gpu
+def test_tuned_metropolis_hastings_line(gpu):
+    """`--kind mh --tune-periods T`: T auto-tuning periods before the clock (the reference samples with tuned proposals); the line says
+    which acceptance rate the timed steps had, and tuning moves it towards `mcmc`'s targets (0.23 .. 0.44) from the initial parameters' rate."""
+    rates = []
+    for periods in ("0", "12"):
+        line = _one_line(_run_bench(["--kind", "mh", "--sparse", "--dim", "60", "--chains", "64", "--steps", "1500", "--warmup", "100", "--tune-periods", periods,
+                                     "--no-cpu-baseline"]))
+        mh = line["mh"]
+        assert mh["tune_periods"] == int(periods) and 0.0 < mh["acceptance_rate"] < 1.0 and math.isfinite(line["value"]) and line["value"] > 0
+        assert "segments over a sparse precision matrix" in mh["what"]
+        rates.append(mh["acceptance_rate"])
+    assert 0.2 < rates[1] < 0.55 and abs(rates[1] - 0.35) < abs(rates[0] - 0.35) + 0.02, rates
