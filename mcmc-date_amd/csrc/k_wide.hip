@@ -23,7 +23,7 @@
 namespace mcd {
 
 template <int CT, bool TREE>
-__global__ void __launch_bounds__(64 * WD_WAVES, CT <= 2 ? 4 : 2) k_wide(MvnDev M, WideSrc A, int64_t batch, double* __restrict__ ll)
+__global__ void __launch_bounds__(64 * WD_WAVES, CT <= 2 ? (TREE ? 3 : 4) : 2) k_wide(MvnDev M, WideSrc A, int64_t batch, double* __restrict__ ll)   // (TREE: three blocks per CU -- at four the tree prologue spilled 8 registers)
 {
     extern __shared__ double smem[];
     double* rs = smem;                                   // [CT * 16][WD_LD]
