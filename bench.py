@@ -863,7 +863,7 @@ def main():
                 # ... and on BASELINE config 5's share of one GPU (1025-node tree, 512 chains; `--kind mh --dim 1024` is the full line)
                 try:
                     r5 = mh_measure(dev_index, 1024, 512, 4000, 400, repeats=2)
-                    out["mh_config5_share"] = {k: r5[k] for k in ("value", "unit", "us_per_lockstep", "n_nodes", "dimension", "chains", "lock_steps", "lds_bytes_per_workgroup", "what")}
+                    out["mh_config5_share"] = {k: r5[k] for k in ("value", "unit", "us_per_lockstep", "n_nodes", "dimension", "chains", "lock_steps", "lds_bytes_per_workgroup", "acceptance_rate", "what")}
                 except Exception as e:                       # (a secondary field must not take the line down)
                     out["mh_config5_share"] = {"error": repr(e)}
             if n == 256 and B == 512:
@@ -873,7 +873,7 @@ def main():
                     out["mh_sparse"] = []
                     for dim in (1024, 2012):
                         rs = mh_measure(dev_index, dim, 512, 4000, 400, sparse=True, repeats=2)
-                        out["mh_sparse"].append({k: rs[k] for k in ("value", "unit", "us_per_lockstep", "n_nodes", "dimension", "chains", "lock_steps", "likelihood", "lds_bytes_per_workgroup", "what")})
+                        out["mh_sparse"].append({k: rs[k] for k in ("value", "unit", "us_per_lockstep", "n_nodes", "dimension", "chains", "lock_steps", "likelihood", "lds_bytes_per_workgroup", "acceptance_rate", "what")})
                 except Exception as e:
                     out["mh_sparse"] = {"error": repr(e)}
         if world == 1 and args.kind == "logpdf" and not args.no_mh and B <= 1024:
