@@ -86,6 +86,17 @@ def test_options_table():
     assert M.get_option("MCD_MH_SEGMENTS") is None
     with pytest.raises(M.McdError):
         M.set_option("MCD_NO_SUCH_KNOB", 1)
+    # every knob the header names is in the table (and the table's names are the header's)
+    hdr = open(os.path.join(ROOT, "include", "mcmcdate_mvn.h")).read()
+    doc = hdr[hdr.index("Test and tuning knobs"):hdr.index("int mcd_set_option(")]
+    names = sorted(set(re.findall(r'"(MCD_[A-Z0-9_]+)"', doc)))
+    table = sorted(set(re.findall(r'"(MCD_[A-Z0-9_]+)"', open(os.path.join(ROOT, "mcmc-date_amd", "csrc", "options.cpp")).read())))
+    assert names == table, (sorted(set(names) ^ set(table)))
+    for nm in names:
+        M.set_option(nm, 1)
+        assert M.get_option(nm) == 1
+        M.set_option(nm, None)
+        assert M.get_option(nm) is None
     src = ""
     for f in os.listdir(os.path.join(ROOT, "mcmc-date_amd", "csrc")):
         if f.endswith((".hip", ".hpp", ".cpp", ".h")) and f not in ("options.cpp", "options.h"):
