@@ -23,6 +23,7 @@
 #include <memory>
 #include <random>
 #include <stdexcept>
+#include <optional>
 #include <string>
 #include <utility>
 #include <variant>
@@ -99,6 +100,20 @@ inline void check(int rc)
 struct MvnDeleter { void operator()(mcd_mvn_t* p) const { mcd_mvn_destroy(p); } };
 struct TreeDeleter { void operator()(mcd_tree_t* p) const { mcd_tree_destroy(p); } };
 }  // namespace detail
+
+// The library's test and tuning knobs (mcd_set_option: one explicit table instead of environment variables on the hot path; no counterpart
+// in the reference).  An empty optional puts a knob back to its default; getOption returns what is set.
+inline void setOption(const std::string& name, std::optional<int> value)
+{
+    const std::string v = value ? std::to_string(*value) : std::string();
+    detail::check(mcd_set_option(name.c_str(), value ? v.c_str() : nullptr));
+}
+inline std::optional<int> getOption(const std::string& name)
+{
+    int v = 0, is_set = 0;
+    detail::check(mcd_get_option(name.c_str(), &is_set, &v));
+    return is_set ? std::optional<int>(v) : std::nullopt;
+}
 
 // Kernel form of the log-density entry points: column sweep (latency form), matrix-core multiply (throughput form), or
 // by dimension and batch size (default).  No counterpart in the reference (one CPU code path); returns the previous form.

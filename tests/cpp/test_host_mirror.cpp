@@ -146,6 +146,16 @@ int main(int argc, char** argv)
         const double ll_m = fn(x), lj_m = lik.jacobianRootBranch(x);
         if (mcmcdate::setLogpdfForm(before) != mcmcdate::LogpdfForm::Multiply) return 1;
         if (std::fabs(ll_m - ll_ref) > 1e-10 * std::fmax(1.0, std::fabs(ll_ref)) || lj_m != lj) return 1;
+        // the knob table: set, read back, back to the default; unknown names are refused
+        mcmcdate::setOption("MCD_MH_SEGMENTS", 0);
+        if (mcmcdate::getOption("MCD_MH_SEGMENTS") != std::optional<int>(0)) return 1;
+        mcmcdate::setOption("MCD_MH_SEGMENTS", std::nullopt);
+        if (mcmcdate::getOption("MCD_MH_SEGMENTS").has_value()) return 1;
+        try {
+            mcmcdate::setOption("MCD_NO_SUCH_KNOB", 1);
+            return 1;
+        } catch (const std::runtime_error&) {
+        }
         // structural fault: trifurcating root -> exception with the reference's message
         mcmcdate::Topology bad;
         bad.parent = {-1, 0, 0, 0};
